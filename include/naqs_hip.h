@@ -1,0 +1,147 @@
+/*
+ * naqs_hip.h — C ABI of libnaqs_hip.so: the MI355X (gfx950) local-energy path of a
+ * neural-autoregressive-quantum-state VMC step.
+ *
+ * The reference (tomdbar/naqs-for-quantum-chemistry) has no C ABI of its own; its native seam is
+ * three Cython extension modules that its Python imports.  Every entry
+ * point below names the reference interface it replaces (file:line relative to the reference
+ * repository).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross the boundary;
+ *   - every function returns NAQS_OK (0) or a negative naqs_status; nothing throws;
+ *   - `*_dev` pointers are device memory on the handle's device and stay owned by the caller;
+ *   - all device work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream) and is asynchronous: results are valid after the stream is synchronised;
+ *   - a handle is bound to one device, owns its packed term tables and scratch buffers, and must
+ *     not be used from two streams/threads at the same time;
+ *   - bit-string convention: qubit q <-> bit q of the key; even bits = alpha spin-orbitals, odd
+ *     bits = beta (src/utils/hilbert.py:446-449, :573-581).
+ */
+#ifndef NAQS_HIP_H
+#define NAQS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAQS_ABI_VERSION 1
+
+typedef struct naqs_ham naqs_ham_t;
+
+enum naqs_status {
+    NAQS_OK = 0,
+    NAQS_ERR_INVALID = -1,      /* bad argument (NULL pointer, negative size, range outside table) */
+    NAQS_ERR_HIP = -2,          /* a HIP runtime call failed; see naqs_last_hip_error() */
+    NAQS_ERR_NOMEM = -3,        /* host or device allocation failed */
+    NAQS_ERR_UNSUPPORTED = -4,  /* e.g. n_qubits > 64, unsupported element width */
+    NAQS_ERR_NO_DEVICE = -5     /* no usable HIP device / wrong architecture */
+};
+
+/* How the wave function of the sampled states is handed over (second index: 2 components). */
+enum naqs_psi_kind {
+    NAQS_PSI_F32 = 0,     /* float  [M][2] = (Re psi, Im psi): what the reference passes, energy.py:241-243 */
+    NAQS_PSI_F64 = 1,     /* double [M][2] = (Re psi, Im psi) */
+    NAQS_LOGPSI_F32 = 2,  /* float  [M][2] = (log|psi|, phase): network output, wavefunction.py:167-183 */
+    NAQS_LOGPSI_F64 = 3   /* double [M][2] = (log|psi|, phase) */
+};
+
+int naqs_abi_version(void);
+const char *naqs_strerror(int status);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none) and its text. */
+int naqs_last_hip_error(void);
+const char *naqs_last_hip_error_string(void);
+
+/* Number of HIP devices visible to the library (0 when there is none); never fails. */
+int naqs_device_count(void);
+
+/*
+ * Host-only: group K Pauli terms by their XY (bit-flip) mask — the dedupe of
+ * src/optimizer/hamiltonian.py:248-252 (np.unique(XY, return_inverse)) turned into a CSR:
+ *   xy_g[Kxy] ascending unique masks, row_ptr[Kxy+1], and per-term yz_t[K], c_t[K], order[K]
+ *   (order[t] = original term index; terms keep ascending original order inside a group, so a
+ *   sequential sum over a group reproduces the reference's summation order, hamiltonian_math.pyx:95-98).
+ * Output arrays are caller-allocated with room for K (row_ptr: K+1) entries.
+ */
+int naqs_terms_group(int64_t K, const uint64_t *xy, const uint64_t *yz, const double *coeff,
+                     int64_t *Kxy_out, uint64_t *xy_g, int32_t *row_ptr,
+                     uint64_t *yz_t, double *c_t, int64_t *order);
+
+/*
+ * Create a device-resident Pauli Hamiltonian from K pre-processed terms
+ *   xy[k]   bit q set iff the Pauli on qubit q is X or Y      (hamiltonian.py:389-390)
+ *   yz[k]   bit q set iff the Pauli on qubit q is Y or Z      (hamiltonian.py:391-393, :402-403)
+ *   coeff[k] = Re(i^{nY}) * coefficient, real                 (hamiltonian.py:416, :424)
+ * host arrays, copied.  Replaces _PauliHamiltonianDynamic.__init__ (hamiltonian.py:241-262); the
+ * lazily cached scipy CSR matrix of the reference (hamiltonian.py:86, :350-363) has no counterpart:
+ * matrix elements are regenerated on the fly.
+ * n_alpha / n_beta: electrons per spin (particle-number filter, replaces the 2^N look-up table of
+ * src/utils/hilbert.py:429-434); pass -1/-1 for an unrestricted space.
+ */
+int naqs_ham_create(int n_qubits, int n_alpha, int n_beta, int64_t K,
+                    const uint64_t *xy, const uint64_t *yz, const double *coeff,
+                    int device, naqs_ham_t **out);
+int naqs_ham_destroy(naqs_ham_t *h);
+
+/* info[0..7] = { K, Kxy, n_qubits, n_alpha, n_beta, key_bits (32|64), diag_terms, device } */
+int naqs_ham_info(const naqs_ham_t *h, int64_t info[8]);
+
+/* Pre-size the scratch buffers for up to M sampled states (otherwise grown on demand, which
+ * synchronises the device). */
+int naqs_ham_reserve(naqs_ham_t *h, int64_t M);
+
+/*
+ * Local energies.  Replaces OptimizerBase.calculate_local_energy (src/optimizer/energy.py:219-263)
+ * = update_H (hamiltonian.py:272-370: get_Hij_cy + popcount_parity) + get_H (hamiltonian.py:93-111)
+ * + sparse_dense_mv (sparse_math.pyx:47-100), fused and matrix-free:
+ *
+ *   E_loc[i] = conj( sum_j H[i,j] psi[j] / psi[i] ),  j restricted to the M sampled states
+ *   H[i, key_i ^ xy_g] = sum_{k in g} coeff_k (-1)^{popcount(key_i & yz_k)}
+ *
+ * keys_dev[M]   unique sampled bit-strings (any order), all physical
+ * psi_dev       per psi_kind, [M][2]
+ * rows          E_loc is produced for table rows [row_begin, row_begin + n_rows) only — the shard of
+ *               one rank; couplings are still looked up in the whole table
+ * eloc_dev      double [n_rows][2] = (Re, Im)
+ */
+int naqs_eloc(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+              int64_t row_begin, int64_t n_rows, double *eloc_dev, void *stream);
+
+/*
+ * Weighted sums over n local energies, deterministic order:
+ *   out4_dev = { sum w Re(E), sum w Im(E), sum w Re(E)^2, sum w }
+ * from which <E> and Var follow as in _SGD_step (src/optimizer/energy.py:367-377).
+ */
+int naqs_eloc_reduce(naqs_ham_t *h, int64_t n, const double *w_dev, const double *eloc_dev,
+                     double *out4_dev, void *stream);
+
+/* ---- inner ring: device versions of the three Cython entry points the reference imports ---- */
+
+/* src.utils.hamiltonian_math.popcount_parity (hamiltonian_math.pyx:455-484):
+ * out[i] = 1 - 2*(popcount(arr[i]) & 1), arr of signed ints with elem_bytes in {2,4,8}. */
+int naqs_popcount_parity(const void *arr_dev, int elem_bytes, int64_t n, int8_t *out_dev, void *stream);
+
+/* src.utils.hamiltonian_math.get_Hij_cy (hamiltonian_math.pyx:198-288): dense matrix elements
+ * hij_dev[i*Kxy + g] = H[i, key_i ^ xy_g] for M states, row-major, bit-identical to the reference
+ * (same summation order). */
+int naqs_get_hij(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, double *hij_dev, void *stream);
+
+/* src.utils.sparse_math.sparse_dense_mv (sparse_math.pyx:47-100): CSR (f64 data, int32 indices)
+ * times complex128 vector; v_dev/out_dev are [.][2] = (Re, Im). */
+int naqs_csr_mv(int64_t rows, const double *data_dev, const int32_t *indices_dev,
+                const int32_t *indptr_dev, const double *v_dev, double *out_dev, void *stream);
+
+/* ---- measurement ---- */
+
+/* Record a hipEvent pair around every launch of the main E_loc kernel (up to max_records launches;
+ * 0 disables and frees the events). */
+int naqs_prof_enable(naqs_ham_t *h, int max_records);
+/* Synchronises the recorded events: total milliseconds and number of launches since enable. */
+int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAQS_HIP_H */

@@ -1,0 +1,742 @@
+// naqs_hip.hip — gfx950 (MI355X / CDNA4) kernels + the C ABI declared in include/naqs_hip.h.
+//
+// The path: for a batch of M unique sampled occupation bit-strings (keys) with their wave-function
+// values, generate the connected states key ^ xy_g of the packed Pauli Hamiltonian, look each one
+// up among the samples, regenerate the matrix element on the fly and reduce the local energy
+//   E_loc[i] = conj( sum_j H[i,j] psi[j] / psi[i] )
+// (reference: src/optimizer/energy.py:219-263, src/optimizer/hamiltonian.py:272-370,
+//  src_cpp/hamiltonian_math.pyx:85-100, src_cpp/sparse_math.pyx:85-100).
+//
+// Design (see DESIGN.md for the numbers):
+//   * terms are packed CSR-by-unique-XY mask; masks are 32-bit when n_qubits <= 32 (all BASELINE
+//     molecules), 64-bit otherwise (template parameter KT);
+//   * one 64-lane wavefront owns one sample at a time; lanes stride over the XY groups, whose masks
+//     (and, when they fit, the per-term YZ masks + coefficients) are staged once per workgroup in LDS;
+//   * candidates that break particle-number conservation are rejected with two popcounts
+//     (replaces the reference's 2^N look-up table), the rest are probed in an open-addressing hash
+//     table of the sample keys that a small prep kernel rebuilds every call (L2 resident);
+//   * hits are compacted across the wave (ballot + mbcnt) into a per-wave LDS queue so that the
+//     sign-sum loops run with full lanes; the diagonal group is evaluated wave-cooperatively;
+//   * per-sample result is a wave reduction (DPP shuffles) + one complex division.
+// Everything is integer/bit work plus a handful of f64 adds per hit: the bound is cache/HBM
+// traffic and issue rate, not MFMA, so there is deliberately no matrix-core code here.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "naqs_hip.h"
+
+#define NAQS_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local hipError_t g_last_hip = hipSuccess;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e__ = (expr);                       \
+        if (e__ != hipSuccess) {                       \
+            g_last_hip = e__;                          \
+            return NAQS_ERR_HIP;                       \
+        }                                              \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;                 // 4 waves: one per SIMD of a CU
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int QUEUE_CAP = 128;             // per-wave hit queue (needs 64 + 63 entries)
+constexpr int LDS_BUDGET = 64 * 1024;      // per-workgroup staging budget (160 KiB/CU -> >= 2 WGs/CU)
+
+template <typename KT> struct Slot;
+template <> struct Slot<uint32_t> { unsigned long long kv; };              // key << 32 | index
+template <> struct Slot<uint64_t> { unsigned long long key; uint32_t val; uint32_t pad; };
+
+__device__ __forceinline__ int popc(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int popc(uint64_t x) { return __popcll(x); }
+
+__device__ __forceinline__ uint32_t hash_key(uint32_t k, int bits) { return (k * 0x9E3779B1u) >> (32 - bits); }
+__device__ __forceinline__ uint32_t hash_key(uint64_t k, int bits) {
+    return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: narrow the keys, build the hash table, bring psi to f64 (re, im).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hash_insert(Slot<uint32_t> *tab, int bits, uint32_t key, uint32_t idx) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = hash_key(key, bits);
+    const unsigned long long packed = ((unsigned long long)key << 32) | idx;
+    for (;;) {
+        unsigned long long old = atomicCAS(&tab[h].kv, ~0ull, packed);
+        if (old == ~0ull) return;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ void hash_insert(Slot<uint64_t> *tab, int bits, uint64_t key, uint32_t idx) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = hash_key(key, bits);
+    for (;;) {
+        unsigned long long old = atomicCAS(&tab[h].key, ~0ull, (unsigned long long)key);
+        if (old == ~0ull) { tab[h].val = idx; return; }
+        h = (h + 1) & mask;
+    }
+}
+
+// returns the table index of `key`, or -1
+__device__ __forceinline__ int hash_find(const Slot<uint32_t> *__restrict__ tab, int bits, uint32_t key) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = hash_key(key, bits);
+    for (;;) {
+        const unsigned long long kv = tab[h].kv;
+        if (kv == ~0ull) return -1;
+        if ((uint32_t)(kv >> 32) == key) return (int)(uint32_t)kv;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ int hash_find(const Slot<uint64_t> *__restrict__ tab, int bits, uint64_t key) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t h = hash_key(key, bits);
+    for (;;) {
+        const Slot<uint64_t> s = tab[h];
+        if (s.key == ~0ull) return -1;
+        if (s.key == key) return (int)s.val;
+        h = (h + 1) & mask;
+    }
+}
+
+template <typename KT>
+__global__ __launch_bounds__(BLOCK) void prep_kernel(int64_t M, const uint64_t *__restrict__ keys,
+                                                     const void *__restrict__ psi_in, int psi_kind,
+                                                     KT *__restrict__ keys_out, double2 *__restrict__ psi_out,
+                                                     Slot<KT> *__restrict__ tab, int bits) {
+    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < M; i += (int64_t)gridDim.x * BLOCK) {
+        const KT k = (KT)keys[i];
+        keys_out[i] = k;
+        hash_insert(tab, bits, k, (uint32_t)i);
+        double a, b;
+        if (psi_kind == NAQS_PSI_F32 || psi_kind == NAQS_LOGPSI_F32) {
+            const float2 v = reinterpret_cast<const float2 *>(psi_in)[i];
+            a = (double)v.x; b = (double)v.y;
+        } else {
+            const double2 v = reinterpret_cast<const double2 *>(psi_in)[i];
+            a = v.x; b = v.y;
+        }
+        if (psi_kind == NAQS_LOGPSI_F32 || psi_kind == NAQS_LOGPSI_F64) {
+            const double amp = exp(a);
+            double s, c;
+            sincos(b, &s, &c);
+            a = amp * c; b = amp * s;
+        }
+        psi_out[i] = make_double2(a, b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main E_loc kernel
+// ------------------------------------------------------------------------------------------------
+template <typename KT>
+struct ElocParams {
+    // packed Hamiltonian
+    const KT *xy_g;          // [Kxy] ascending
+    const int32_t *row_ptr;  // [Kxy+1]
+    const KT *yz_t;          // [K]
+    const double *c_t;       // [K]
+    int32_t Kxy, K;
+    int32_t diag_group;      // index of the xy == 0 group or -1
+    KT alpha_mask, beta_mask;
+    int32_t n_alpha, n_beta; // < 0: no particle-number filter
+    // sample table
+    const KT *keys;          // [M]
+    const double2 *psi;      // [M]
+    const Slot<KT> *tab;
+    int32_t bits;
+    // rows to produce
+    int64_t row_begin, n_rows;
+    int32_t rows_per_block;
+    double2 *eloc;           // [n_rows]
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// a / b for complex f64 (Smith's algorithm, as numpy's complex128 division)
+__device__ __forceinline__ double2 cdiv(double2 a, double2 b) {
+    double2 q;
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double rat = b.y / b.x, scl = 1.0 / (b.x + b.y * rat);
+        q.x = (a.x + a.y * rat) * scl;
+        q.y = (a.y - a.x * rat) * scl;
+    } else {
+        const double rat = b.x / b.y, scl = 1.0 / (b.y + b.x * rat);
+        q.x = (a.x * rat + a.y) * scl;
+        q.y = (a.y * rat - a.x) * scl;
+    }
+    return q;
+}
+
+// sum_{t in [t0,t1)} c_t * (-1)^{popcount(key & yz_t)}, sequential, ascending t: the reference's
+// summation order for one matrix element (hamiltonian_math.pyx:95-98), so H_ij is bit-identical.
+template <typename KT>
+__device__ __forceinline__ double sign_sum(KT key, const KT *__restrict__ yz, const double *__restrict__ c,
+                                           int t0, int t1) {
+    double h = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const double ct = c[t];
+        h += (popc((KT)(key & yz[t])) & 1) ? -ct : ct;
+    }
+    return h;
+}
+
+template <typename KT, bool STAGE_GROUPS, bool STAGE_TERMS>
+__global__ __launch_bounds__(BLOCK) void eloc_kernel(const ElocParams<KT> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS layout: [c_t: K doubles][queue: WAVES*QUEUE_CAP int2][row_ptr: Kxy+1][xy: Kxy KT][yz: K KT]
+    double *s_c = reinterpret_cast<double *>(smem);
+    int2 *s_queue = reinterpret_cast<int2 *>(s_c + (STAGE_TERMS ? p.K : 0));
+    int32_t *s_rp = reinterpret_cast<int32_t *>(s_queue + WAVES_PER_BLOCK * QUEUE_CAP);
+    KT *s_xy = reinterpret_cast<KT *>(s_rp + (STAGE_GROUPS ? (p.Kxy + 2) & ~1 : 0));
+    KT *s_yz = s_xy + (STAGE_GROUPS ? p.Kxy : 0);
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+
+    if (STAGE_GROUPS) {
+        for (int g = tid; g < p.Kxy; g += BLOCK) s_xy[g] = p.xy_g[g];
+        for (int g = tid; g <= p.Kxy; g += BLOCK) s_rp[g] = p.row_ptr[g];
+    }
+    if (STAGE_TERMS) {
+        for (int t = tid; t < p.K; t += BLOCK) { s_yz[t] = p.yz_t[t]; s_c[t] = p.c_t[t]; }
+    }
+    if (STAGE_GROUPS || STAGE_TERMS) __syncthreads();
+
+    const KT *xy = STAGE_GROUPS ? s_xy : p.xy_g;
+    const int32_t *rp = STAGE_GROUPS ? s_rp : p.row_ptr;
+    const KT *yz = STAGE_TERMS ? s_yz : p.yz_t;
+    const double *cf = STAGE_TERMS ? s_c : p.c_t;
+    int2 *queue = s_queue + wave * QUEUE_CAP;
+
+    const int64_t blk_begin = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t blk_end = min(blk_begin + p.rows_per_block, p.n_rows);
+    const bool filter = p.n_alpha >= 0;
+
+    for (int64_t r = blk_begin + wave; r < blk_end; r += WAVES_PER_BLOCK) {
+        const int64_t i = p.row_begin + r;
+        const KT key = p.keys[i];             // wave-uniform
+        const double2 psi_i = p.psi[i];
+        double sr = 0.0, si = 0.0;
+
+        // diagonal group: all lanes share the terms
+        if (p.diag_group >= 0) {
+            const int t0 = rp[p.diag_group], t1 = rp[p.diag_group + 1];
+            double h = 0.0;
+            for (int t = t0 + lane; t < t1; t += WAVE) {
+                const double ct = cf[t];
+                h += (popc((KT)(key & yz[t])) & 1) ? -ct : ct;
+            }
+            sr = h * psi_i.x;
+            si = h * psi_i.y;
+        }
+
+        int qn = 0;  // wave-uniform number of queued hits
+        for (int g0 = 0; g0 < p.Kxy; g0 += WAVE) {
+            const int g = g0 + lane;
+            int idx = -1;
+            if (g < p.Kxy && g != p.diag_group) {
+                const KT j = key ^ xy[g];
+                const bool phys = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha &&
+                                              popc((KT)(j & p.beta_mask)) == p.n_beta);
+                if (phys) idx = hash_find(p.tab, p.bits, j);
+            }
+            const unsigned long long hits = __ballot(idx >= 0);
+            if (hits) {
+                if (idx >= 0) {
+                    const int pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0));
+                    queue[pos] = make_int2(g, idx);
+                }
+                qn += __popcll(hits);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= WAVE) {
+                    qn -= WAVE;
+                    const int2 e = queue[qn + lane];
+                    const double2 pj = p.psi[e.y];
+                    const double h = sign_sum<KT>(key, yz, cf, rp[e.x], rp[e.x + 1]);
+                    sr += h * pj.x;
+                    si += h * pj.y;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (lane < qn) {
+            const int2 e = queue[lane];
+            const double2 pj = p.psi[e.y];
+            const double h = sign_sum<KT>(key, yz, cf, rp[e.x], rp[e.x + 1]);
+            sr += h * pj.x;
+            si += h * pj.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        sr = wave_sum(sr);
+        si = wave_sum(si);
+        if (lane == 0) {
+            const double2 q = cdiv(make_double2(sr, si), psi_i);
+            p.eloc[r] = make_double2(q.x, -q.y);   // conj, energy.py:248
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weighted reduction (deterministic: fixed grid-stride order + LDS tree), one workgroup
+// ------------------------------------------------------------------------------------------------
+constexpr int RED_BLOCK = 1024;
+__global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(int64_t n, const double *__restrict__ w,
+                                                           const double2 *__restrict__ e, double *__restrict__ out4) {
+    __shared__ double s[4][RED_BLOCK / WAVE];
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int64_t i = threadIdx.x; i < n; i += RED_BLOCK) {
+        const double wi = w[i];
+        const double2 ei = e[i];
+        a += wi * ei.x; b += wi * ei.y; c += wi * ei.x * ei.x; d += wi;
+    }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s[0][wv] = a; s[1][wv] = b; s[2][wv] = c; s[3][wv] = d; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double t = 0;
+        for (int k = 0; k < RED_BLOCK / WAVE; ++k) t += s[threadIdx.x][k];
+        out4[threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inner-ring kernels
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void parity_kernel(const T *__restrict__ a, int64_t n, int8_t *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t v = (uint64_t)(int64_t)a[i];   // sign-extends like the C promotion in the reference
+        out[i] = (int8_t)(1 - 2 * (__popcll(v) & 1));
+    }
+}
+
+template <typename KT>
+__global__ __launch_bounds__(BLOCK) void hij_kernel(int64_t M, int32_t Kxy, const uint64_t *__restrict__ keys,
+                                                    const int32_t *__restrict__ rp, const KT *__restrict__ yz,
+                                                    const double *__restrict__ c, double *__restrict__ out) {
+    const int64_t total = M * (int64_t)Kxy;
+    for (int64_t e = blockIdx.x * (int64_t)BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = e / Kxy;
+        const int g = (int)(e - i * Kxy);
+        out[e] = sign_sum<KT>((KT)keys[i], yz, c, rp[g], rp[g + 1]);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void csr_mv_kernel(int64_t rows, const double *__restrict__ data,
+                                                       const int32_t *__restrict__ indices,
+                                                       const int32_t *__restrict__ indptr,
+                                                       const double2 *__restrict__ v, double2 *__restrict__ out) {
+    // one wavefront per row; lanes stride the row, fixed-order tree at the end
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (blockIdx.x * (int64_t)BLOCK + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    for (int64_t r = wave_id; r < rows; r += n_waves) {
+        double re = 0, im = 0;
+        for (int pidx = indptr[r] + lane; pidx < indptr[r + 1]; pidx += WAVE) {
+            const double d = data[pidx];
+            const double2 x = v[indices[pidx]];
+            re += d * x.x; im += d * x.y;
+        }
+        re = wave_sum(re); im = wave_sum(im);
+        if (lane == 0) out[r] = make_double2(re, im);
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct naqs_ham {
+    int device = 0;
+    int n_qubits = 0, n_alpha = -1, n_beta = -1;
+    int key_bits = 32;
+    int64_t K = 0, Kxy = 0;
+    int32_t diag_group = -1, diag_terms = 0;
+    uint64_t alpha_mask = 0, beta_mask = 0;
+    // device tables
+    void *d_xy = nullptr, *d_yz = nullptr;
+    int32_t *d_rp = nullptr;
+    double *d_c = nullptr;
+    // scratch
+    int64_t cap_M = 0;
+    void *d_keys = nullptr;
+    double2 *d_psi = nullptr;
+    void *d_tab = nullptr;
+    int64_t tab_slots = 0;
+    int cu_count = 256;
+    // profiling
+    std::vector<hipEvent_t> ev;
+    int64_t ev_used = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int init(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) return NAQS_ERR_NO_DEVICE;
+        if (prev != dev) {
+            HIP_TRY(hipSetDevice(dev));
+            switched = true;
+        }
+        return NAQS_OK;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+int table_bits(int64_t M) {
+    int bits = 10;
+    while ((1ll << bits) < 2 * M) ++bits;
+    return bits;
+}
+
+int ensure_scratch(naqs_ham *h, int64_t M) {
+    if (M <= h->cap_M) return NAQS_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->d_keys) (void)hipFree(h->d_keys);
+    if (h->d_psi) (void)hipFree(h->d_psi);
+    if (h->d_tab) (void)hipFree(h->d_tab);
+    h->d_keys = nullptr; h->d_psi = nullptr; h->d_tab = nullptr; h->cap_M = 0;
+    const int64_t cap = std::max<int64_t>(1024, M + M / 4);
+    const size_t kb = h->key_bits / 8;
+    const size_t slot = h->key_bits == 32 ? sizeof(Slot<uint32_t>) : sizeof(Slot<uint64_t>);
+    h->tab_slots = 1ll << table_bits(cap);
+    HIP_TRY(hipMalloc(&h->d_keys, cap * kb));
+    HIP_TRY(hipMalloc((void **)&h->d_psi, cap * sizeof(double2)));
+    HIP_TRY(hipMalloc(&h->d_tab, h->tab_slots * slot));
+    h->cap_M = cap;
+    return NAQS_OK;
+}
+
+template <typename KT>
+int upload_tables(naqs_ham *h, const std::vector<uint64_t> &xy_g, const std::vector<int32_t> &rp,
+                  const std::vector<uint64_t> &yz_t, const std::vector<double> &c_t) {
+    std::vector<KT> xy_n(xy_g.begin(), xy_g.end()), yz_n(yz_t.begin(), yz_t.end());
+    HIP_TRY(hipMalloc(&h->d_xy, std::max<size_t>(1, xy_n.size()) * sizeof(KT)));
+    HIP_TRY(hipMalloc(&h->d_yz, std::max<size_t>(1, yz_n.size()) * sizeof(KT)));
+    HIP_TRY(hipMalloc((void **)&h->d_rp, rp.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_c, std::max<size_t>(1, c_t.size()) * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_xy, xy_n.data(), xy_n.size() * sizeof(KT), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_yz, yz_n.data(), yz_n.size() * sizeof(KT), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_rp, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_c, c_t.data(), c_t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return NAQS_OK;
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+template <typename KT>
+int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                int64_t row_begin, int64_t n_rows, double *eloc_dev, hipStream_t s) {
+    const int bits = table_bits(M);
+    auto *tab = reinterpret_cast<Slot<KT> *>(h->d_tab);
+    HIP_TRY(hipMemsetAsync(tab, 0xFF, (size_t)(1ll << bits) * sizeof(Slot<KT>), s));
+    {
+        const int grid = (int)std::min<int64_t>((M + BLOCK - 1) / BLOCK, 4 * h->cu_count);
+        hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
+                           reinterpret_cast<KT *>(h->d_keys), h->d_psi, tab, bits);
+        HIP_TRY(hipGetLastError());
+    }
+
+    ElocParams<KT> p;
+    p.xy_g = reinterpret_cast<const KT *>(h->d_xy);
+    p.row_ptr = h->d_rp;
+    p.yz_t = reinterpret_cast<const KT *>(h->d_yz);
+    p.c_t = h->d_c;
+    p.Kxy = (int32_t)h->Kxy; p.K = (int32_t)h->K;
+    p.diag_group = h->diag_group;
+    p.alpha_mask = (KT)h->alpha_mask; p.beta_mask = (KT)h->beta_mask;
+    p.n_alpha = h->n_alpha; p.n_beta = h->n_beta;
+    p.keys = reinterpret_cast<const KT *>(h->d_keys);
+    p.psi = h->d_psi;
+    p.tab = tab; p.bits = bits;
+    p.row_begin = row_begin; p.n_rows = n_rows;
+    p.eloc = reinterpret_cast<double2 *>(eloc_dev);
+
+    // workgroups: aim at >= 8 per CU so that every SIMD holds several waves (latency hiding), but
+    // keep at least one row per wave
+    int rpb = env_int("NAQS_ROWS_PER_BLOCK", 0);
+    if (rpb <= 0) {
+        const int64_t target_blocks = (int64_t)h->cu_count * 8;
+        rpb = (int)std::max<int64_t>(WAVES_PER_BLOCK, (n_rows + target_blocks - 1) / target_blocks);
+        rpb = (rpb + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+    }
+    p.rows_per_block = rpb;
+    const int grid = (int)((n_rows + rpb - 1) / rpb);
+
+    const size_t q_bytes = WAVES_PER_BLOCK * QUEUE_CAP * sizeof(int2);
+    const size_t g_bytes = (size_t)((h->Kxy + 2) & ~1ll) * sizeof(int32_t) + (size_t)h->Kxy * sizeof(KT);
+    const size_t t_bytes = (size_t)h->K * (sizeof(double) + sizeof(KT));
+    const int force = env_int("NAQS_STAGE", -1);   // tuning/testing: 0 none, 1 groups, 2 groups+terms
+    int stage = (q_bytes + g_bytes + t_bytes <= (size_t)LDS_BUDGET) ? 2 : (q_bytes + g_bytes <= (size_t)LDS_BUDGET ? 1 : 0);
+    if (force >= 0 && force < stage) stage = force;
+
+    const bool prof = !h->ev.empty() && h->ev_used + 2 <= (int64_t)h->ev.size();
+    if (prof) HIP_TRY(hipEventRecord(h->ev[h->ev_used], s));
+    if (stage == 2)
+        hipLaunchKernelGGL((eloc_kernel<KT, true, true>), dim3(grid), dim3(BLOCK), q_bytes + g_bytes + t_bytes, s, p);
+    else if (stage == 1)
+        hipLaunchKernelGGL((eloc_kernel<KT, true, false>), dim3(grid), dim3(BLOCK), q_bytes + g_bytes, s, p);
+    else
+        hipLaunchKernelGGL((eloc_kernel<KT, false, false>), dim3(grid), dim3(BLOCK), q_bytes, s, p);
+    HIP_TRY(hipGetLastError());
+    if (prof) { HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
+    return NAQS_OK;
+}
+
+}  // namespace
+
+NAQS_API int naqs_abi_version(void) { return NAQS_ABI_VERSION; }
+
+NAQS_API const char *naqs_strerror(int status) {
+    switch (status) {
+        case NAQS_OK: return "ok";
+        case NAQS_ERR_INVALID: return "invalid argument";
+        case NAQS_ERR_HIP: return "HIP runtime error (see naqs_last_hip_error_string)";
+        case NAQS_ERR_NOMEM: return "out of memory";
+        case NAQS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case NAQS_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return "unknown naqs status";
+    }
+}
+
+NAQS_API int naqs_last_hip_error(void) { return (int)g_last_hip; }
+NAQS_API const char *naqs_last_hip_error_string(void) { return hipGetErrorString(g_last_hip); }
+
+NAQS_API int naqs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+NAQS_API int naqs_terms_group(int64_t K, const uint64_t *xy, const uint64_t *yz, const double *coeff,
+                              int64_t *Kxy_out, uint64_t *xy_g, int32_t *row_ptr,
+                              uint64_t *yz_t, double *c_t, int64_t *order) {
+    if (K < 0 || !Kxy_out || !row_ptr) return NAQS_ERR_INVALID;
+    if (K > 0 && (!xy || !yz || !coeff || !xy_g || !yz_t || !c_t)) return NAQS_ERR_INVALID;
+    if (K >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    std::vector<int64_t> perm((size_t)K);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return xy[a] < xy[b]; });
+    int64_t ng = 0;
+    for (int64_t t = 0; t < K; ++t) {
+        const int64_t k = perm[(size_t)t];
+        if (t == 0 || xy[k] != xy_g[ng - 1]) { xy_g[ng] = xy[k]; row_ptr[ng] = (int32_t)t; ++ng; }
+        yz_t[t] = yz[k];
+        c_t[t] = coeff[k];
+        if (order) order[t] = k;
+    }
+    row_ptr[ng] = (int32_t)K;
+    *Kxy_out = ng;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_ham_create(int n_qubits, int n_alpha, int n_beta, int64_t K,
+                             const uint64_t *xy, const uint64_t *yz, const double *coeff,
+                             int device, naqs_ham_t **out) {
+    if (!out) return NAQS_ERR_INVALID;
+    *out = nullptr;
+    if (n_qubits <= 0 || K < 0 || (K > 0 && (!xy || !yz || !coeff))) return NAQS_ERR_INVALID;
+    if (n_qubits > 64 || K >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    if ((n_alpha < 0) != (n_beta < 0)) return NAQS_ERR_INVALID;
+    if (n_alpha > (n_qubits + 1) / 2 || n_beta > n_qubits / 2) return NAQS_ERR_INVALID;
+    const uint64_t full = n_qubits == 64 ? ~0ull : ((1ull << n_qubits) - 1ull);
+    for (int64_t k = 0; k < K; ++k)
+        if ((xy[k] | yz[k]) & ~full) return NAQS_ERR_INVALID;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NAQS_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return NAQS_ERR_INVALID;
+
+    naqs_ham *h = new (std::nothrow) naqs_ham();
+    if (!h) return NAQS_ERR_NOMEM;
+    h->device = device;
+    h->n_qubits = n_qubits; h->n_alpha = n_alpha; h->n_beta = n_beta;
+    h->key_bits = n_qubits <= 32 ? 32 : 64;
+    h->K = K;
+    for (int q = 0; q < n_qubits; ++q) ((q & 1) ? h->beta_mask : h->alpha_mask) |= 1ull << q;
+
+    std::vector<uint64_t> xy_g((size_t)std::max<int64_t>(K, 1)), yz_t((size_t)std::max<int64_t>(K, 1));
+    std::vector<int32_t> rp((size_t)K + 1);
+    std::vector<double> c_t((size_t)std::max<int64_t>(K, 1));
+    int64_t Kxy = 0;
+    int st = naqs_terms_group(K, xy, yz, coeff, &Kxy, xy_g.data(), rp.data(), yz_t.data(), c_t.data(), nullptr);
+    if (st != NAQS_OK) { delete h; return st; }
+    xy_g.resize((size_t)Kxy); rp.resize((size_t)Kxy + 1); yz_t.resize((size_t)K); c_t.resize((size_t)K);
+    h->Kxy = Kxy;
+    if (Kxy > 0 && xy_g[0] == 0) { h->diag_group = 0; h->diag_terms = rp[1] - rp[0]; }
+
+    DeviceGuard guard;
+    st = guard.init(device);
+    if (st == NAQS_OK) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
+        st = h->key_bits == 32 ? upload_tables<uint32_t>(h, xy_g, rp, yz_t, c_t)
+                               : upload_tables<uint64_t>(h, xy_g, rp, yz_t, c_t);
+    }
+    if (st != NAQS_OK) { naqs_ham_destroy(h); return st; }
+    *out = h;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_ham_destroy(naqs_ham_t *h) {
+    if (!h) return NAQS_OK;
+    DeviceGuard guard;
+    (void)guard.init(h->device);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_c, h->d_keys, h->d_psi, h->d_tab};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_ham_info(const naqs_ham_t *h, int64_t info[8]) {
+    if (!h || !info) return NAQS_ERR_INVALID;
+    info[0] = h->K; info[1] = h->Kxy; info[2] = h->n_qubits; info[3] = h->n_alpha; info[4] = h->n_beta;
+    info[5] = h->key_bits; info[6] = h->diag_terms; info[7] = h->device;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_ham_reserve(naqs_ham_t *h, int64_t M) {
+    if (!h || M < 0) return NAQS_ERR_INVALID;
+    if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    DeviceGuard guard;
+    int st = guard.init(h->device);
+    if (st != NAQS_OK) return st;
+    return ensure_scratch(h, M);
+}
+
+NAQS_API int naqs_eloc(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                       int64_t row_begin, int64_t n_rows, double *eloc_dev, void *stream) {
+    if (!h || M < 0 || row_begin < 0 || n_rows < 0 || row_begin + n_rows > M) return NAQS_ERR_INVALID;
+    if (psi_kind < NAQS_PSI_F32 || psi_kind > NAQS_LOGPSI_F64) return NAQS_ERR_INVALID;
+    if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    if (n_rows == 0) return NAQS_OK;
+    if (!keys_dev || !psi_dev || !eloc_dev) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(h->device);
+    if (st != NAQS_OK) return st;
+    st = ensure_scratch(h, M);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return h->key_bits == 32
+               ? launch_eloc<uint32_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, s)
+               : launch_eloc<uint64_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, s);
+}
+
+NAQS_API int naqs_eloc_reduce(naqs_ham_t *h, int64_t n, const double *w_dev, const double *eloc_dev,
+                              double *out4_dev, void *stream) {
+    if (!h || n < 0 || !out4_dev || (n > 0 && (!w_dev || !eloc_dev))) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(h->device);
+    if (st != NAQS_OK) return st;
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(RED_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), n, w_dev,
+                       reinterpret_cast<const double2 *>(eloc_dev), out4_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_popcount_parity(const void *arr_dev, int elem_bytes, int64_t n, int8_t *out_dev, void *stream) {
+    if (n < 0 || (n > 0 && (!arr_dev || !out_dev))) return NAQS_ERR_INVALID;
+    if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return NAQS_ERR_UNSUPPORTED;
+    if (n == 0) return NAQS_OK;
+    const int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, 8192);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(parity_kernel<int16_t>, dim3(grid), dim3(BLOCK), 0, s, (const int16_t *)arr_dev, n, out_dev);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(parity_kernel<int32_t>, dim3(grid), dim3(BLOCK), 0, s, (const int32_t *)arr_dev, n, out_dev);
+    else
+        hipLaunchKernelGGL(parity_kernel<int64_t>, dim3(grid), dim3(BLOCK), 0, s, (const int64_t *)arr_dev, n, out_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_get_hij(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, double *hij_dev, void *stream) {
+    if (!h || M < 0 || (M > 0 && (!keys_dev || !hij_dev))) return NAQS_ERR_INVALID;
+    if (M == 0 || h->Kxy == 0) return NAQS_OK;
+    DeviceGuard guard;
+    int st = guard.init(h->device);
+    if (st != NAQS_OK) return st;
+    const int64_t total = M * h->Kxy;
+    const int grid = (int)std::min<int64_t>((total + BLOCK - 1) / BLOCK, 16384);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (h->key_bits == 32)
+        hipLaunchKernelGGL(hij_kernel<uint32_t>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)h->Kxy, keys_dev, h->d_rp,
+                           (const uint32_t *)h->d_yz, h->d_c, hij_dev);
+    else
+        hipLaunchKernelGGL(hij_kernel<uint64_t>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)h->Kxy, keys_dev, h->d_rp,
+                           (const uint64_t *)h->d_yz, h->d_c, hij_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_csr_mv(int64_t rows, const double *data_dev, const int32_t *indices_dev,
+                         const int32_t *indptr_dev, const double *v_dev, double *out_dev, void *stream) {
+    if (rows < 0 || (rows > 0 && (!indptr_dev || !v_dev || !out_dev))) return NAQS_ERR_INVALID;
+    if (rows == 0) return NAQS_OK;
+    const int grid = (int)std::min<int64_t>((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 8192);
+    hipLaunchKernelGGL(csr_mv_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows,
+                       data_dev, indices_dev, indptr_dev, reinterpret_cast<const double2 *>(v_dev),
+                       reinterpret_cast<double2 *>(out_dev));
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_prof_enable(naqs_ham_t *h, int max_records) {
+    if (!h || max_records < 0) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(h->device);
+    if (st != NAQS_OK) return st;
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->ev_used = 0;
+    for (int i = 0; i < 2 * max_records; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches) {
+    if (!h || !total_ms || !launches) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(h->device);
+    if (st != NAQS_OK) return st;
+    double tot = 0;
+    for (int64_t i = 0; i + 1 < h->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = h->ev_used / 2;
+    h->ev_used = 0;
+    return NAQS_OK;
+}

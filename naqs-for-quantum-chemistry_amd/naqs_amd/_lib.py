@@ -1,0 +1,82 @@
+"""ctypes binding of ``include/naqs_hip.h``.
+
+The product path has no CPU fallback: if ``libnaqs_hip.so`` is missing or does not export
+the ABI, importing a compute entry point raises ``NaqsError`` loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_DIR = os.path.join(os.path.dirname(_HERE), "lib")
+
+NAQS_OK = 0
+PSI_F32, PSI_F64, LOGPSI_F32, LOGPSI_F64 = 0, 1, 2, 3
+
+c_i64, c_u64p, c_f64p, c_vp = ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+
+# symbol -> (restype, argtypes); mirrors include/naqs_hip.h one-to-one (tests/test_abi.py checks it)
+SIGNATURES = {
+    "naqs_abi_version": (ctypes.c_int, []),
+    "naqs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "naqs_last_hip_error": (ctypes.c_int, []),
+    "naqs_last_hip_error_string": (ctypes.c_char_p, []),
+    "naqs_device_count": (ctypes.c_int, []),
+    "naqs_terms_group": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_ham_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_vp, c_vp, c_vp,
+                                       ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "naqs_ham_destroy": (ctypes.c_int, [c_vp]),
+    "naqs_ham_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64 * 8)]),
+    "naqs_ham_reserve": (ctypes.c_int, [c_vp, c_i64]),
+    "naqs_eloc": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp]),
+    "naqs_eloc_reduce": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_popcount_parity": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
+    "naqs_get_hij": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "naqs_csr_mv": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "naqs_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+}
+
+
+class NaqsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path():
+    return os.environ.get("NAQS_HIP_LIB", os.path.join(_LIB_DIR, "libnaqs_hip.so"))
+
+
+def load_library():
+    """Load libnaqs_hip.so and type its entry points.  Raises NaqsError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NaqsError(f"{path} not found: build it with `make -C naqs-for-quantum-chemistry_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no CPU fallback for the product path")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise NaqsError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NaqsError(f"{path} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.naqs_abi_version() != 1:
+        raise NaqsError(f"{path}: ABI version {lib.naqs_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != NAQS_OK:
+        lib = load_library()
+        msg = lib.naqs_strerror(status).decode()
+        if status == -2:
+            msg += ": " + lib.naqs_last_hip_error_string().decode()
+        raise NaqsError(f"{what} failed: {msg} ({status})")

@@ -1,0 +1,298 @@
+"""Generate the golden vectors in ``tests/golden/*.npz`` from the REFERENCE itself.
+
+TEST INFRASTRUCTURE — runs only in the build container (needs ``/root/reference``);
+``python tests/golden/make_golden.py`` regenerates every fixture.  The reference is
+imported through ``ref_harness`` (scratch copy + shims); only
+arrays (inputs and the reference's outputs) are written — no reference source.
+
+Fixtures
+  ham_<mol>.npz    packed Pauli terms exactly as hamiltonian.py:373-430 / :248-252 produce them
+  eloc_<mol>.npz   fixed sample sets + psi -> calculate_local_energy (energy.py:219-263), the
+                   complex128 result *before* the float32 cast and the float32 tensor returned,
+                   plus the inner-ring intermediates (popcount_parity, get_Hij_cy, H_sub CSR,
+                   sparse_dense_mv) on a small subset
+  nade_<mol>.npz   NADE state_dict, states -> log_psi (wavefunction.py:167-183), one sampler draw
+                   (statistical use only) and the scalars / gradients of one _SGD_step
+                   (energy.py:273-377)
+  kat.json         physics known answers (FCI energies through the reference path) + timings
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+rh.setup()
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+import scipy.sparse.linalg as spla  # noqa: E402
+
+import src.utils.complex as cplx  # noqa: E402
+from src.naqs.network.activations import SoftmaxLogProbAmps  # noqa: E402
+from src.naqs.network.base import InputEncoding, NadeMasking  # noqa: E402
+from src.naqs.wavefunction import NAQSComplex_NADE_orbitals  # noqa: E402
+from src.optimizer.energy import PartialSamplingOptimizer  # noqa: E402
+from src.optimizer.hamiltonian import PauliHamiltonian, _PauliHamiltonianDynamic  # noqa: E402
+from src.utils.hamiltonian_math import get_Hij_cy, popcount_parity  # noqa: E402
+from src.utils.hilbert import Encoding, Hilbert  # noqa: E402
+from src.utils.sparse_math import sparse_dense_mv  # noqa: E402
+from src.utils.system import set_global_seed  # noqa: E402
+
+N2_SWEEP = ["N2_0.75", "N2_0.9", "N2_1.05", "N2_1.2", "N2_1.35", "N2_1.5", "N2_1.65", "N2_1.8",
+            "N2_1.95", "N2_2.1", "N2_2.25"]
+
+
+def electrons(mol):
+    return rh.ELECTRONS["N2" if mol.startswith("N2") else mol]
+
+
+def make_hilbert(mol, qh):
+    N = rh.n_qubits_of(qh)
+    na, nb = electrons(mol)
+    return Hilbert.get(N, na, nb, encoding=Encoding.SIGNED, make_basis=True)
+
+
+class _StubHilbert:
+    """Just enough of _HilbertRestricted for __calc_coupling_info (Li2O: the real one needs >25 GB)."""
+
+    def __init__(self, N):
+        self.N, self.N_occ, self.encoding = N, 0, Encoding.SIGNED
+        self._idx_np_dtype = np.int16 if N < 16 else (np.int32 if N < 30 else np.int64)
+        self._idx_torch_dtype = {np.int16: torch.int16, np.int32: torch.int32,
+                                 np.int64: torch.int64}[self._idx_np_dtype]
+        self._idx_basis_vec = torch.tensor([2 ** n for n in range(N)], dtype=self._idx_torch_dtype)
+        self.size = 1
+
+    def to_idx_array(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.numpy()
+        return np.asarray(idx).astype(self._idx_np_dtype)
+
+    def get_idx_dtype(self, kind="torch"):
+        return self._idx_np_dtype if kind in ("np", "numpy") else self._idx_torch_dtype
+
+    def full2restricted_idx(self, idx):
+        return idx
+
+
+def pack_hamiltonian(mol, ph, hilbert_N, out):
+    na, nb = electrons(mol)
+    np.savez_compressed(
+        out,
+        n_qubits=np.int64(hilbert_N), n_alpha=np.int64(na), n_beta=np.int64(nb),
+        xy=ph.XY_sites_idx.astype(np.uint64), yz=ph.YZ_sites_idx.astype(np.uint64),
+        coeff=ph.couplings.squeeze().astype(np.float64),
+        unique_xy=ph._unique_XY_sites_idx.astype(np.uint64),
+        unique2all_xy=ph._unique2all_XY_sites_idx.astype(np.int64),
+        unique_yz=ph._unique_YZ_sites_idx.astype(np.uint64),
+        unique2all_yz=ph._unique2all_YZ_sites_idx.astype(np.int64))
+
+
+def gen_ham_only(mol):
+    """Term packing through the reference's own pre-processing, with a stub Hilbert space."""
+    qh = rh.load_qubit_hamiltonian(mol)
+    N = rh.n_qubits_of(qh)
+    ph = object.__new__(_PauliHamiltonianDynamic)
+    ph.hilbert, ph.qubit_hamiltonian = _StubHilbert(N), qh
+    ph.n_excitations_max, ph.dtype, ph.verbose = None, np.float64, False
+    ph.XY_sites_idx, ph.YZ_sites_idx, ph.couplings = ph._PauliHamiltonianDynamic__calc_coupling_info()
+    ph._unique_XY_sites_idx, ph._unique2all_XY_sites_idx = np.unique(ph.XY_sites_idx, return_inverse=True)
+    ph._unique_YZ_sites_idx, ph._unique2all_YZ_sites_idx = np.unique(ph.YZ_sites_idx, return_inverse=True)
+    pack_hamiltonian(mol, ph, N, os.path.join(HERE, f"ham_{mol}.npz"))
+    print(f"[ham] {mol}: N={N} K={len(ph.couplings)} Kxy={len(ph._unique_XY_sites_idx)} "
+          f"Kyz={len(ph._unique_YZ_sites_idx)}")
+
+
+def wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking=NadeMasking.PARTIAL):
+    # experiments/_base.py:150-187 with the published flags (batch_train.sh:14)
+    return dict(qubit_ordering=-1, masking=masking, num_lut=0, input_encoding=InputEncoding.BINARY,
+                amp_hidden_size=[n_hid], amp_hidden_activation=nn.ReLU, amp_bias=True,
+                phase_hidden_size=[n_hid_phase] * n_layer_phase, phase_hidden_activation=nn.ReLU,
+                phase_bias=True, combined_amp_phase_blocks=False, use_amp_spin_sym=True,
+                use_phase_spin_sym=False, aggregate_phase=False, amp_batch_norm=False,
+                phase_batch_norm=False, batch_norm_momentum=1, amp_activation=SoftmaxLogProbAmps,
+                phase_activation=None, n_alpha_electrons=na, n_beta_electrons=nb)
+
+
+def make_optimizer(wf, qh, na, nb, n_samples):
+    # experiments/_base.py:209-246
+    return PartialSamplingOptimizer(
+        n_samples=n_samples, n_samples_max=1e12, n_unq_samples_min=10, n_unq_samples_max=1e5,
+        log_exact_energy=False, wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False,
+        n_electrons=na + nb, n_alpha_electrons=na, n_beta_electrons=nb, n_fixed_electrons=None,
+        n_excitations_max=None, reweight_samples_by_psi=False, normalise_psi=True,
+        normalize_grads=False, grad_clip_factor=None, grad_clip_memory_length=50,
+        optimizer=torch.optim.Adam,
+        optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'weight_decay': 0, 'eps': 1e-15,
+                         'amsgrad': False}, {'lr': 1e-2}],
+        save_loc="/tmp/golden_out", pauli_hamiltonian_fname=None, overwrite_pauli_hamiltonian=True,
+        pauli_hamiltonian_dtype=np.float64, verbose=False)
+
+
+def synthetic_psi(M, sigma, seed=4321):
+    """SURVEY 8d recipe: log|psi| ~ N(-ln(M)/2, sigma), phase ~ U[0, 2pi); float32 like the reference."""
+    rs = np.random.RandomState(seed)
+    la = rs.normal(-0.5 * np.log(M), sigma, size=M)
+    ph = rs.uniform(0, 2 * np.pi, size=M)
+    log_psi = torch.tensor(np.stack([la, ph], -1), dtype=torch.float32)
+    return log_psi, cplx.exp(log_psi)            # psi exactly as _SGD_step builds it (energy.py:310)
+
+
+def fresh_pauli(opt):
+    """A cold _PauliHamiltonianDynamic, built the way OptimizerBase.__init__ does (energy.py:115-125)."""
+    restricted = opt.hilbert.get_subspace(ret_states=False, ret_idxs=True, **opt.subspace_args)
+    return PauliHamiltonian.get(opt.hilbert, opt.qubit_hamiltonian, hamiltonian_fname=None,
+                                restricted_idxs=restricted, verbose=False, n_excitations_max=None,
+                                dtype=np.float64)
+
+
+def gen_molecule(mol, M_sets, nade_cfg, seed=111, kat=None, time_it=False):
+    set_global_seed(seed)
+    qh = rh.load_qubit_hamiltonian(mol)
+    na, nb = electrons(mol)
+    hil = make_hilbert(mol, qh)
+    N = hil.N
+    wf = NAQSComplex_NADE_orbitals(hil, **wavefunction_args(na, nb, *nade_cfg))
+    opt = make_optimizer(wf, qh, na, nb, n_samples=1000)
+    ph = opt.pauli_hamiltonian
+    pack_hamiltonian(mol, ph, N, os.path.join(HERE, f"ham_{mol}.npz"))
+    all_keys = hil.restricted2full_basis_idxs.numpy().astype(np.int64)
+
+    # ---------------- E_loc goldens on fixed synthetic sample sets ----------------
+    out = {}
+    for tag, (M, sigma) in M_sets.items():
+        keys = np.sort(np.random.RandomState(1234).choice(all_keys, M, replace=False))
+        log_psi, psi = synthetic_psi(M, sigma)
+        opt.pauli_hamiltonian = fresh_pauli(opt)
+        idx = hil.to_idx_tensor(keys)
+        e128 = opt.calculate_local_energy(idx, psi=psi, ret_complex=True)
+        e32 = opt.calculate_local_energy(idx, psi=psi, ret_complex=False).numpy()
+        out.update({f"{tag}_keys": keys.astype(np.uint64), f"{tag}_log_psi_f32": log_psi.numpy(),
+                    f"{tag}_psi_f32": psi.numpy(), f"{tag}_eloc_c128": e128, f"{tag}_eloc_f32": e32})
+        print(f"[eloc] {mol}/{tag}: M={M} <E_loc>={e128.real.mean():.6f}")
+
+    # ---------------- inner ring on a small subset ----------------
+    Ms = min(48, len(all_keys) // 2)
+    keys_s = np.sort(np.random.RandomState(99).choice(all_keys, Ms, replace=False))
+    idx_s = hil.to_idx_array(keys_s)
+    P_bits = np.bitwise_and(idx_s[:, None], ph._unique_YZ_sites_idx[None, :])
+    P = popcount_parity(P_bits)
+    Hij = get_Hij_cy(idx_s, ph._unique_XY_sites_idx, ph._unique2all_XY_sites_idx, P,
+                     ph._unique2all_YZ_sites_idx, ph.couplings.squeeze())
+    opt.pauli_hamiltonian = fresh_pauli(opt)
+    opt.pauli_hamiltonian.update_H(hil.to_idx_tensor(keys_s), check_unseen=True, assume_unique=True)
+    Hs = opt.pauli_hamiltonian.get_H(hil.to_idx_tensor(keys_s)).tocsr()
+    Hs.sort_indices()
+    _, psi_s = synthetic_psi(Ms, 1.0, seed=7)
+    v = cplx.torch_to_numpy(psi_s)
+    mv = sparse_dense_mv(Hs, v)
+    out.update(dict(ring_keys=keys_s.astype(np.uint64), ring_P=np.asarray(P), ring_Hij=np.asarray(Hij),
+                    ring_csr_data=Hs.data, ring_csr_indices=Hs.indices.astype(np.int32),
+                    ring_csr_indptr=Hs.indptr.astype(np.int32), ring_v=v, ring_mv=mv))
+    # popcount_parity dtype coverage (hamiltonian_math.pyx:455-484)
+    rs = np.random.RandomState(5)
+    for dt in (np.int16, np.int32, np.int64):
+        arr = rs.randint(0, np.iinfo(dt).max, size=(7, 33), dtype=np.int64).astype(dt)
+        out[f"pp_in_{np.dtype(dt).name}"] = arr
+        out[f"pp_out_{np.dtype(dt).name}"] = np.asarray(popcount_parity(arr))
+    np.savez_compressed(os.path.join(HERE, f"eloc_{mol}.npz"), **out)
+
+    # ---------------- NADE: log_psi, sampler draw, one SGD step ----------------
+    nd = {"cfg_n_hid": nade_cfg[0], "cfg_n_hid_phase": nade_cfg[1], "cfg_n_layer_phase": nade_cfg[2],
+          "seed": seed}
+    for k, v_ in wf.model.state_dict().items():
+        nd["sd:" + k] = v_.detach().numpy().copy()
+    B = min(512, len(all_keys))
+    sel = np.sort(np.random.RandomState(3).choice(len(all_keys), B, replace=False))
+    states_eval = hil.basis_states[sel]
+    with torch.no_grad():
+        lp_eval = wf.log_psi(states_eval).numpy()
+        cond = wf._evaluate_log_psi(states_eval, gather_state=False).numpy()   # [B, N/2, 4, 2]
+    nd.update(eval_states=states_eval.numpy(), eval_keys=all_keys[sel].astype(np.uint64),
+              eval_log_psi=lp_eval, eval_cond=cond)
+
+    opt.pauli_hamiltonian = fresh_pauli(opt)
+    n_draw = 2000 if len(all_keys) < 1000 else 200000
+    states, counts, probs, log_psi = wf.sample(n_draw)
+    idx = hil.state2idx(states)
+    nd.update(samp_n=n_draw, samp_states=states.numpy(), samp_counts=counts.numpy(),
+              samp_probs=probs.detach().numpy(), samp_log_psi=log_psi.detach().numpy(),
+              samp_keys=idx.squeeze().numpy().astype(np.uint64))
+    weights = counts.float() / counts.sum().float()
+    e_loc = opt.calculate_local_energy(idx.squeeze(), psi=cplx.exp(log_psi.detach()))
+    e128 = opt.calculate_local_energy(idx.squeeze(), psi=cplx.exp(log_psi.detach()), ret_complex=True)
+    w2 = weights.unsqueeze(-1)
+    e_corr = e_loc - (w2 * e_loc).sum(axis=0)
+    loss = 2 * cplx.real(w2 * cplx.scalar_mult(log_psi, e_corr)).sum(axis=0)
+    grads = {}
+    real_step = opt.optimizer.step
+
+    def capture_step(*a, **k):
+        for name, p in wf.model.named_parameters():
+            grads[name] = p.grad.detach().numpy().copy()
+        return real_step(*a, **k)
+
+    opt.optimizer.step = capture_step
+    E, Var = opt._SGD_step(states, idx, log_psi, sample_weights=weights.clone())
+    nd.update(sgd_eloc_f32=e_loc.numpy(), sgd_eloc_c128=e128, sgd_loss=np.float32(loss.item()),
+              sgd_E=np.float64(E), sgd_Var=np.float64(Var))
+    for k, g in grads.items():
+        nd["grad:" + k] = g
+    for k, v_ in wf.model.state_dict().items():
+        nd["sd_after:" + k] = v_.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, f"nade_{mol}.npz"), **nd)
+    print(f"[nade] {mol}: n_unq={len(states)} E={E:.6f} Var={Var:.6f} loss={loss.item():.6e}")
+
+    # ---------------- physics known answer: FCI through the reference path ----------------
+    if kat is not None:
+        opt.pauli_hamiltonian = fresh_pauli(opt)
+        H = opt.pauli_hamiltonian.update_H(hil.to_idx_tensor(all_keys), check_unseen=False,
+                                           assume_unique=True)
+        w = spla.eigsh(H.astype(np.float64), k=1, which="SA", return_eigenvectors=False)
+        kat.setdefault("fci", {})[mol] = float(w[0])
+        kat.setdefault("nnz", {})[mol] = int(H.nnz)
+        print(f"[kat] {mol}: E_FCI={w[0]:.12f} nnz={H.nnz}")
+
+    if time_it:
+        tag = list(M_sets)[-1]
+        keys = out[f"{tag}_keys"].astype(np.int64)
+        psi = torch.tensor(out[f"{tag}_psi_f32"])
+        idx = hil.to_idx_tensor(keys)
+        cold = []
+        for _ in range(7):
+            opt.pauli_hamiltonian = fresh_pauli(opt)
+            t = time.perf_counter()
+            opt.calculate_local_energy(idx, psi=psi)
+            cold.append(time.perf_counter() - t)
+        warm = []
+        for _ in range(10):
+            t = time.perf_counter()
+            opt.calculate_local_energy(idx, psi=psi)
+            warm.append(time.perf_counter() - t)
+        kat.setdefault("timing", {})[mol] = {
+            "M": int(len(keys)), "threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count())),
+            "cold_s_median": float(np.median(cold[2:])), "warm_s_median": float(np.median(warm)),
+            "where": "build container, reference calculate_local_energy via ref_harness"}
+        print("[time]", kat["timing"][mol])
+
+
+def main():
+    kat = {}
+    gen_molecule("LiH", {"c1": (150, 1.0), "half": (100, 2.0)}, (64, 32, 2), kat=kat)
+    gen_molecule("H2O", {"c1": (300, 1.0)}, (64, 32, 2), kat=kat)
+    gen_molecule("N2", {"small": (2000, 2.0), "c2": (10000, 2.0)}, (64, 512, 2), kat=kat, time_it=True)
+    gen_ham_only("Li2O")
+    for mol in N2_SWEEP:
+        gen_ham_only(mol)
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

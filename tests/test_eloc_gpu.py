@@ -1,0 +1,324 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle
+and the golden vectors dumped from the reference.  Run on the GPU box with ``-m gpu``.
+
+Tolerances: matrix elements / parities are bit-exact; E_loc is f64 arithmetic with a different
+summation order than the reference's SpMV, asserted to 1e-10 relative (north star: 1e-6 Ha).
+"""
+import ctypes
+import os
+from itertools import combinations
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def rel_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) if len(a) else 0.0
+
+
+@pytest.fixture(scope="module")
+def env():
+    from naqs_amd import _lib, hamiltonian, packing
+    from oracle import oracle
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.load_library()
+    return dict(lib=_lib, H=hamiltonian, P=packing, O=oracle)
+
+
+def dev_ham(env, mol):
+    return env["H"].DevicePauliHamiltonian(env["P"].load_packed(os.path.join(GOLDEN, f"ham_{mol}.npz")))
+
+
+def run_eloc(env, ham, keys, wf, kind="psi", dtype=torch.float32, **kw):
+    k = env["H"].keys_to_device(np.asarray(keys, np.uint64), ham.device)
+    w = torch.as_tensor(np.asarray(wf), dtype=dtype, device=ham.device)
+    e = ham.local_energy(k, w, kind=kind, **kw)
+    torch.cuda.synchronize()
+    e = e.cpu().numpy()
+    return e[:, 0] + 1j * e[:, 1]
+
+
+def all_keys(N, na, nb):
+    al = [sum(1 << b for b in c) for c in combinations(range(0, N, 2), na)]
+    be = [sum(1 << b for b in c) for c in combinations(range(1, N, 2), nb)]
+    return np.sort(np.array([a | b for a in al for b in be], np.uint64))
+
+
+def random_physical_keys(N, na, nb, M, seed):
+    rs = np.random.RandomState(seed)
+    keys = set()
+    ev, od = np.arange(0, N, 2), np.arange(1, N, 2)
+    while len(keys) < M:
+        a = rs.choice(ev, na, replace=False)
+        b = rs.choice(od, nb, replace=False)
+        keys.add(int(sum(1 << int(q) for q in a) | sum(1 << int(q) for q in b)))
+    return np.sort(np.array(list(keys), np.uint64))
+
+
+def synth_logpsi(M, seed, sigma=2.0):
+    rs = np.random.RandomState(seed)
+    return np.stack([rs.normal(-0.5 * np.log(max(M, 1)), sigma, M), rs.uniform(0, 2 * np.pi, M)], -1)
+
+
+# ------------------------------------------------------------------ golden vectors (reference outputs)
+@pytest.mark.parametrize("mol,tag", [("LiH", "c1"), ("LiH", "half"), ("H2O", "c1"), ("N2", "small"), ("N2", "c2")])
+def test_eloc_matches_reference_golden(env, mol, tag):
+    z = golden(f"eloc_{mol}.npz")
+    ham = dev_ham(env, mol)
+    e = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+    want = z[f"{tag}_eloc_c128"]
+    assert rel_err(e, want) < 1e-10
+    # variational energy for fixed samples: north-star bound 1e-6 Ha, we hold 1e-9
+    w = np.abs(z[f"{tag}_psi_f32"][:, 0] + 1j * z[f"{tag}_psi_f32"][:, 1]) ** 2
+    w /= w.sum()
+    assert abs(np.sum(w * e.real) - np.sum(w * want.real)) < 1e-9
+    # float32 tensor the reference hands to the optimiser
+    assert np.max(np.abs(e.real - z[f"{tag}_eloc_f32"][:, 0]) / np.maximum(1, np.abs(e.real))) < 2e-6
+
+
+@pytest.mark.parametrize("mol", ["LiH", "H2O", "N2"])
+def test_inner_ring_bit_exact(env, mol):
+    z = golden(f"eloc_{mol}.npz")
+    ham = dev_ham(env, mol)
+    k = env["H"].keys_to_device(z["ring_keys"], ham.device)
+    hij = ham.dense_hij(k).cpu().numpy().ravel()
+    assert np.array_equal(hij, z["ring_Hij"])                      # get_Hij_cy, identical bits
+    for name, tdt in (("int16", torch.int16), ("int32", torch.int32), ("int64", torch.int64)):
+        a = torch.as_tensor(z[f"pp_in_{name}"], dtype=tdt, device=ham.device)
+        got = env["H"].popcount_parity_device(a).cpu().numpy()
+        assert np.array_equal(got, z[f"pp_out_{name}"])
+    dev = ham.device
+    mv = env["H"].csr_mv_device(torch.as_tensor(z["ring_csr_data"], device=dev),
+                                torch.as_tensor(z["ring_csr_indices"], device=dev),
+                                torch.as_tensor(z["ring_csr_indptr"], device=dev),
+                                torch.as_tensor(np.stack([z["ring_v"].real, z["ring_v"].imag], -1).astype(np.float64),
+                                                device=dev)).cpu().numpy()
+    assert rel_err(mv[:, 0] + 1j * mv[:, 1], z["ring_mv"]) < 1e-13
+
+
+def test_popcount_parity_negative_1d_typeerror(env):
+    a = torch.tensor([-1, -2, 5, 0, -32768], dtype=torch.int16, device="cuda")
+    got = env["H"].popcount_parity_device(a).cpu().numpy()
+    assert got.shape == (5, 1) and np.array_equal(got, env["O"].popcount_parity(a.cpu().numpy()))
+    with pytest.raises(TypeError):
+        env["H"].popcount_parity_device(torch.zeros(3, device="cuda"))
+
+
+# ------------------------------------------------------------------ oracle on seeded inputs
+@pytest.mark.parametrize("mol,M,seed", [("LiH", 37, 1), ("LiH", 224, 2), ("H2O", 440, 3), ("N2", 3000, 4)])
+def test_eloc_vs_oracle_all_input_kinds(env, mol, M, seed):
+    h = golden(f"ham_{mol}.npz")
+    ham = dev_ham(env, mol)
+    space = all_keys(int(h["n_qubits"]), int(h["n_alpha"]), int(h["n_beta"]))
+    rs = np.random.RandomState(seed)
+    keys = rs.permutation(rs.choice(space, M, replace=False))      # deliberately unsorted
+    lp = synth_logpsi(M, seed)
+    psi64 = np.exp(lp[:, 0]) * np.exp(1j * lp[:, 1])
+    want = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi64)
+    e = run_eloc(env, ham, keys, np.stack([psi64.real, psi64.imag], -1), dtype=torch.float64)
+    assert rel_err(e, want) < 1e-10
+    e = run_eloc(env, ham, keys, lp, kind="log_psi", dtype=torch.float64)
+    assert rel_err(e, want) < 1e-9                                  # device exp/sincos vs numpy
+    lp32 = lp.astype(np.float32)
+    psi32 = np.exp(lp32[:, 0].astype(np.float64)) * np.exp(1j * lp32[:, 1].astype(np.float64))
+    want32 = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi32)
+    e = run_eloc(env, ham, keys, lp32, kind="log_psi", dtype=torch.float32)
+    assert rel_err(e, want32) < 1e-9
+
+
+def test_row_shards_tile_the_full_result(env):
+    """The multi-GPU shape: each rank evaluates a contiguous slice of rows against the whole table."""
+    h, z = golden("ham_N2.npz"), golden("eloc_N2.npz")
+    ham = dev_ham(env, "N2")
+    keys, psi, want = z["small_keys"], z["small_psi_f32"], z["small_eloc_c128"]
+    parts = []
+    for r in range(3):
+        b = len(keys) * r // 3
+        n = len(keys) * (r + 1) // 3 - b
+        parts.append(run_eloc(env, ham, keys, psi, row_begin=b, n_rows=n))
+    assert rel_err(np.concatenate(parts), want) < 1e-10
+    assert len(run_eloc(env, ham, keys, psi, row_begin=5, n_rows=0)) == 0
+
+
+def test_staging_variants_agree_bitwise(env):
+    z = golden("eloc_N2.npz")
+    ham = dev_ham(env, "N2")
+    res = []
+    for stage in ("0", "1", "2"):
+        os.environ["NAQS_STAGE"] = stage
+        try:
+            res.append(run_eloc(env, ham, z["small_keys"], z["small_psi_f32"]))
+        finally:
+            del os.environ["NAQS_STAGE"]
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    for rpb in ("4", "64", "1000"):
+        os.environ["NAQS_ROWS_PER_BLOCK"] = rpb
+        try:
+            assert np.array_equal(run_eloc(env, ham, z["small_keys"], z["small_psi_f32"]), res[0])
+        finally:
+            del os.environ["NAQS_ROWS_PER_BLOCK"]
+
+
+def test_edge_cases(env):
+    h = golden("ham_LiH.npz")
+    ham = dev_ham(env, "LiH")
+    # a single sample: only the diagonal group couples
+    key = all_keys(12, 2, 2)[:1]
+    e = run_eloc(env, ham, key, np.array([[0.3, -0.4]]), dtype=torch.float64)
+    want = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], key, np.array([0.3 - 0.4j]))
+    assert rel_err(e, want) < 1e-12 and abs(e[0].imag) < 1e-12
+    # M = 0
+    k = torch.empty(0, dtype=torch.int64, device=ham.device)
+    w = torch.empty((0, 2), dtype=torch.float32, device=ham.device)
+    assert ham.local_energy(k, w).shape == (0, 2)
+    # bad shapes / ranges raise
+    k = env["H"].keys_to_device(all_keys(12, 2, 2)[:8], ham.device)
+    with pytest.raises(ValueError):
+        ham.local_energy(k, torch.zeros((7, 2), device=ham.device))
+    with pytest.raises(env["lib"].NaqsError):
+        ham.local_energy(k, torch.ones((8, 2), device=ham.device), row_begin=4, n_rows=8)
+    # scratch growth: small call, then a larger one, then small again
+    for M in (10, 200, 10):
+        ks = all_keys(12, 2, 2)[:M]
+        lp = synth_logpsi(M, 9)
+        psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+        e = run_eloc(env, ham, ks, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+        assert rel_err(e, env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], ks, psi)) < 1e-10
+
+
+def test_hamiltonian_without_diagonal_and_empty(env):
+    P, H, O = env["P"], env["H"], env["O"]
+    full = P.load_packed(os.path.join(GOLDEN, "ham_LiH.npz"))
+    nd = full.xy != 0
+    ham = H.DevicePauliHamiltonian(P.PackedHamiltonian(12, 2, 2, full.xy[nd], full.yz[nd], full.coeff[nd]))
+    keys = all_keys(12, 2, 2)[::2]
+    lp = synth_logpsi(len(keys), 5)
+    psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+    assert rel_err(e, O.eloc_matrix_free(full.xy[nd], full.yz[nd], full.coeff[nd], keys, psi)) < 1e-10
+    empty = H.DevicePauliHamiltonian(P.PackedHamiltonian(12, 2, 2, np.zeros(0, np.uint64), np.zeros(0, np.uint64),
+                                                         np.zeros(0)))
+    e = run_eloc(env, empty, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+    assert np.all(e == 0)
+
+
+@pytest.mark.parametrize("filtered", [False, True])
+def test_64bit_keys(env, filtered):
+    """n_qubits > 32 takes the 64-bit mask path; synthetic Hamiltonian (no reference molecule is that big)."""
+    P, H, O = env["P"], env["H"], env["O"]
+    N, na, nb = 40, 6, 6
+    rs = np.random.RandomState(17)
+    keys = random_physical_keys(N, na, nb, 1500, 17)
+    # XY masks that connect sampled states: xor of random key pairs (+ the diagonal), a few terms each
+    pairs = rs.randint(0, len(keys), size=(300, 2))
+    xys = np.unique(np.r_[np.uint64(0), keys[pairs[:, 0]] ^ keys[pairs[:, 1]]])
+    xy = np.repeat(xys, rs.randint(1, 6, size=len(xys)))
+    yz = rs.randint(0, 1 << 20, size=len(xy)).astype(np.uint64) | (rs.randint(0, 1 << 20, size=len(xy)).astype(np.uint64) << np.uint64(20))
+    cf = rs.normal(size=len(xy))
+    perm = rs.permutation(len(xy))
+    xy, yz, cf = xy[perm], yz[perm], cf[perm]
+    ham = H.DevicePauliHamiltonian(P.PackedHamiltonian(N, na if filtered else -1, nb if filtered else -1, xy, yz, cf))
+    assert ham.key_bits == 64
+    lp = synth_logpsi(len(keys), 3)
+    psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+    want = O.eloc_matrix_free(xy, yz, cf, keys, psi)
+    assert np.count_nonzero(np.abs(want) > 0) > 100
+    assert rel_err(e, want) < 1e-10
+
+
+def test_li2o_subset_vs_oracle(env):
+    """Config 4 shape (30 qubits, 20 558 terms) at a size the oracle finishes in seconds."""
+    h = golden("ham_Li2O.npz")
+    ham = dev_ham(env, "Li2O")
+    rs = np.random.RandomState(1234)
+    # clustered samples (single/double excitations of one determinant) so that couplings do hit
+    base = random_physical_keys(30, 7, 7, 1, 7)[0]
+    keys = {int(base)}
+    uxy = np.unique(h["xy"])
+    frontier = [int(base)]
+    while len(keys) < 4000:
+        k = frontier[rs.randint(len(frontier))]
+        j = k ^ int(uxy[rs.randint(len(uxy))])
+        if bin(j & 0x15555555).count("1") == 7 and bin(j & 0x2AAAAAAA).count("1") == 7 and j not in keys:
+            keys.add(j)
+            frontier.append(j)
+    keys = np.sort(np.array(list(keys), np.uint64))
+    lp = synth_logpsi(len(keys), 11)
+    psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+    want = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi)
+    assert rel_err(e, want) < 1e-10
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+@pytest.mark.parametrize("mol", ["LiH", "H2O", "N2"])
+def test_exact_eigenvector_gives_constant_local_energy(env, mol):
+    """Physics KAT on the whole restricted space: H psi0 = E0 psi0  =>  E_loc[i] == E0 for every i."""
+    import json
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    h = golden(f"ham_{mol}.npz")
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    ham = dev_ham(env, mol)
+    keys = all_keys(int(h["n_qubits"]), int(h["n_alpha"]), int(h["n_beta"]))
+    k = env["H"].keys_to_device(keys, ham.device)
+    hij = ham.dense_hij(k).cpu().numpy()
+    uxy = np.unique(h["xy"])
+    j = keys[:, None] ^ uxy[None, :]
+    pos = np.searchsorted(keys, j)
+    pos[pos == len(keys)] = 0
+    hit = keys[pos] == j
+    rows = np.broadcast_to(np.arange(len(keys))[:, None], j.shape)[hit]
+    Hm = sp.csr_matrix((hij[hit], (rows, pos[hit])), shape=(len(keys),) * 2)
+    w, v = spla.eigsh(Hm, k=1, which="SA")
+    assert abs(w[0] - kat["fci"][mol]) < 1e-8
+    psi = v[:, 0] * np.exp(0.7j)                                   # global phase must not matter
+    big = np.abs(psi) > 1e-6 * np.abs(psi).max()
+    e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+    assert np.max(np.abs(e[big] - w[0])) < 1e-6 * max(1.0, abs(w[0]))
+
+
+def test_full_size_properties_li2o_50k(env):
+    """BASELINE config 4 size (M = 50 000, Li2O).  No oracle at this size; properties instead:
+    <psi|H|psi> = sum |psi_i|^2 conj(E_loc_i) is real for a symmetric H, E_loc is invariant under a
+    global rescaling/rephasing of psi, and a row shard equals the same rows of the full result."""
+    h = golden("ham_Li2O.npz")
+    ham = dev_ham(env, "Li2O")
+    keys = random_physical_keys(30, 7, 7, 50000, 1234)
+    lp = synth_logpsi(len(keys), 4321, sigma=1.0)
+    psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    wf = np.stack([psi.real, psi.imag], -1)
+    e = run_eloc(env, ham, keys, wf, dtype=torch.float64)
+    assert np.all(np.isfinite(e.real)) and np.all(np.isfinite(e.imag))
+    expect = np.sum(np.abs(psi) ** 2 * np.conj(e))
+    assert abs(expect.imag) < 1e-9 * abs(expect.real)
+    c = 3.0 * np.exp(1.1j)
+    e2 = run_eloc(env, ham, keys, np.stack([(c * psi).real, (c * psi).imag], -1), dtype=torch.float64)
+    assert rel_err(e2, e) < 1e-11
+    part = run_eloc(env, ham, keys, wf, dtype=torch.float64, row_begin=12345, n_rows=6250)
+    assert np.array_equal(part, e[12345:12345 + 6250])
+    # spot-check 64 random rows against the oracle's direct formula
+    rows = np.random.RandomState(0).choice(len(keys), 64, replace=False)
+    for r in rows[:8]:
+        want = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi, row_begin=int(r), n_rows=1)
+        assert rel_err(e[r:r + 1], want) < 1e-10
+
+
+def test_reduce_matches_oracle(env):
+    z = golden("nade_N2.npz")
+    ham = dev_ham(env, "N2")
+    e = z["sgd_eloc_c128"]
+    w = z["samp_counts"].astype(np.float64)
+    et = torch.as_tensor(np.stack([e.real, e.imag], -1), device=ham.device)
+    got = ham.reduce(torch.as_tensor(w, device=ham.device), et).cpu().numpy()
+    want = env["O"].eloc_reduce(w, e)
+    assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) < 1e-12
+    E = got[0] / got[3]
+    assert abs(E - z["sgd_E"]) < 2e-5 * abs(E)

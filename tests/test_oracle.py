@@ -1,0 +1,138 @@
+"""The CPU oracle against the golden vectors dumped from the reference (tests/golden/make_golden.py).
+
+This is what pins the oracle: every function of oracle/naqs_oracle.c is compared with the
+reference's own output on the same inputs.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from conftest import GOLDEN, golden
+from oracle import oracle
+
+MOLS = ["LiH", "H2O", "N2"]
+
+
+def rel_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+@pytest.mark.parametrize("mol", MOLS)
+def test_popcount_parity_bit_exact(mol):
+    z = golden(f"eloc_{mol}.npz")
+    for name in ("int16", "int32", "int64"):
+        got = oracle.popcount_parity(z[f"pp_in_{name}"])
+        assert got.dtype == np.int8 and np.array_equal(got, z[f"pp_out_{name}"])
+
+
+def test_popcount_parity_negative_and_1d_and_typeerror():
+    a = np.array([-1, -2, 5, 0, -32768], np.int16)
+    got = oracle.popcount_parity(a)
+    assert got.shape == (5, 1)
+    want = [1 - 2 * (bin(int(x) & 0xFFFFFFFF).count("1") % 2) for x in a]
+    assert got.ravel().tolist() == want
+    with pytest.raises(TypeError):
+        oracle.popcount_parity(np.zeros(3, np.float32))
+
+
+@pytest.mark.parametrize("mol", MOLS)
+def test_dedupe_matches_reference(mol):
+    h = golden(f"ham_{mol}.npz")
+    uxy, u2a_xy, uyz, u2a_yz = oracle.dedupe(h["xy"], h["yz"])
+    assert np.array_equal(uxy, h["unique_xy"]) and np.array_equal(u2a_xy, h["unique2all_xy"])
+    assert np.array_equal(uyz, h["unique_yz"]) and np.array_equal(u2a_yz, h["unique2all_yz"])
+
+
+@pytest.mark.parametrize("mol", MOLS)
+def test_get_hij_bit_exact(mol):
+    h, z = golden(f"ham_{mol}.npz"), golden(f"eloc_{mol}.npz")
+    hij, P = oracle.get_hij(z["ring_keys"], h["xy"], h["yz"], h["coeff"])
+    assert np.array_equal(P, z["ring_P"])
+    assert np.array_equal(hij, z["ring_Hij"])          # same summation order -> identical bits
+
+
+@pytest.mark.parametrize("mol", MOLS)
+def test_csr_mv(mol):
+    z = golden(f"eloc_{mol}.npz")
+    got = oracle.csr_mv(z["ring_csr_data"], z["ring_csr_indices"], z["ring_csr_indptr"], z["ring_v"])
+    assert rel_err(got, z["ring_mv"]) < 1e-13
+
+
+def _cases(mol):
+    z = golden(f"eloc_{mol}.npz")
+    return z, sorted({k.split("_")[0] for k in z.files if k.endswith("_eloc_c128")})
+
+
+@pytest.mark.parametrize("mol", MOLS)
+def test_eloc_staged_vs_reference(mol):
+    h = golden(f"ham_{mol}.npz")
+    z, tags = _cases(mol)
+    for tag in tags:
+        if len(z[f"{tag}_keys"]) > 4000:
+            continue                      # the staged restatement allocates M*Kyz; covered by 'small'
+        e = oracle.eloc_staged(int(h["n_qubits"]), int(h["n_alpha"]), int(h["n_beta"]), h["xy"], h["yz"],
+                               h["coeff"], z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+        # complex128 result of the reference before its float32 cast: <= 1e-12
+        assert rel_err(e, z[f"{tag}_eloc_c128"]) < 1e-12, (mol, tag)
+        # and the float32 tensor the reference returns, within float32 resolution
+        e32 = z[f"{tag}_eloc_f32"]
+        assert np.max(np.abs(e.real - e32[:, 0]) / np.maximum(1, np.abs(e.real))) < 2e-6
+
+
+@pytest.mark.parametrize("mol", MOLS)
+def test_eloc_matrix_free_vs_reference(mol):
+    h = golden(f"ham_{mol}.npz")
+    z, tags = _cases(mol)
+    for tag in tags:
+        e = oracle.eloc_matrix_free(h["xy"], h["yz"], h["coeff"], z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+        assert rel_err(e, z[f"{tag}_eloc_c128"]) < 1e-12, (mol, tag)
+
+
+def test_eloc_matrix_free_unsorted_keys_and_row_shard():
+    h, z = golden("ham_LiH.npz"), golden("eloc_LiH.npz")
+    keys, psi, want = z["c1_keys"], z["c1_psi_f32"], z["c1_eloc_c128"]
+    perm = np.random.RandomState(0).permutation(len(keys))
+    e = oracle.eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys[perm], psi[perm])
+    assert rel_err(e, want[perm]) < 1e-12
+    e = oracle.eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi, row_begin=40, n_rows=30)
+    assert rel_err(e, want[40:70]) < 1e-12
+
+
+def test_sgd_step_energy_statistics():
+    """E and Var of _SGD_step (energy.py:367-377) from the reference's own E_loc."""
+    for mol in MOLS:
+        z = golden(f"nade_{mol}.npz")
+        w = z["samp_counts"].astype(np.float64)
+        s = oracle.eloc_reduce(w, z["sgd_eloc_c128"])
+        E = s[0] / s[3]
+        var = s[2] / s[3] - E * E
+        assert abs(E - z["sgd_E"]) < 2e-5 * max(1, abs(E))            # reference works in float32
+        assert abs(var - z["sgd_Var"]) < 1e-3 * max(1, abs(var))
+
+
+@pytest.mark.parametrize("mol", ["LiH", "H2O"])
+def test_fci_known_answer(mol):
+    """Physics KAT: lowest eigenvalue of H over the whole restricted space == reference/FCI value."""
+    from itertools import combinations
+    h = golden(f"ham_{mol}.npz")
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    N, na, nb = int(h["n_qubits"]), int(h["n_alpha"]), int(h["n_beta"])
+    al = [sum(1 << b for b in c) for c in combinations(range(0, N, 2), na)]
+    be = [sum(1 << b for b in c) for c in combinations(range(1, N, 2), nb)]
+    keys = np.sort(np.array([a | b for a in al for b in be], np.uint64))
+    hij, _ = oracle.get_hij(keys, h["xy"], h["yz"], h["coeff"])
+    uxy = np.unique(h["xy"])
+    j = keys[:, None] ^ uxy[None, :]
+    pos = np.searchsorted(keys, j)
+    pos[pos == len(keys)] = 0
+    hit = keys[pos] == j
+    rows = np.broadcast_to(np.arange(len(keys))[:, None], j.shape)[hit]
+    H = sp.csr_matrix((hij.reshape(len(keys), -1)[hit], (rows, pos[hit])), shape=(len(keys),) * 2)
+    assert abs(H - H.T).max() < 1e-12                                   # Hermitian (real symmetric)
+    w = spla.eigsh(H, k=1, which="SA", return_eigenvectors=False)[0]
+    assert abs(w - kat["fci"][mol]) < 1e-9
+    assert H.nnz == kat["nnz"][mol]
