@@ -10,13 +10,17 @@
 // Design (see DESIGN.md for the numbers):
 //   * terms are packed CSR-by-unique-XY mask; masks are 32-bit when n_qubits <= 32 (all BASELINE
 //     molecules), 64-bit otherwise (template parameter KT);
-//   * one 64-lane wavefront owns one sample at a time; lanes stride over the XY groups, whose masks
-//     (and, when they fit, the per-term YZ masks + coefficients) are staged once per workgroup in LDS;
+//   * groups are stored in three classes: the diagonal (xy == 0), "heavy" groups (single excitations,
+//     tens of terms each) and "light" groups (double excitations, 4-6 terms each);
+//   * one 64-lane wavefront owns one sample at a time (rows are dealt to the waves of a workgroup
+//     round-robin); lanes stride over the XY groups, whose masks (and, when they fit, the
+//     per-term YZ masks + coefficients) are staged once per workgroup in LDS;
 //   * candidates that break particle-number conservation are rejected with two popcounts
 //     (replaces the reference's 2^N look-up table), the rest are probed in an open-addressing hash
 //     table of the sample keys that a small prep kernel rebuilds every call (L2 resident);
-//   * hits are compacted across the wave (ballot + mbcnt) into a per-wave LDS queue so that the
-//     sign-sum loops run with full lanes; the diagonal group is evaluated wave-cooperatively;
+//   * light hits are compacted across the wave (ballot + mbcnt) into a per-wave LDS queue so that the
+//     sign-sum loops run with full lanes; the diagonal and the heavy hits are evaluated
+//     wave-cooperatively (lanes stride the terms of one group);
 //   * per-sample result is a wave reduction (DPP shuffles) + one complex division.
 // Everything is integer/bit work plus a handful of f64 adds per hit: the bound is cache/HBM
 // traffic and issue rate, not MFMA, so there is deliberately no matrix-core code here.
@@ -49,10 +53,10 @@ thread_local hipError_t g_last_hip = hipSuccess;
     } while (0)
 
 constexpr int WAVE = 64;
-constexpr int BLOCK = 256;                 // 4 waves: one per SIMD of a CU
-constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
-constexpr int QUEUE_CAP = 128;             // per-wave hit queue (needs 64 + 63 entries)
+constexpr int BLOCK = 256;                 // helper kernels: 4 waves, one per SIMD of a CU
+constexpr int QUEUE_CAP = 192;             // per-wave hit queue: < 64 carried + 2 x 64 pushed per iteration
 constexpr int LDS_BUDGET = 64 * 1024;      // per-workgroup staging budget (160 KiB/CU -> >= 2 WGs/CU)
+constexpr int HEAVY_TERMS = 8;             // groups with more terms than this are "heavy"
 
 template <typename KT> struct Slot;
 template <> struct Slot<uint32_t> { unsigned long long kv; };              // key << 32 | index
@@ -143,13 +147,14 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(int64_t M, const uint64_t *
 // ------------------------------------------------------------------------------------------------
 template <typename KT>
 struct ElocParams {
-    // packed Hamiltonian
-    const KT *xy_g;          // [Kxy] ascending
+    // packed Hamiltonian, device group order: [diagonal (0|1)] [heavy ...] [light ...]
+    const KT *xy_g;          // [Kxy]
     const int32_t *row_ptr;  // [Kxy+1]
     const KT *yz_t;          // [K]
     const double *c_t;       // [K]
     int32_t Kxy, K;
-    int32_t diag_group;      // index of the xy == 0 group or -1
+    int32_t has_diag;        // 1 when group 0 is the xy == 0 group
+    int32_t light_begin;     // first light group = has_diag + n_heavy
     KT alpha_mask, beta_mask;
     int32_t n_alpha, n_beta; // < 0: no particle-number filter
     // sample table
@@ -167,6 +172,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
+}
+
+// the builtin returns a signed int: go through uint32_t before widening, or bit 31 smears upwards
+__device__ __forceinline__ uint32_t to_sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t to_sgpr(uint64_t v) {
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
 }
 
 // a / b for complex f64 (Smith's algorithm, as numpy's complex128 division)
@@ -197,65 +210,111 @@ __device__ __forceinline__ double sign_sum(KT key, const KT *__restrict__ yz, co
     return h;
 }
 
-template <typename KT, bool STAGE_GROUPS, bool STAGE_TERMS>
-__global__ __launch_bounds__(BLOCK) void eloc_kernel(const ElocParams<KT> p) {
+// the same sum with the lanes of a wave striding the terms (partial sum per lane)
+template <typename KT>
+__device__ __forceinline__ double sign_sum_strided(KT key, const KT *__restrict__ yz, const double *__restrict__ c,
+                                                   int t0, int t1, int lane) {
+    double h = 0.0;
+    for (int t = t0 + lane; t < t1; t += WAVE) {
+        const double ct = c[t];
+        h += (popc((KT)(key & yz[t])) & 1) ? -ct : ct;
+    }
+    return h;
+}
+
+template <typename KT, int STAGE, int NT>
+__global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
+    constexpr int NWAVES = NT / WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS layout: [c_t: K doubles][queue: WAVES*QUEUE_CAP int2][row_ptr: Kxy+1][xy: Kxy KT][yz: K KT]
+    // LDS layout: [c_t: K doubles][queue: NWAVES*QUEUE_CAP int2][row_ptr: Kxy+1 (+pad)][xy: Kxy KT][yz: K KT]
     double *s_c = reinterpret_cast<double *>(smem);
-    int2 *s_queue = reinterpret_cast<int2 *>(s_c + (STAGE_TERMS ? p.K : 0));
-    int32_t *s_rp = reinterpret_cast<int32_t *>(s_queue + WAVES_PER_BLOCK * QUEUE_CAP);
-    KT *s_xy = reinterpret_cast<KT *>(s_rp + (STAGE_GROUPS ? (p.Kxy + 2) & ~1 : 0));
-    KT *s_yz = s_xy + (STAGE_GROUPS ? p.Kxy : 0);
+    int2 *s_queue = reinterpret_cast<int2 *>(s_c + (STAGE >= 2 ? p.K : 0));
+    int32_t *s_rp = reinterpret_cast<int32_t *>(s_queue + NWAVES * QUEUE_CAP);
+    KT *s_xy = reinterpret_cast<KT *>(s_rp + (STAGE >= 1 ? (p.Kxy + 2) & ~1 : 0));
+    KT *s_yz = s_xy + (STAGE >= 1 ? p.Kxy : 0);
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
 
-    if (STAGE_GROUPS) {
-        for (int g = tid; g < p.Kxy; g += BLOCK) s_xy[g] = p.xy_g[g];
-        for (int g = tid; g <= p.Kxy; g += BLOCK) s_rp[g] = p.row_ptr[g];
+    if (STAGE >= 1) {
+#pragma unroll 4
+        for (int g = tid; g < p.Kxy; g += NT) s_xy[g] = p.xy_g[g];
+#pragma unroll 4
+        for (int g = tid; g <= p.Kxy; g += NT) s_rp[g] = p.row_ptr[g];
     }
-    if (STAGE_TERMS) {
-        for (int t = tid; t < p.K; t += BLOCK) { s_yz[t] = p.yz_t[t]; s_c[t] = p.c_t[t]; }
+    if (STAGE >= 2) {
+#pragma unroll 4
+        for (int t = tid; t < p.K; t += NT) s_yz[t] = p.yz_t[t];
+#pragma unroll 4
+        for (int t = tid; t < p.K; t += NT) s_c[t] = p.c_t[t];
     }
-    if (STAGE_GROUPS || STAGE_TERMS) __syncthreads();
+    __syncthreads();
 
-    const KT *xy = STAGE_GROUPS ? s_xy : p.xy_g;
-    const int32_t *rp = STAGE_GROUPS ? s_rp : p.row_ptr;
-    const KT *yz = STAGE_TERMS ? s_yz : p.yz_t;
-    const double *cf = STAGE_TERMS ? s_c : p.c_t;
+    const KT *xy = STAGE >= 1 ? s_xy : p.xy_g;
+    const int32_t *rp = STAGE >= 1 ? s_rp : p.row_ptr;
+    const KT *yz = STAGE >= 2 ? s_yz : p.yz_t;
+    const double *cf = STAGE >= 2 ? s_c : p.c_t;
     int2 *queue = s_queue + wave * QUEUE_CAP;
 
     const int64_t blk_begin = (int64_t)blockIdx.x * p.rows_per_block;
-    const int64_t blk_end = min(blk_begin + p.rows_per_block, p.n_rows);
+    const int blk_rows = (int)min((int64_t)p.rows_per_block, p.n_rows - blk_begin);
     const bool filter = p.n_alpha >= 0;
+    const Slot<KT> *__restrict__ tab = p.tab;
+    const double2 *__restrict__ psi = p.psi;
 
-    for (int64_t r = blk_begin + wave; r < blk_end; r += WAVES_PER_BLOCK) {
+    auto physical = [&](KT j) {
+        return !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
+    };
+
+    // Rows of the workgroup are dealt to its waves round-robin.  (A dynamic deal through an LDS
+    // counter — `if (lane == 0) rl = atomicAdd(s_next, 1); rl = readfirstlane(rl)` — is miscompiled by
+    // ROCm 7.2's hipcc into a loop that re-reads a stale register and never terminates on gfx950;
+    // measured, then removed.)
+    for (int rl = wave; rl < blk_rows; rl += NWAVES) {
+        const int64_t r = blk_begin + rl;
         const int64_t i = p.row_begin + r;
-        const KT key = p.keys[i];             // wave-uniform
-        const double2 psi_i = p.psi[i];
+        const KT key = to_sgpr(p.keys[i]);
+        const double2 psi_i = psi[i];
         double sr = 0.0, si = 0.0;
 
-        // diagonal group: all lanes share the terms
-        if (p.diag_group >= 0) {
-            const int t0 = rp[p.diag_group], t1 = rp[p.diag_group + 1];
-            double h = 0.0;
-            for (int t = t0 + lane; t < t1; t += WAVE) {
-                const double ct = cf[t];
-                h += (popc((KT)(key & yz[t])) & 1) ? -ct : ct;
-            }
+        // ---- diagonal group: lanes stride its terms
+        if (p.has_diag) {
+            const double h = sign_sum_strided<KT>(key, yz, cf, rp[0], rp[1], lane);
             sr = h * psi_i.x;
             si = h * psi_i.y;
         }
 
-        int qn = 0;  // wave-uniform number of queued hits
-        for (int g0 = 0; g0 < p.Kxy; g0 += WAVE) {
+        // ---- heavy groups: one probe per lane, then each hit is summed by the whole wave
+        for (int g0 = p.has_diag; g0 < p.light_begin; g0 += WAVE) {
             const int g = g0 + lane;
             int idx = -1;
-            if (g < p.Kxy && g != p.diag_group) {
+            if (g < p.light_begin) {
                 const KT j = key ^ xy[g];
-                const bool phys = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha &&
-                                              popc((KT)(j & p.beta_mask)) == p.n_beta);
-                if (phys) idx = hash_find(p.tab, p.bits, j);
+                if (physical(j)) idx = hash_find(tab, p.bits, j);
             }
+            unsigned long long m = __ballot(idx >= 0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int ib = __shfl(idx, b, WAVE);
+                const double2 pj = psi[ib];
+                const double h = sign_sum_strided<KT>(key, yz, cf, rp[g0 + b], rp[g0 + b + 1], lane);
+                sr += h * pj.x;
+                si += h * pj.y;
+            }
+        }
+
+        // ---- light groups: two probes in flight per lane, hits compacted into the wave's queue
+        int qn = 0;  // wave-uniform number of queued hits
+        auto drain = [&](int first, bool active) {
+            if (active) {
+                const int2 e = queue[first + lane];
+                const double2 pj = psi[e.y];
+                const double h = sign_sum<KT>(key, yz, cf, rp[e.x], rp[e.x + 1]);
+                sr += h * pj.x;
+                si += h * pj.y;
+            }
+        };
+        auto push = [&](int g, int idx) {
             const unsigned long long hits = __ballot(idx >= 0);
             if (hits) {
                 if (idx >= 0) {
@@ -264,25 +323,26 @@ __global__ __launch_bounds__(BLOCK) void eloc_kernel(const ElocParams<KT> p) {
                     queue[pos] = make_int2(g, idx);
                 }
                 qn += __popcll(hits);
+            }
+        };
+        for (int g0 = p.light_begin; g0 < p.Kxy; g0 += 2 * WAVE) {
+            const int gA = g0 + lane, gB = gA + WAVE;
+            KT jA = 0, jB = 0;
+            bool pA = false, pB = false;
+            if (gA < p.Kxy) { jA = key ^ xy[gA]; pA = physical(jA); }
+            if (gB < p.Kxy) { jB = key ^ xy[gB]; pB = physical(jB); }
+            const int idxA = pA ? hash_find(tab, p.bits, jA) : -1;
+            const int idxB = pB ? hash_find(tab, p.bits, jB) : -1;
+            push(gA, idxA);
+            push(gB, idxB);
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= WAVE) {
+                qn -= WAVE;
+                drain(qn, true);
                 __builtin_amdgcn_wave_barrier();
-                if (qn >= WAVE) {
-                    qn -= WAVE;
-                    const int2 e = queue[qn + lane];
-                    const double2 pj = p.psi[e.y];
-                    const double h = sign_sum<KT>(key, yz, cf, rp[e.x], rp[e.x + 1]);
-                    sr += h * pj.x;
-                    si += h * pj.y;
-                    __builtin_amdgcn_wave_barrier();
-                }
             }
         }
-        if (lane < qn) {
-            const int2 e = queue[lane];
-            const double2 pj = p.psi[e.y];
-            const double h = sign_sum<KT>(key, yz, cf, rp[e.x], rp[e.x + 1]);
-            sr += h * pj.x;
-            si += h * pj.y;
-        }
+        drain(0, lane < qn);
         __builtin_amdgcn_wave_barrier();
 
         sr = wave_sum(sr);
@@ -331,13 +391,14 @@ __global__ __launch_bounds__(BLOCK) void parity_kernel(const T *__restrict__ a, 
 
 template <typename KT>
 __global__ __launch_bounds__(BLOCK) void hij_kernel(int64_t M, int32_t Kxy, const uint64_t *__restrict__ keys,
-                                                    const int32_t *__restrict__ rp, const KT *__restrict__ yz,
-                                                    const double *__restrict__ c, double *__restrict__ out) {
+                                                    const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                    const KT *__restrict__ yz, const double *__restrict__ c,
+                                                    double *__restrict__ out) {
     const int64_t total = M * (int64_t)Kxy;
     for (int64_t e = blockIdx.x * (int64_t)BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
         const int64_t i = e / Kxy;
-        const int g = (int)(e - i * Kxy);
-        out[e] = sign_sum<KT>((KT)keys[i], yz, c, rp[g], rp[g + 1]);
+        const int g = (int)(e - i * Kxy);       // device group order; col[g] = reference (ascending-xy) column
+        out[i * Kxy + col[g]] = sign_sum<KT>((KT)keys[i], yz, c, rp[g], rp[g + 1]);
     }
 }
 
@@ -371,11 +432,11 @@ struct naqs_ham {
     int n_qubits = 0, n_alpha = -1, n_beta = -1;
     int key_bits = 32;
     int64_t K = 0, Kxy = 0;
-    int32_t diag_group = -1, diag_terms = 0;
+    int32_t has_diag = 0, diag_terms = 0, n_heavy = 0;
     uint64_t alpha_mask = 0, beta_mask = 0;
-    // device tables
+    // device tables, group order [diagonal][heavy][light]; d_col[g] = reference (ascending-xy) column
     void *d_xy = nullptr, *d_yz = nullptr;
-    int32_t *d_rp = nullptr;
+    int32_t *d_rp = nullptr, *d_col = nullptr;
     double *d_c = nullptr;
     // scratch
     int64_t cap_M = 0;
@@ -431,11 +492,14 @@ int ensure_scratch(naqs_ham *h, int64_t M) {
 
 template <typename KT>
 int upload_tables(naqs_ham *h, const std::vector<uint64_t> &xy_g, const std::vector<int32_t> &rp,
-                  const std::vector<uint64_t> &yz_t, const std::vector<double> &c_t) {
+                  const std::vector<int32_t> &col, const std::vector<uint64_t> &yz_t,
+                  const std::vector<double> &c_t) {
     std::vector<KT> xy_n(xy_g.begin(), xy_g.end()), yz_n(yz_t.begin(), yz_t.end());
     HIP_TRY(hipMalloc(&h->d_xy, std::max<size_t>(1, xy_n.size()) * sizeof(KT)));
     HIP_TRY(hipMalloc(&h->d_yz, std::max<size_t>(1, yz_n.size()) * sizeof(KT)));
     HIP_TRY(hipMalloc((void **)&h->d_rp, rp.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_col, std::max<size_t>(1, col.size()) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(h->d_col, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&h->d_c, std::max<size_t>(1, c_t.size()) * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_xy, xy_n.data(), xy_n.size() * sizeof(KT), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_yz, yz_n.data(), yz_n.size() * sizeof(KT), hipMemcpyHostToDevice));
@@ -468,7 +532,8 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
     p.yz_t = reinterpret_cast<const KT *>(h->d_yz);
     p.c_t = h->d_c;
     p.Kxy = (int32_t)h->Kxy; p.K = (int32_t)h->K;
-    p.diag_group = h->diag_group;
+    p.has_diag = h->has_diag;
+    p.light_begin = h->has_diag + h->n_heavy;
     p.alpha_mask = (KT)h->alpha_mask; p.beta_mask = (KT)h->beta_mask;
     p.n_alpha = h->n_alpha; p.n_beta = h->n_beta;
     p.keys = reinterpret_cast<const KT *>(h->d_keys);
@@ -477,32 +542,42 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
     p.row_begin = row_begin; p.n_rows = n_rows;
     p.eloc = reinterpret_cast<double2 *>(eloc_dev);
 
-    // workgroups: aim at >= 8 per CU so that every SIMD holds several waves (latency hiding), but
-    // keep at least one row per wave
+    // Workgroup shape.  The term tables are staged per workgroup, so big workgroups amortise the
+    // staging; small batches still want every CU busy.  1024 threads = 16 waves = 4 per SIMD.
+    int nt = env_int("NAQS_BLOCK", 0);
+    if (nt != 256 && nt != 512 && nt != 1024) nt = n_rows >= 4096 ? 1024 : 256;
+    const int nwaves = nt / WAVE;
     int rpb = env_int("NAQS_ROWS_PER_BLOCK", 0);
     if (rpb <= 0) {
-        const int64_t target_blocks = (int64_t)h->cu_count * 8;
-        rpb = (int)std::max<int64_t>(WAVES_PER_BLOCK, (n_rows + target_blocks - 1) / target_blocks);
-        rpb = (rpb + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+        const int64_t target_blocks = (int64_t)h->cu_count * (2048 / nt);     // fill every CU's wave slots
+        rpb = (int)std::max<int64_t>(nwaves, (n_rows + target_blocks - 1) / target_blocks);
     }
     p.rows_per_block = rpb;
     const int grid = (int)((n_rows + rpb - 1) / rpb);
 
-    const size_t q_bytes = WAVES_PER_BLOCK * QUEUE_CAP * sizeof(int2);
+    const size_t q_bytes = (size_t)nwaves * QUEUE_CAP * sizeof(int2) + 16;
     const size_t g_bytes = (size_t)((h->Kxy + 2) & ~1ll) * sizeof(int32_t) + (size_t)h->Kxy * sizeof(KT);
     const size_t t_bytes = (size_t)h->K * (sizeof(double) + sizeof(KT));
     const int force = env_int("NAQS_STAGE", -1);   // tuning/testing: 0 none, 1 groups, 2 groups+terms
     int stage = (q_bytes + g_bytes + t_bytes <= (size_t)LDS_BUDGET) ? 2 : (q_bytes + g_bytes <= (size_t)LDS_BUDGET ? 1 : 0);
     if (force >= 0 && force < stage) stage = force;
+    const size_t lds = q_bytes + (stage >= 1 ? g_bytes : 0) + (stage >= 2 ? t_bytes : 0);
 
     const bool prof = !h->ev.empty() && h->ev_used + 2 <= (int64_t)h->ev.size();
     if (prof) HIP_TRY(hipEventRecord(h->ev[h->ev_used], s));
-    if (stage == 2)
-        hipLaunchKernelGGL((eloc_kernel<KT, true, true>), dim3(grid), dim3(BLOCK), q_bytes + g_bytes + t_bytes, s, p);
-    else if (stage == 1)
-        hipLaunchKernelGGL((eloc_kernel<KT, true, false>), dim3(grid), dim3(BLOCK), q_bytes + g_bytes, s, p);
-    else
-        hipLaunchKernelGGL((eloc_kernel<KT, false, false>), dim3(grid), dim3(BLOCK), q_bytes, s, p);
+#define NAQS_LAUNCH(ST, NTHREADS) \
+    hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS>), dim3(grid), dim3(NTHREADS), lds, s, p)
+#define NAQS_LAUNCH_NT(ST)                                   \
+    do {                                                     \
+        if (nt == 1024) NAQS_LAUNCH(ST, 1024);               \
+        else if (nt == 512) NAQS_LAUNCH(ST, 512);            \
+        else NAQS_LAUNCH(ST, 256);                           \
+    } while (0)
+    if (stage == 2) NAQS_LAUNCH_NT(2);
+    else if (stage == 1) NAQS_LAUNCH_NT(1);
+    else NAQS_LAUNCH_NT(0);
+#undef NAQS_LAUNCH_NT
+#undef NAQS_LAUNCH
     HIP_TRY(hipGetLastError());
     if (prof) { HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
     return NAQS_OK;
@@ -588,15 +663,38 @@ NAQS_API int naqs_ham_create(int n_qubits, int n_alpha, int n_beta, int64_t K,
     if (st != NAQS_OK) { delete h; return st; }
     xy_g.resize((size_t)Kxy); rp.resize((size_t)Kxy + 1); yz_t.resize((size_t)K); c_t.resize((size_t)K);
     h->Kxy = Kxy;
-    if (Kxy > 0 && xy_g[0] == 0) { h->diag_group = 0; h->diag_terms = rp[1] - rp[0]; }
+
+    // device group order: [diagonal][heavy: more than HEAVY_TERMS terms][light], each class in ascending xy
+    std::vector<int32_t> col;                       // device position -> reference (ascending-xy) column
+    col.reserve((size_t)Kxy);
+    if (Kxy > 0 && xy_g[0] == 0) { h->has_diag = 1; h->diag_terms = rp[1] - rp[0]; col.push_back(0); }
+    for (int64_t g = h->has_diag; g < Kxy; ++g)
+        if (rp[(size_t)g + 1] - rp[(size_t)g] > HEAVY_TERMS) col.push_back((int32_t)g);
+    h->n_heavy = (int32_t)col.size() - h->has_diag;
+    for (int64_t g = h->has_diag; g < Kxy; ++g)
+        if (rp[(size_t)g + 1] - rp[(size_t)g] <= HEAVY_TERMS) col.push_back((int32_t)g);
+    std::vector<uint64_t> xy_d((size_t)Kxy), yz_d((size_t)K);
+    std::vector<int32_t> rp_d((size_t)Kxy + 1);
+    std::vector<double> c_d((size_t)K);
+    int32_t pos = 0;
+    for (int64_t d = 0; d < Kxy; ++d) {
+        const int32_t g = col[(size_t)d];
+        xy_d[(size_t)d] = xy_g[(size_t)g];
+        rp_d[(size_t)d] = pos;
+        for (int32_t t = rp[(size_t)g]; t < rp[(size_t)g + 1]; ++t, ++pos) {
+            yz_d[(size_t)pos] = yz_t[(size_t)t];
+            c_d[(size_t)pos] = c_t[(size_t)t];
+        }
+    }
+    rp_d[(size_t)Kxy] = pos;
 
     DeviceGuard guard;
     st = guard.init(device);
     if (st == NAQS_OK) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
-        st = h->key_bits == 32 ? upload_tables<uint32_t>(h, xy_g, rp, yz_t, c_t)
-                               : upload_tables<uint64_t>(h, xy_g, rp, yz_t, c_t);
+        st = h->key_bits == 32 ? upload_tables<uint32_t>(h, xy_d, rp_d, col, yz_d, c_d)
+                               : upload_tables<uint64_t>(h, xy_d, rp_d, col, yz_d, c_d);
     }
     if (st != NAQS_OK) { naqs_ham_destroy(h); return st; }
     *out = h;
@@ -608,7 +706,7 @@ NAQS_API int naqs_ham_destroy(naqs_ham_t *h) {
     DeviceGuard guard;
     (void)guard.init(h->device);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_c, h->d_keys, h->d_psi, h->d_tab};
+    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_col, h->d_c, h->d_keys, h->d_psi, h->d_tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return NAQS_OK;
@@ -687,10 +785,10 @@ NAQS_API int naqs_get_hij(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, do
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (h->key_bits == 32)
         hipLaunchKernelGGL(hij_kernel<uint32_t>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)h->Kxy, keys_dev, h->d_rp,
-                           (const uint32_t *)h->d_yz, h->d_c, hij_dev);
+                           h->d_col, (const uint32_t *)h->d_yz, h->d_c, hij_dev);
     else
         hipLaunchKernelGGL(hij_kernel<uint64_t>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)h->Kxy, keys_dev, h->d_rp,
-                           (const uint64_t *)h->d_yz, h->d_c, hij_dev);
+                           h->d_col, (const uint64_t *)h->d_yz, h->d_c, hij_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -699,7 +797,7 @@ NAQS_API int naqs_csr_mv(int64_t rows, const double *data_dev, const int32_t *in
                          const int32_t *indptr_dev, const double *v_dev, double *out_dev, void *stream) {
     if (rows < 0 || (rows > 0 && (!indptr_dev || !v_dev || !out_dev))) return NAQS_ERR_INVALID;
     if (rows == 0) return NAQS_OK;
-    const int grid = (int)std::min<int64_t>((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 8192);
+    const int grid = (int)std::min<int64_t>((rows + BLOCK / WAVE - 1) / (BLOCK / WAVE), 8192);
     hipLaunchKernelGGL(csr_mv_kernel, dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream), rows,
                        data_dev, indices_dev, indptr_dev, reinterpret_cast<const double2 *>(v_dev),
                        reinterpret_cast<double2 *>(out_dev));

@@ -53,6 +53,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and
+    # resolves it by file name; it must be in the process BEFORE libnaqs_hip.so so that the dynamic
+    # loader binds our NEEDED libamdhip64.so.7 to that same copy — two HIP runtimes in one process
+    # cannot share device pointers or streams (and the second one finds no device).
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise NaqsError(f"{path} not found: build it with `make -C naqs-for-quantum-chemistry_amd/csrc` "
