@@ -1,0 +1,234 @@
+"""Ansatz API: the counterpart of the reference's ``NAQSComplex_NADE_orbitals``
+(src/naqs/wavefunction.py:18-521) with the network resident on the GPU.
+
+Same constructor keywords, method names and return conventions (``sample`` ->
+``[states int8 [M, N] in qubit order, counts int64 [M], probs float32 [M], log_psi float32 [M, 2]]``
+with ``log_psi`` carrying gradients; ``log_psi`` / ``psi`` / ``amplitude`` / ``phase`` /
+``parameters(group_idx)`` / ``conditional_parameters`` / ``save`` / ``load``).  Unlike the reference
+(``out_device="cpu"``, wavefunction.py:27, nade.py:194) tensors stay on ``self.device`` unless the
+caller asks for numpy output.
+"""
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .hilbert import Encoding
+from .nade import (InputEncoding, MaxBatchSizeExceededError, NadeMasking, OrbitalNADE,  # noqa: F401
+                   SoftmaxLogProbAmps)
+
+
+class NAQSComplex_NADE_orbitals:
+    _cplx_dtype = np.complex64
+
+    def __init__(self, hilbert, N_up=None, N_alpha=None, N_beta=None, qubit_ordering=-1, num_lut=0,
+                 input_encoding=InputEncoding.BINARY, n_electrons=None, n_alpha_electrons=None,
+                 n_beta_electrons=None, masking=NadeMasking.PARTIAL,
+                 amp_hidden_size=(), amp_hidden_activation=nn.ReLU, amp_bias=True,
+                 phase_hidden_size=(), phase_hidden_activation=nn.ReLU, phase_bias=True,
+                 combined_amp_phase_blocks=False, use_amp_spin_sym=True, use_phase_spin_sym=True,
+                 aggregate_phase=True, amp_batch_norm=False, phase_batch_norm=False, batch_norm_momentum=1,
+                 amp_activation=SoftmaxLogProbAmps, phase_activation=None, device=None, out_device=None):
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        self.out_device = self.device if out_device is None else torch.device(out_device)
+        self.hilbert = hilbert
+        self.encoding = hilbert.encoding
+        if hilbert.N_occ != 0:
+            raise NotImplementedError("frozen (always-occupied) qubits are out of scope")
+        self._N_model, self._N_fixed = hilbert.N, 0
+        N = hilbert.N
+        # qubit <-> model permutations (wavefunction.py:56-83, :369-383)
+        if qubit_ordering == 1:
+            self.permute_qubits = False
+            q2m = np.arange(N)
+            self.state2model_permutation_shell = np.arange(N // 2)
+        elif qubit_ordering == -1:
+            self.permute_qubits = True
+            q2m = np.stack([np.arange(N - 2, -1, -2), np.arange(N - 1, -1, -2)], 1).reshape(-1)
+            self.state2model_permutation_shell = np.arange(N // 2 - 1, -1, -1)
+        else:
+            self.permute_qubits = True
+            if isinstance(qubit_ordering, int) and qubit_ordering == 0:
+                q2m = np.random.permutation(N)
+            else:
+                q2m = np.array(qubit_ordering)
+                assert len(q2m) == N and len(set(q2m.tolist())) == N, "custom ordering must list each qubit once"
+            self.state2model_permutation_shell = q2m[1::2] // 2
+        self.qubit2model_permutation = q2m
+        self.model2qubit_permutation = np.argsort(q2m)
+        self.model2state_permutation_shell = np.argsort(self.state2model_permutation_shell)
+
+        self.model = OrbitalNADE(
+            num_qubits=N, num_lut=num_lut, input_encoding=input_encoding, n_electrons=n_electrons,
+            n_alpha_electrons=n_alpha_electrons, n_beta_electrons=n_beta_electrons, masking=masking,
+            amp_hidden_size=list(amp_hidden_size), amp_hidden_activation=amp_hidden_activation, amp_bias=amp_bias,
+            phase_hidden_size=list(phase_hidden_size), phase_hidden_activation=phase_hidden_activation,
+            phase_bias=phase_bias, combined_amp_phase_blocks=combined_amp_phase_blocks,
+            use_amp_spin_sym=use_amp_spin_sym, use_phase_spin_sym=use_phase_spin_sym,
+            aggregate_phase=aggregate_phase, amp_batch_norm=amp_batch_norm, phase_batch_norm=phase_batch_norm,
+            batch_norm_momentum=batch_norm_momentum, amp_activation=amp_activation,
+            phase_activation=phase_activation, device=self.device)
+        self._q2m = torch.as_tensor(self.qubit2model_permutation, device=self.device)
+        self._m2q = torch.as_tensor(self.model2qubit_permutation, device=self.device)
+        self._m2s_shell = torch.as_tensor(self.model2state_permutation_shell, device=self.device)
+        self.model.train()
+        self.model.predict()
+
+    # ---- mode helpers (wavefunction.py:90-100)
+    def train_model(self):
+        self.model.train()
+
+    def eval_model(self):
+        self.model.eval()
+
+    def sample_model(self):
+        self.model.sample()
+
+    def predict_model(self):
+        self.model.predict()
+
+    # ---- evaluation (wavefunction.py:167-215, :397-414, :466-481)
+    def state2shell(self, s):
+        shp = s.shape
+        s = s.to(self.device)
+        return ((s.reshape(shp[0], shp[-1] // 2, 2) > 0).long() * torch.tensor([1, 2], device=self.device)).sum(-1)
+
+    def _evaluate_model(self, s):
+        self.model.predict()
+        x = s.to(self.device)[..., self._q2m].float()
+        return self.model(x)[:, self._m2s_shell]
+
+    def _evaluate_log_psi(self, s, gather_state=True):
+        out = self._evaluate_model(s)                                  # [B, N/2 (state shell order), 4, 2]
+        if gather_state:
+            sel = self.state2shell(s).view(out.shape[0], -1, 1, 1).expand(-1, -1, 1, 2)
+            out = out.gather(-2, sel)
+        return out
+
+    def log_psi(self, s, ret_complex=False, combine_conditionals=True):
+        if s.dim() < 2:
+            s = s.unsqueeze(0)
+        log_psi = self._evaluate_log_psi(s, gather_state=True)
+        if combine_conditionals:
+            log_psi = log_psi.sum(axis=1)
+        log_psi = log_psi.squeeze()
+        if ret_complex:
+            v = log_psi.detach().cpu().numpy()
+            return (v[..., 0] + 1j * v[..., 1]).astype(self._cplx_dtype)
+        return log_psi
+
+    def psi(self, s, ret_complex=False, combine_conditionals=True):
+        lp = self.log_psi(s, ret_complex=False, combine_conditionals=combine_conditionals)
+        psi = torch.stack([lp[..., 0].exp() * lp[..., 1].cos(), lp[..., 0].exp() * lp[..., 1].sin()], -1)
+        if ret_complex:
+            v = psi.detach().cpu().numpy()
+            return (v[..., 0] + 1j * v[..., 1]).astype(self._cplx_dtype)
+        return psi
+
+    def amplitude(self, s, combine_conditionals=True):
+        log_amps = self.log_psi(s, combine_conditionals=False)[..., 0]
+        if combine_conditionals:
+            log_amps = log_amps.sum(axis=-1).squeeze()
+        if log_amps.dim() == 0:
+            log_amps = log_amps.unsqueeze(0)
+        return log_amps.exp()
+
+    def phase(self, s, combine_conditionals=True):
+        phases = self.log_psi(s, combine_conditionals=False)[..., 1]
+        if combine_conditionals:
+            phases = phases.sum(axis=-1).squeeze()
+        return phases
+
+    # ---- sampling (wavefunction.py:488-521)
+    def sample(self, num_samples=1, ret_probs=True, ret_log_psi=True, ret_norm_reg=False, eval_mode=False,
+               max_batch_size=None, generator=None):
+        if ret_norm_reg:
+            raise NotImplementedError("ret_norm_reg")
+        was_training = self.model.training
+        self.model.eval() if eval_mode else self.model.train()
+        self.model.sample()
+        try:
+            states_m, counts, probs = self.model(num_samples, ret_output=False, max_batch_size=max_batch_size,
+                                                 generator=generator)
+        finally:
+            self.model.predict()
+            self.model.train(was_training)
+        states = states_m[:, self._m2q].to(self.hilbert.get_state_dtype("torch"))
+        out = [states, counts]
+        if ret_probs:
+            out.append(probs)
+        if ret_log_psi:
+            # differentiable log psi of the unique samples: one batched teacher-forced pass
+            lp = self.log_psi(states)
+            out.append(lp.reshape(-1, 2))
+        return out
+
+    # ---- parameters (wavefunction.py:416-451)
+    def parameters(self, group_idx=None):
+        if group_idx is None or group_idx == -1 or group_idx == 0:
+            return list(self.model.parameters())
+        if group_idx == 1:
+            return []                                   # look-up-table blocks: none on this path
+        raise NotImplementedError()
+
+    def conditional_parameters(self, cond_idx=None):
+        if cond_idx is None:
+            return list(self.model.parameters())
+        params = list(self.model.amp_layers[cond_idx].parameters())
+        if self.model.aggregate_phase:
+            params += list(self.model.phase_layers[cond_idx].parameters())
+        elif cond_idx == self._N_model // 2 - 1:
+            params += list(self.model.phase_layers[0].parameters())
+        return params
+
+    def count_parameters(self, print_verbose=True):
+        total = 0
+        for name, p in self.model.named_parameters():
+            if p.requires_grad:
+                if print_verbose:
+                    print(f"{name} : {p.numel()}")
+                total += p.numel()
+        print(f"\n--> Total trainable params: {total}")
+        return total
+
+    # ---- checkpoints, same keys as the reference (wavefunction.py:240-262)
+    def save(self, fname, quiet=False):
+        d = os.path.dirname(fname)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        ckpt = {"model:state_dict": {k: v.cpu() for k, v in self.model.state_dict().items()},
+                "wavefunction:permute_qubits": self.permute_qubits,
+                "wavefunction:qubit2model_permutation": self.qubit2model_permutation,
+                "wavefunction:model2qubit_permutation": self.model2qubit_permutation}
+        if os.path.splitext(fname)[-1] != ".pth":
+            fname += ".pth"
+        torch.save(ckpt, fname)
+        if not quiet:
+            print("Saved NAQSComplex wavefunction model to {}.".format(fname))
+        return fname
+
+    def load(self, fname):
+        ckpt = torch.load(fname, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ckpt["model:state_dict"])
+        self.permute_qubits = ckpt["wavefunction:permute_qubits"]
+        self.qubit2model_permutation = np.asarray(ckpt["wavefunction:qubit2model_permutation"])
+        self.model2qubit_permutation = np.asarray(ckpt["wavefunction:model2qubit_permutation"])
+        self._q2m = torch.as_tensor(self.qubit2model_permutation, device=self.device)
+        self._m2q = torch.as_tensor(self.model2qubit_permutation, device=self.device)
+        print("Loaded NAQSComplex wavefunction from {}.".format(fname))
+
+    @torch.no_grad()
+    def save_psi(self, fname="psi", subspace_args={}, normalise=True):
+        basis, basis_idxs = self.hilbert.get_subspace(ret_states=True, ret_idxs=True)
+        amps = self.amplitude(basis)
+        if normalise:
+            amps = amps / amps.pow(2).sum().pow(0.5)
+        phases = self.phase(basis)
+        order = torch.argsort(amps, descending=True).cpu()
+        psi = torch.stack([amps.cpu()[order], phases.cpu()[order]]).transpose(0, 1)
+        np.savetxt(f"{fname}.txt", psi.numpy(), fmt="%5e")
+        np.savetxt(f"{fname}_basis.txt", basis[order].clamp(min=0).numpy(), fmt="%i")
+        np.savetxt(f"{fname}_basis_idxs.txt", basis_idxs[order].numpy(), fmt="%i")
