@@ -27,6 +27,7 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TF = 157.3   # f32-in/f32-acc MFMA dense peak (MI355X_MICROARCH.md: = the f32 vector rate)
 
 
 def physical_keys(n_qubits, n_alpha, n_beta):
@@ -53,25 +54,49 @@ def algorithmic_bytes(M, K, Kxy):
     return M * (40 + 24 * Kxy) + 16 * K + 12 * Kxy
 
 
-def cpu_baseline(ham_p, keys, log_psi, budget_s=12.0):
-    """The oracle's staged restatement of the reference algorithm (cold Hamiltonian cache, like the
-    matrix-free GPU path: equal work), on the host cores of this box.  Bounded sample."""
+def cpu_baseline(ham_p, keys, log_psi, wf_args, budget_s=12.0):
+    """CPU leg, same two stages as the GPU step, on the host cores of this box, bounded sample:
+      * E_loc: the oracle's staged restatement of the reference algorithm (update_H + get_H + SpMV
+        with a cold Hamiltonian cache — equal work to the matrix-free GPU path), OpenMP;
+      * log-psi eval: the same torch modules the reference would run on CPU (its nade.py is PyTorch),
+        float32, torch's default intra-op threads."""
+    import torch
+    from naqs_amd.hilbert import Encoding, Hilbert
+    from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
     from oracle import oracle
     psi = np.exp(log_psi[:, 0].astype(np.float64)) * np.exp(1j * log_psi[:, 1].astype(np.float64))
-    Ms = min(len(keys), 4000)          # M*Kyz/M*Kxy temporaries like the reference; bounded
+    Ms = min(len(keys), 4000)          # M*Kyz / M*Kxy temporaries like the reference; bounded
     k, p = keys[:Ms], psi[:Ms]
     threads = oracle.max_threads()
-    oracle.eloc_staged(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, ham_p.xy, ham_p.yz, ham_p.coeff, k, p)
+    args = (ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, ham_p.xy, ham_p.yz, ham_p.coeff, k, p)
+    oracle.eloc_staged(*args)
     reps, t0 = 0, time.perf_counter()
     while True:
-        oracle.eloc_staged(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, ham_p.xy, ham_p.yz, ham_p.coeff, k, p)
+        oracle.eloc_staged(*args)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or reps >= 200:
+        if dt > budget_s / 2 or reps >= 100:
             break
-    return {"value": Ms * reps / dt, "unit": "unique samples/s", "cores": int(threads), "kind": "port",
-            "sample": f"{reps} x E_loc (oracle staged restatement of update_H+get_H+SpMV, cold cache) on the "
-                      f"first {Ms} samples of the N2 batch, {threads} OpenMP threads, {dt:.1f} s"}
+    t_eloc = dt / reps
+    hil = Hilbert.get(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, encoding=Encoding.SIGNED)
+    wf = NAQSComplex_NADE_orbitals(hil, device="cpu", **wf_args)
+    states = hil.idx2state(torch.from_numpy(k.astype(np.int64)))
+    with torch.no_grad():
+        wf.log_psi(states)
+        reps2, t0 = 0, time.perf_counter()
+        while True:
+            wf.log_psi(states)
+            reps2 += 1
+            dt2 = time.perf_counter() - t0
+            if dt2 > budget_s / 2 or reps2 >= 100:
+                break
+    t_lp = dt2 / reps2
+    return {"value": Ms / (t_eloc + t_lp), "unit": "unique samples/s", "cores": int(threads), "kind": "port",
+            "sample": f"first {Ms} samples of the N2 batch: {reps} x E_loc (oracle staged restatement of "
+                      f"update_H+get_H+SpMV, cold cache, {threads} OpenMP threads, {t_eloc * 1e3:.1f} ms each) + "
+                      f"{reps2} x log-psi eval (torch CPU float32, {torch.get_num_threads()} threads, "
+                      f"{t_lp * 1e3:.1f} ms each)",
+            "eloc_only_samples_per_s": Ms / t_eloc, "logpsi_only_samples_per_s": Ms / t_lp}
 
 
 def main():
@@ -110,18 +135,20 @@ def main():
     from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
     torch.manual_seed(1234 + rank)
     hil = Hilbert.get(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, encoding=Encoding.SIGNED)
-    wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512],
-                                   use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=False,
-                                   n_alpha_electrons=ham_p.n_alpha, n_beta_electrons=ham_p.n_beta, device=dev)
-    states = hil.idx2state(keys)                       # int8 [M, N] occupations, resident in HBM
+    wf_args = dict(qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512], use_amp_spin_sym=True,
+                   use_phase_spin_sym=False, aggregate_phase=False, n_alpha_electrons=ham_p.n_alpha,
+                   n_beta_electrons=ham_p.n_beta)
+    wf = NAQSComplex_NADE_orbitals(hil, device=dev, **wf_args)
+    from naqs_amd.fused import FusedLogPsi
+    fused = FusedLogPsi(wf)                            # libnaqs_hip.so: amp_kernel + MFMA phase_kernel
+    log_psi = torch.empty((M, 2), dtype=torch.float32, device=dev)
     weights = torch.as_tensor(counts_np / counts_np.sum(), dtype=torch.float64, device=dev)
     ham.reserve(M)
     eloc = torch.empty((M, 2), dtype=torch.float64, device=dev)
     acc = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def step():
-        with torch.no_grad():
-            log_psi = wf.log_psi(states)               # teacher-forced evaluation, float32 [M, 2]
+        fused.log_psi(keys, out=log_psi)               # teacher-forced evaluation, float32 [M, 2]
         ham.local_energy(keys, log_psi, kind="log_psi", out=eloc)
         s = ham.reduce(weights, eloc)
         if world > 1:
@@ -137,6 +164,7 @@ def main():
         step()
     fence()
     ham.prof_enable(args.steps)
+    fused.prof_enable(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -144,6 +172,8 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = ham.prof_read()
     ham.prof_enable(0)
+    mlp_ms, mlp_launches = fused.prof_read()
+    fused.prof_enable(0)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -155,6 +185,20 @@ def main():
         b_alg = algorithmic_bytes(M, ham.K, ham.Kxy)
         t_kernel = kern_ms / max(launches, 1) * 1e-3
         achieved = b_alg / t_kernel / 1e9 if t_kernel > 0 else 0.0
+        eloc_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "eloc_kernel",
+                     "kernel_us": t_kernel * 1e6, "algorithmic_bytes_per_launch": b_alg}
+        # phase MLP: 2*(K*N) flops per layer and sample (18->512->512->4 for N2), f32 matrix cores
+        dims = [2 * (ham.n_qubits // 2 - 1), 512, 512, 4]
+        flops = 2.0 * M * sum(a * b for a, b in zip(dims, dims[1:]))
+        t_mlp = mlp_ms / max(mlp_launches, 1) * 1e-3
+        mlp_tf = flops / t_mlp / 1e12 if t_mlp > 0 else 0.0
+        mlp_roof = {"bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": mlp_tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "phase_kernel (f32 MFMA 16x16x4)",
+                    "kernel_us": t_mlp * 1e6, "algorithmic_flops_per_launch": flops}
+        dominant, other = (mlp_roof, eloc_roof) if t_mlp >= t_kernel else (eloc_roof, mlp_roof)
+        roofline = dict(dominant)
+        roofline["other_kernels"] = [other]
         out = {
             "metric": "unique samples/sec through E_loc + log-psi eval (N2, 20 qubits)",
             "value": world * M * args.steps / dt,
@@ -165,18 +209,15 @@ def main():
             "dtype": "f32 network / f64 E_loc", "data": "synthetic",
             "config": {"workload": f"{args.molecule} STO-3G ({ham.n_qubits} qubits, K={ham.K} Pauli terms, "
                                    f"Kxy={ham.Kxy}), {M} unique samples per GPU, 1xMI355X per rank",
-                       "stages": "NADE log-psi eval (amp 1x64, phase 2x512, f32) + hash build + matrix-free E_loc "
+                       "stages": "fused NADE log-psi eval (amp 1x64, phase 2x512, f32 MFMA) + hash build + matrix-free E_loc "
                                  "(f64) + weighted energy reduction"
                                  + (" + RCCL all-reduce of 4 accumulators" if world > 1 else ""),
                        "input": "unique sampled bit-strings (keys + int8 occupations) resident in HBM; random-init network",
                        "energy": float(s[0] / s[3])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "eloc_kernel", "kernel_us": t_kernel * 1e6,
-                         "algorithmic_bytes_per_launch": b_alg},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np)
+            out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np, wf_args)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

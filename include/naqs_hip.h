@@ -141,6 +141,44 @@ int naqs_prof_enable(naqs_ham_t *h, int max_records);
 /* Synchronises the recorded events: total milliseconds and number of launches since enable. */
 int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches);
 
+
+/* ================================================================================================
+ * Fused log-psi evaluation of the orbital NADE (inference; gradients stay with PyTorch autograd).
+ * Replaces wavefunction.log_psi(states) (src/naqs/wavefunction.py:167-183) ->
+ * _forward_predict (src/naqs/network/nade.py:738-770) for the published architecture family:
+ * one amplitude MLP per orbital pair (one hidden layer), a single phase MLP on the last pair
+ * (aggregate_phase = False), SoftmaxLogProbAmps amplitudes, no phase symmetry.
+ * ============================================================================================== */
+typedef struct naqs_net naqs_net_t;
+
+#define NAQS_NET_MAX_PAIRS 16
+#define NAQS_NET_MAX_PHASE_LAYERS 8
+
+typedef struct naqs_net_config {
+    int32_t n_qubits;                 /* even, <= 2 * NAQS_NET_MAX_PAIRS */
+    int32_t n_alpha, n_beta;          /* electron budget of the masks (nade.py:417-474); -1/-1: unrestricted */
+    int32_t masking;                  /* NadeMasking: 0 NONE, 1 PARTIAL, 2 FULL (network/base.py:20-23) */
+    int32_t use_amp_spin_sym;         /* 1: 5 amplitude outputs + symmetrisation (nade.py:576-594) */
+    int32_t amp_hidden;               /* width of the single hidden layer of every amplitude block */
+    int32_t n_phase_hidden;           /* hidden layers of the phase block (>= 1) */
+    int32_t phase_hidden[NAQS_NET_MAX_PHASE_LAYERS];   /* their widths */
+    int32_t qubit2model[2 * NAQS_NET_MAX_PAIRS];       /* model position -> qubit (wavefunction.py:56-83, :369-383) */
+} naqs_net_config_t;
+
+int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_t **out);
+int naqs_net_destroy(naqs_net_t *net);
+/* Number of float parameters expected by naqs_net_set_weights: the reference's state_dict order,
+ * flattened (amp_layers.0.layers.0.0.weight, .bias, amp_layers.0.layers.1.0.weight, .bias, ...,
+ * phase_layers.0.layers.<l>.0.weight, .bias). */
+int naqs_net_param_count(const naqs_net_t *net, int64_t *count);
+/* Copy/re-pack the parameters (device pointer, float32, state_dict order) into the kernels' layout. */
+int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream);
+/* logpsi_dev: float [M][2] = (log|psi|, phase) for M keys. */
+int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream);
+/* HIP-event timing of the phase-MLP kernel, like naqs_prof_enable / naqs_prof_read. */
+int naqs_net_prof_enable(naqs_net_t *net, int max_records);
+int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

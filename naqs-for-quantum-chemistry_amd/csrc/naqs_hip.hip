@@ -35,24 +35,16 @@
 #include <numeric>
 #include <vector>
 
-#include "naqs_hip.h"
+#include "naqs_common.hpp"
 
-#define NAQS_API extern "C" __attribute__((visibility("default")))
+namespace naqs { thread_local hipError_t g_last_hip = hipSuccess; }
 
 namespace {
 
-thread_local hipError_t g_last_hip = hipSuccess;
+using naqs::WAVE;
+using naqs::DeviceGuard;
+using naqs::env_int;
 
-#define HIP_TRY(expr)                                  \
-    do {                                               \
-        hipError_t e__ = (expr);                       \
-        if (e__ != hipSuccess) {                       \
-            g_last_hip = e__;                          \
-            return NAQS_ERR_HIP;                       \
-        }                                              \
-    } while (0)
-
-constexpr int WAVE = 64;
 constexpr int BLOCK = 256;                 // helper kernels: 4 waves, one per SIMD of a CU
 constexpr int QUEUE_CAP = 192;             // per-wave hit queue: < 64 carried + 2 x 64 pushed per iteration
 constexpr int LDS_BUDGET = 64 * 1024;      // per-workgroup staging budget (160 KiB/CU -> >= 2 WGs/CU)
@@ -445,26 +437,10 @@ struct naqs_ham {
     void *d_tab = nullptr;
     int64_t tab_slots = 0;
     int cu_count = 256;
-    // profiling
-    std::vector<hipEvent_t> ev;
-    int64_t ev_used = 0;
+    naqs::EventRing prof;
 };
 
 namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    int init(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) return NAQS_ERR_NO_DEVICE;
-        if (prev != dev) {
-            HIP_TRY(hipSetDevice(dev));
-            switched = true;
-        }
-        return NAQS_OK;
-    }
-    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
-};
 
 int table_bits(int64_t M) {
     int bits = 10;
@@ -506,11 +482,6 @@ int upload_tables(naqs_ham *h, const std::vector<uint64_t> &xy_g, const std::vec
     HIP_TRY(hipMemcpy(h->d_rp, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_c, c_t.data(), c_t.size() * sizeof(double), hipMemcpyHostToDevice));
     return NAQS_OK;
-}
-
-int env_int(const char *name, int dflt) {
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
 }
 
 template <typename KT>
@@ -563,8 +534,8 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
     if (force >= 0 && force < stage) stage = force;
     const size_t lds = q_bytes + (stage >= 1 ? g_bytes : 0) + (stage >= 2 ? t_bytes : 0);
 
-    const bool prof = !h->ev.empty() && h->ev_used + 2 <= (int64_t)h->ev.size();
-    if (prof) HIP_TRY(hipEventRecord(h->ev[h->ev_used], s));
+    const bool prof = h->prof.armed();
+    if (prof) { int st = h->prof.begin(s); if (st != NAQS_OK) return st; }
 #define NAQS_LAUNCH(ST, NTHREADS) \
     hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS>), dim3(grid), dim3(NTHREADS), lds, s, p)
 #define NAQS_LAUNCH_NT(ST)                                   \
@@ -579,7 +550,7 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
 #undef NAQS_LAUNCH_NT
 #undef NAQS_LAUNCH
     HIP_TRY(hipGetLastError());
-    if (prof) { HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
+    if (prof) { int st = h->prof.end(s); if (st != NAQS_OK) return st; }
     return NAQS_OK;
 }
 
@@ -599,8 +570,8 @@ NAQS_API const char *naqs_strerror(int status) {
     }
 }
 
-NAQS_API int naqs_last_hip_error(void) { return (int)g_last_hip; }
-NAQS_API const char *naqs_last_hip_error_string(void) { return hipGetErrorString(g_last_hip); }
+NAQS_API int naqs_last_hip_error(void) { return (int)naqs::g_last_hip; }
+NAQS_API const char *naqs_last_hip_error_string(void) { return hipGetErrorString(naqs::g_last_hip); }
 
 NAQS_API int naqs_device_count(void) {
     int n = 0;
@@ -705,7 +676,7 @@ NAQS_API int naqs_ham_destroy(naqs_ham_t *h) {
     if (!h) return NAQS_OK;
     DeviceGuard guard;
     (void)guard.init(h->device);
-    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    (void)h->prof.enable(0);
     void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_col, h->d_c, h->d_keys, h->d_psi, h->d_tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -810,15 +781,7 @@ NAQS_API int naqs_prof_enable(naqs_ham_t *h, int max_records) {
     DeviceGuard guard;
     int st = guard.init(h->device);
     if (st != NAQS_OK) return st;
-    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    h->ev.clear();
-    h->ev_used = 0;
-    for (int i = 0; i < 2 * max_records; ++i) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreate(&e));
-        h->ev.push_back(e);
-    }
-    return NAQS_OK;
+    return h->prof.enable(max_records);
 }
 
 NAQS_API int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches) {
@@ -826,15 +789,5 @@ NAQS_API int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches) 
     DeviceGuard guard;
     int st = guard.init(h->device);
     if (st != NAQS_OK) return st;
-    double tot = 0;
-    for (int64_t i = 0; i + 1 < h->ev_used; i += 2) {
-        HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        tot += ms;
-    }
-    *total_ms = tot;
-    *launches = h->ev_used / 2;
-    h->ev_used = 0;
-    return NAQS_OK;
+    return h->prof.read(total_ms, launches);
 }

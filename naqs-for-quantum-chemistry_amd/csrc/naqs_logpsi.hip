@@ -1,0 +1,486 @@
+// naqs_logpsi.hip — fused teacher-forced evaluation  keys -> (log|psi|, phase)  of the orbital NADE
+// on gfx950 (MI355X).  Semantics: src/naqs/network/nade.py:738-770 (+ helpers :417-630) and
+// src/naqs/wavefunction.py:167-183, :397-414 of the reference, float32 like the reference.
+//
+// Two kernels per call (the PyTorch-eager formulation of the same thing is ~200 launches):
+//
+//   amp_kernel    one thread = one (sample, orbital pair n).  The 2n prefix occupations are built
+//                 from key bits, spin-ordered (nade.py:519-530) and kept in registers; the pair's
+//                 MLP weights are wave-uniform (blockIdx.y = n), so they arrive through scalar
+//                 loads and feed v_fmac straight from SGPRs.  Symmetrisation (:585-586), the
+//                 electron-budget mask (:426-474) and 0.5*log_softmax(2x) (activations.py:40-46)
+//                 are fused; the log-amplitude of the realised outcome goes to scratch[n][i].
+//   phase_kernel  the phase MLP (e.g. 18 -> 512 -> 512 -> 4) for a tile of BM samples per workgroup,
+//                 every layer on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, the
+//                 reference's precision).  Activations stay in LDS between layers (one buffer: the
+//                 MFMA accumulators hold a layer's output until every wave has finished reading its
+//                 input), weights stream from L2 as 16-byte loads in the MFMA operand layout, bias +
+//                 ReLU are fused into the write-back, and the epilogue adds the N/2 log-amplitudes in
+//                 fixed order and stores (log|psi|, phase).
+//
+// The 512x512 layer is GEMM-shaped (5.2 GFLOP for 10 000 samples) -> MFMA roofline; everything else
+// is negligible next to it.
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "naqs_common.hpp"
+
+namespace {
+
+using naqs::WAVE;
+using naqs::DeviceGuard;
+
+constexpr int MAXP = NAQS_NET_MAX_PAIRS;
+constexpr int MAXL = NAQS_NET_MAX_PHASE_LAYERS + 1;   // linear layers of the phase block
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NetDims {
+    int32_t P;                         // orbital pairs
+    int32_t n_alpha, n_beta;           // < 0: unrestricted
+    int32_t n_alpha_down, n_beta_down;
+    int32_t min_n_set;
+    int32_t masking;                   // 0 NONE, 1 PARTIAL, 2 FULL
+    int32_t sym;                       // amplitude spin symmetry
+    int32_t Ha;                        // amplitude hidden width
+    int32_t n_out_amp;                 // 5 with symmetry, 4 without
+    uint8_t qa[MAXP], qb[MAXP];        // qubit (bit) index of the alpha / beta orbital of model pair n
+    int32_t amp_off[MAXP];             // offset (floats) of pair n's parameters in the flat buffer:
+                                       //   W1 [Ha][max(1,2n)], b1 [Ha], W2 [n_out][Ha], b2 [n_out]
+    // phase MLP, packed & zero-padded: layer l: W [Nout_pad][K_pad], bias [Nout_pad]
+    int32_t n_lin;
+    int32_t K_pad[MAXL], N_pad[MAXL], w_off[MAXL], b_off[MAXL];
+    int32_t ld;                        // LDS row stride (floats)
+};
+
+// ------------------------------------------------------------------------------------------------
+// amplitude conditionals
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ float amp_block(const NetDims &d, const float *__restrict__ w, uint64_t key) {
+    constexpr int NIN = NB == 0 ? 1 : 2 * NB;
+    // prefix occupations of pairs 0..NB-1 and the realised outcome of pair NB
+    uint32_t abits = 0, bbits = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+        bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+    }
+    const int occ = (int)((key >> d.qa[NB]) & 1ull) + 2 * (int)((key >> d.qb[NB]) & 1ull);
+    // spin ordering: the string with the smaller index goes first (nade.py:399-405, :519-530)
+    const bool swap = d.sym && abits > bbits;
+    const int x_order = !d.sym ? 2 : (abits > bbits ? 0 : (abits == bbits ? 1 : 2));
+    const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
+    float x[NIN];
+    if (NB == 0) {
+        x[0] = 0.0f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            x[k] = ((first >> k) & 1u) ? 1.0f : -1.0f;
+            x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
+        }
+    }
+    const int Ha = d.Ha, nout = d.n_out_amp;
+    const float *W1 = w + d.amp_off[NB];
+    const float *b1 = W1 + Ha * NIN;
+    const float *W2 = b1 + Ha;
+    const float *b2 = W2 + nout * Ha;
+    float o[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) o[c] = c < nout ? b2[c] : 0.0f;
+    for (int j = 0; j < Ha; ++j) {
+        float h = b1[j];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) h = fmaf(W1[j * NIN + k], x[k], h);
+        h = fmaxf(h, 0.0f);
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (c < nout) o[c] = fmaf(W2[c * Ha + j], h, o[c]);
+    }
+    // symmetrise 5 -> 4 (nade.py:585-586): (o[0,1,1,2] + o[idx2sort[x_order]]) / 2
+    float a4[4];
+    if (d.sym) {
+        const float s1 = x_order == 0 ? o[3] : (x_order == 1 ? o[1] : o[4]);
+        const float s2 = x_order == 0 ? o[4] : (x_order == 1 ? o[1] : o[3]);
+        a4[0] = (o[0] + o[0]) * 0.5f;
+        a4[1] = (o[1] + s1) * 0.5f;
+        a4[2] = (o[1] + s2) * 0.5f;
+        a4[3] = (o[2] + o[2]) * 0.5f;
+    } else {
+        a4[0] = o[0]; a4[1] = o[1]; a4[2] = o[2]; a4[3] = o[3];
+    }
+    // electron-budget mask (nade.py:426-474), skipped on the last pair under PARTIAL (:615-617)
+    bool ok[4] = {true, true, true, true};
+    const bool mask_active = !(d.masking == 0 || (d.masking == 1 && NB == d.P - 1));
+    if (mask_active && d.n_alpha >= 0 && NB >= max(d.min_n_set, 1)) {
+        const int ua = __popc(abits), ub = __popc(bbits);
+        const bool a_up = ua < d.n_alpha, a_dn = (NB - ua) < d.n_alpha_down;
+        const bool b_up = ub < d.n_beta, b_dn = (NB - ub) < d.n_beta_down;
+        ok[0] = a_dn && b_dn; ok[1] = a_up && b_dn; ok[2] = a_dn && b_up; ok[3] = a_up && b_up;
+    }
+    // 0.5 * log_softmax(2 a) over the allowed outcomes (activations.py:40-46)
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { a4[c] *= 2.0f; if (ok[c]) m = fmaxf(m, a4[c]); }
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (ok[c]) s += expf(a4[c] - m);
+    const float sel = occ == 0 ? a4[0] : (occ == 1 ? a4[1] : (occ == 2 ? a4[2] : a4[3]));
+    const bool sel_ok = occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3]));
+    return sel_ok ? 0.5f * ((sel - m) - logf(s)) : -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void amp_kernel(const NetDims d, const float *__restrict__ w, int64_t M,
+                                                  const uint64_t *__restrict__ keys, float *__restrict__ scratch) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= M) return;
+    const uint64_t key = keys[i];
+    const int n = blockIdx.y;            // wave-uniform -> the weights come through scalar loads
+    float la;
+    switch (n) {
+#define CASE(NB) case NB: la = amp_block<NB>(d, w, key); break;
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
+        CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+#undef CASE
+        default: la = 0.0f;
+    }
+    scratch[(int64_t)n * M + i] = la;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase MLP on the f32 matrix cores
+// ------------------------------------------------------------------------------------------------
+constexpr int PH_THREADS = 512;                  // 8 waves = 2 per SIMD: one computes while the other waits on loads
+constexpr int PH_WAVES = PH_THREADS / WAVE;
+constexpr int CBT = 4;                           // 16-column blocks per wave per pass
+
+// K loop of one linear layer for one wave: RB row blocks x NC column blocks of 16x16 outputs.
+// Operand layout of v_mfma_f32_16x16x4_f32: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15].
+// One 16-byte load per lane covers 4 MFMAs: lane (m, kq) holds k = k0 + 4*kq + j for j = 0..3 on both
+// operands, so MFMA j contracts {k0+j, k0+4+j, k0+8+j, k0+12+j} — over a 16-wide chunk every k is
+// visited exactly once.
+template <int RB, int NC>
+__device__ __forceinline__ void mlp_accumulate(const float *__restrict__ a_ptr, int ld,
+                                               const float *__restrict__ w_ptr, int K_pad, f32x4 (&acc)[RB][CBT]) {
+    for (int k0 = 0; k0 < K_pad; k0 += 16) {
+        f32x4 a[RB], b[NC];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const f32x4 *>(a_ptr + rb * 16 * ld + k0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) b[c] = *reinterpret_cast<const f32x4 *>(w_ptr + (size_t)c * 16 * K_pad + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][j], b[c][j], acc[rb][c], 0, 0, 0);
+    }
+}
+
+// one linear layer for RB*16 rows held in LDS: buf[rows][ld] (K_pad valid floats per row) ->
+// buf[rows][0..N_pad) = act(buf * W^T + b).  All waves of the workgroup call it together.  The outputs
+// are written only after every wave has finished reading the input (the MFMA accumulators hold them
+// meanwhile), so a single LDS buffer suffices; the host guarantees N_pad <= PH_WAVES*CBT*16.
+template <int RB>
+__device__ __forceinline__ void mlp_layer(float *__restrict__ buf, int ld, int K_pad, int N_pad,
+                                          const float *__restrict__ W, const float *__restrict__ bias, bool relu,
+                                          int wave, int lane) {
+    const int m = lane & 15, kq = lane >> 4;
+    const int ncb = N_pad >> 4;
+    f32x4 acc[RB][CBT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int c = 0; c < CBT; ++c) acc[rb][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int cb0 = wave * CBT;
+    const int my_cb = min(CBT, max(0, ncb - cb0));       // wave-uniform
+    const float *a_ptr = buf + m * ld + 4 * kq;
+    const float *w_ptr = W + (size_t)(cb0 * 16 + m) * K_pad + 4 * kq;
+    if (my_cb == 4) mlp_accumulate<RB, 4>(a_ptr, ld, w_ptr, K_pad, acc);
+    else if (my_cb == 3) mlp_accumulate<RB, 3>(a_ptr, ld, w_ptr, K_pad, acc);
+    else if (my_cb == 2) mlp_accumulate<RB, 2>(a_ptr, ld, w_ptr, K_pad, acc);
+    else if (my_cb == 1) mlp_accumulate<RB, 1>(a_ptr, ld, w_ptr, K_pad, acc);
+    __syncthreads();                                      // everyone is done reading the input
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int c = 0; c < CBT; ++c) {
+        if (c < my_cb) {
+            const int col = (cb0 + c) * 16 + m;
+            const float bv = bias[col];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[rb][c][r] + bv;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    buf[(rb * 16 + kq * 4 + r) * ld + col] = v;
+                }
+        }
+    }
+    __syncthreads();
+}
+
+template <int RB>
+__global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, const float *__restrict__ w, int64_t M,
+                                                           const uint64_t *__restrict__ keys,
+                                                           const float *__restrict__ scratch,
+                                                           float2 *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];
+    constexpr int BM = RB * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int P = d.P, ld = d.ld;
+
+    // layer-0 input: [alpha occupations of pairs 0..P-2 | beta ...] as +-1 (no spin ordering for the
+    // phase block, nade.py:531-537), zero-padded to K_pad[0]; rows past M are zero
+    const int K0 = d.K_pad[0];
+    for (int e = tid; e < BM * K0; e += PH_THREADS) {
+        const int r = e / K0, k = e - r * K0;
+        const int64_t i = row0 + r;
+        float v = 0.0f;
+        if (i < M && k < 2 * (P - 1)) {
+            const uint64_t key = keys[i];
+            const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
+            v = ((key >> q) & 1ull) ? 1.0f : -1.0f;
+        }
+        buf[r * ld + k] = v;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < d.n_lin; ++l)
+        mlp_layer<RB>(buf, ld, d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l], l + 1 < d.n_lin, wave, lane);
+
+    // epilogue: phase of the realised outcome of the last pair + sum of the log-amplitudes
+    if (tid < BM) {
+        const int64_t i = row0 + tid;
+        if (i < M) {
+            const uint64_t key = keys[i];
+            const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
+            float la = 0.0f;
+            for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + i];   // fixed order: block 0..P-1
+            out[i] = make_float2(la, buf[tid * ld + occ]);
+        }
+    }
+}
+
+// re-pack the flat state_dict-order parameters into the kernels' layout
+__global__ __launch_bounds__(256) void pack_phase_kernel(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
+                                                         float *__restrict__ Wd, float *__restrict__ bd) {
+    const int total = N_pad * K_pad;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total + N_pad; e += gridDim.x * 256) {
+        if (e < total) {
+            const int n = e / K_pad, k = e - n * K_pad;
+            Wd[e] = (n < N && k < K) ? src[n * K + k] : 0.0f;
+        } else {
+            const int n = e - total;
+            bd[n] = n < N ? src[N * K + n] : 0.0f;
+        }
+    }
+}
+
+}  // namespace
+
+struct naqs_net {
+    int device = 0;
+    naqs_net_config_t cfg{};
+    NetDims dims{};
+    int64_t n_params = 0;
+    int64_t amp_params = 0;                 // floats of all amplitude blocks (copied verbatim)
+    std::vector<int64_t> phase_src_off;     // per phase linear layer: offset in the flat source
+    std::vector<int> phase_K, phase_N;
+    float *d_w = nullptr;                   // [amp params | packed phase layers]
+    int64_t w_floats = 0;
+    float *d_scratch = nullptr;             // [P][cap_M] log-amplitude contributions
+    int64_t cap_M = 0;
+    int cu_count = 256;
+    bool have_weights = false;
+    naqs::EventRing prof;
+};
+
+NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_t **out) {
+    if (!cfg || !out) return NAQS_ERR_INVALID;
+    *out = nullptr;
+    const int N = cfg->n_qubits;
+    if (N <= 0 || (N & 1)) return NAQS_ERR_INVALID;
+    const int P = N / 2;
+    if (P > MAXP) return NAQS_ERR_UNSUPPORTED;
+    if (P < 2) return NAQS_ERR_UNSUPPORTED;
+    if (cfg->amp_hidden <= 0 || cfg->n_phase_hidden < 1 || cfg->n_phase_hidden > NAQS_NET_MAX_PHASE_LAYERS)
+        return NAQS_ERR_INVALID;
+    if (cfg->masking < 0 || cfg->masking > 2) return NAQS_ERR_INVALID;
+    if ((cfg->n_alpha < 0) != (cfg->n_beta < 0)) return NAQS_ERR_INVALID;
+    std::vector<bool> seen((size_t)N, false);
+    for (int i = 0; i < N; ++i) {
+        const int q = cfg->qubit2model[i];
+        if (q < 0 || q >= N || seen[(size_t)q]) return NAQS_ERR_INVALID;
+        seen[(size_t)q] = true;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NAQS_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return NAQS_ERR_INVALID;
+
+    naqs_net *net = new (std::nothrow) naqs_net();
+    if (!net) return NAQS_ERR_NOMEM;
+    net->device = device;
+    net->cfg = *cfg;
+    NetDims &d = net->dims;
+    d.P = P;
+    d.n_alpha = cfg->n_alpha; d.n_beta = cfg->n_beta;
+    d.n_alpha_down = (N + 1) / 2 - cfg->n_alpha; d.n_beta_down = N / 2 - cfg->n_beta;
+    d.min_n_set = cfg->n_alpha < 0 ? 0 : std::min(std::min(d.n_alpha, d.n_beta), std::min(d.n_alpha_down, d.n_beta_down));
+    d.masking = cfg->masking;
+    d.sym = cfg->use_amp_spin_sym ? 1 : 0;
+    d.Ha = cfg->amp_hidden;
+    d.n_out_amp = d.sym ? 5 : 4;
+    for (int n = 0; n < P; ++n) { d.qa[n] = (uint8_t)cfg->qubit2model[2 * n]; d.qb[n] = (uint8_t)cfg->qubit2model[2 * n + 1]; }
+    int64_t off = 0;
+    for (int n = 0; n < P; ++n) {
+        d.amp_off[n] = (int32_t)off;
+        const int nin = n == 0 ? 1 : 2 * n;
+        off += (int64_t)d.Ha * nin + d.Ha + (int64_t)d.n_out_amp * d.Ha + d.n_out_amp;
+    }
+    net->amp_params = off;
+    // phase block: 2(P-1) -> hidden... -> 4
+    int K = std::max(1, 2 * (P - 1));
+    d.n_lin = cfg->n_phase_hidden + 1;
+    int64_t src = off, dst = off;
+    int max_k = 0;
+    for (int l = 0; l < d.n_lin; ++l) {
+        const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : 4;
+        if (Nout <= 0) { delete net; return NAQS_ERR_INVALID; }
+        d.K_pad[l] = (K + 15) & ~15;
+        d.N_pad[l] = (Nout + 15) & ~15;
+        if (d.N_pad[l] > PH_WAVES * CBT * 16) { delete net; return NAQS_ERR_UNSUPPORTED; }   // <= 512 outputs per layer
+        dst = (dst + 3) & ~3ll;                                   // 16-byte aligned rows for the float4 weight loads
+        d.w_off[l] = (int32_t)dst; dst += (int64_t)d.N_pad[l] * d.K_pad[l];
+        d.b_off[l] = (int32_t)dst; dst += d.N_pad[l];
+        net->phase_src_off.push_back(src);
+        net->phase_K.push_back(K); net->phase_N.push_back(Nout);
+        src += (int64_t)Nout * K + Nout;
+        max_k = std::max(max_k, std::max(d.K_pad[l], d.N_pad[l]));
+        K = Nout;
+    }
+    d.ld = max_k + 4;                       // +4 floats: consecutive rows start one 16-byte LDS slot apart
+    net->n_params = src;
+    net->w_floats = dst;
+
+    DeviceGuard guard;
+    int st = guard.init(device);
+    if (st == NAQS_OK) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cu_count = prop.multiProcessorCount;
+        if (hipMalloc((void **)&net->d_w, (size_t)net->w_floats * sizeof(float)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        // the activation tile of 48/64 rows x 516 floats exceeds the 64 KiB default of dynamic LDS
+        const int lds_max = 4 * 16 * d.ld * (int)sizeof(float);
+        if (lds_max > 160 * 1024) st = NAQS_ERR_UNSUPPORTED;
+        if (st == NAQS_OK) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4 * 3);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        }
+    }
+    if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
+    *out = net;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_destroy(naqs_net_t *net) {
+    if (!net) return NAQS_OK;
+    DeviceGuard guard;
+    (void)guard.init(net->device);
+    (void)net->prof.enable(0);
+    if (net->d_w) (void)hipFree(net->d_w);
+    if (net->d_scratch) (void)hipFree(net->d_scratch);
+    delete net;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_param_count(const naqs_net_t *net, int64_t *count) {
+    if (!net || !count) return NAQS_ERR_INVALID;
+    *count = net->n_params;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
+    if (!net || !flat_dev || count != net->n_params) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(net->d_w, flat_dev, (size_t)net->amp_params * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const NetDims &d = net->dims;
+    for (int l = 0; l < d.n_lin; ++l) {
+        const int total = d.N_pad[l] * d.K_pad[l] + d.N_pad[l];
+        hipLaunchKernelGGL(pack_phase_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                           flat_dev + net->phase_src_off[(size_t)l], net->phase_K[(size_t)l], net->phase_N[(size_t)l],
+                           d.K_pad[l], d.N_pad[l], net->d_w + d.w_off[l], net->d_w + d.b_off[l]);
+        HIP_TRY(hipGetLastError());
+    }
+    net->have_weights = true;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream) {
+    if (!net || M < 0 || (M > 0 && (!keys_dev || !logpsi_dev))) return NAQS_ERR_INVALID;
+    if (!net->have_weights) return NAQS_ERR_INVALID;
+    if (M == 0) return NAQS_OK;
+    if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    const NetDims &d = net->dims;
+    if (M > net->cap_M) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (net->d_scratch) (void)hipFree(net->d_scratch);
+        net->d_scratch = nullptr; net->cap_M = 0;
+        const int64_t cap = std::max<int64_t>(1024, M + M / 4);
+        HIP_TRY(hipMalloc((void **)&net->d_scratch, (size_t)cap * d.P * sizeof(float)));
+        net->cap_M = cap;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)d.P), dim3(256), 0, s, d, net->d_w, M,
+                       keys_dev, net->d_scratch);
+    HIP_TRY(hipGetLastError());
+
+    // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
+    int rb = naqs::env_int("NAQS_PHASE_RB", 0);
+    if (rb < 1 || rb > 4) rb = (int)std::min<int64_t>(4, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
+    const int bm = rb * 16;
+    const unsigned grid = (unsigned)((M + bm - 1) / bm);
+    const size_t lds = (size_t)bm * d.ld * sizeof(float);
+    float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
+    const bool prof = net->prof.armed();
+    if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
+    switch (rb) {
+        case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+        case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+        case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+        default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_prof_enable(naqs_net_t *net, int max_records) {
+    if (!net || max_records < 0) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    return net->prof.enable(max_records);
+}
+
+NAQS_API int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches) {
+    if (!net || !total_ms || !launches) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    return net->prof.read(total_ms, launches);
+}

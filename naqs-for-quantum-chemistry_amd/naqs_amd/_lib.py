@@ -34,7 +34,24 @@ SIGNATURES = {
     "naqs_csr_mv": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "naqs_net_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "naqs_net_destroy": (ctypes.c_int, [c_vp]),
+    "naqs_net_param_count": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    "naqs_net_set_weights": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "naqs_net_logpsi": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "naqs_net_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "naqs_net_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }
+
+NET_MAX_PAIRS, NET_MAX_PHASE_LAYERS = 16, 8
+
+
+class NetConfig(ctypes.Structure):
+    """naqs_net_config_t"""
+    _fields_ = [("n_qubits", ctypes.c_int32), ("n_alpha", ctypes.c_int32), ("n_beta", ctypes.c_int32),
+                ("masking", ctypes.c_int32), ("use_amp_spin_sym", ctypes.c_int32), ("amp_hidden", ctypes.c_int32),
+                ("n_phase_hidden", ctypes.c_int32), ("phase_hidden", ctypes.c_int32 * NET_MAX_PHASE_LAYERS),
+                ("qubit2model", ctypes.c_int32 * (2 * NET_MAX_PAIRS))]
 
 
 class NaqsError(RuntimeError):

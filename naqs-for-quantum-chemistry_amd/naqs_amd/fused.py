@@ -1,0 +1,90 @@
+"""Fused HIP evaluation of log psi for a batch of keys (``naqs_net_*`` entry points).
+
+The product path of the metric's "log-psi eval": two kernels instead of ~200 eager launches.
+Supported architecture family = what the reference's published runs use (batch_train.sh:14):
+one hidden layer per amplitude block, a single phase block (``aggregate_phase=False``), no phase
+symmetry, <= 16 orbital pairs, phase layers <= 512 wide.  Anything else raises
+``NotImplementedError`` — callers then stay on the PyTorch modules (same numbers, more launches).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .hamiltonian import _stream_ptr
+
+
+class FusedLogPsi:
+    def __init__(self, wavefunction):
+        wf, m = wavefunction, wavefunction.model
+        if m.device.type != "cuda":
+            raise _lib.NaqsError("FusedLogPsi needs the network on a HIP device (no CPU fallback)")
+        if m.aggregate_phase or len(m.phase_layers) != 1:
+            raise NotImplementedError("fused log-psi: aggregate_phase=True")
+        if len(m.amp_layers[0].linears()) != 2:
+            raise NotImplementedError("fused log-psi: amplitude blocks need exactly one hidden layer")
+        if m.P > _lib.NET_MAX_PAIRS or m.P < 2:
+            raise NotImplementedError("fused log-psi: 2..16 orbital pairs")
+        phase_lin = m.phase_layers[0].linears()
+        hidden = [lin.out_features for lin in phase_lin[:-1]]
+        if not 1 <= len(hidden) <= _lib.NET_MAX_PHASE_LAYERS or max(hidden) > 512:
+            raise NotImplementedError("fused log-psi: 1..8 phase hidden layers of width <= 512")
+        self._lib = _lib.load_library()
+        self.wf = wf
+        self.device = m.device
+        cfg = _lib.NetConfig()
+        cfg.n_qubits = m.N
+        cfg.n_alpha = m.n_alpha_up if m.use_restricted_hilbert else -1
+        cfg.n_beta = m.n_beta_up if m.use_restricted_hilbert else -1
+        cfg.masking = m.masking.value
+        cfg.use_amp_spin_sym = int(m.use_amp_spin_sym)
+        cfg.amp_hidden = m.amp_layers[0].linears()[0].out_features
+        cfg.n_phase_hidden = len(hidden)
+        for i, h in enumerate(hidden):
+            cfg.phase_hidden[i] = h
+        for i, q in enumerate(wf.qubit2model_permutation):
+            cfg.qubit2model[i] = int(q)
+        self._h = ctypes.c_void_p(None)
+        st = self._lib.naqs_net_create(ctypes.byref(cfg), self.device.index or 0, ctypes.byref(self._h))
+        _lib.check(st, "naqs_net_create")
+        n = ctypes.c_int64(0)
+        _lib.check(self._lib.naqs_net_param_count(self._h, ctypes.byref(n)), "naqs_net_param_count")
+        self.n_params = n.value
+        assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
+        self.refresh()
+
+    def refresh(self):
+        """Re-pack the current network parameters (call after every optimiser step)."""
+        flat = torch.cat([p.detach().reshape(-1) for p in self.wf.model.parameters()]).to(torch.float32).contiguous()
+        st = self._lib.naqs_net_set_weights(self._h, flat.data_ptr(), flat.numel(), _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_set_weights")
+        self._flat = flat          # keep alive until the async copy has been consumed
+
+    def log_psi(self, keys, out=None):
+        """keys: int64 device tensor [M] (uint64 bit patterns, qubit order) -> float32 [M, 2]."""
+        M = keys.shape[0]
+        if out is None:
+            out = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+        st = self._lib.naqs_net_logpsi(self._h, M, keys.contiguous().data_ptr(), out.data_ptr(),
+                                       _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_logpsi")
+        return out
+
+    def prof_enable(self, n):
+        _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")
+
+    def prof_read(self):
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        _lib.check(self._lib.naqs_net_prof_read(self._h, ctypes.byref(ms), ctypes.byref(n)), "naqs_net_prof_read")
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.naqs_net_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -45,3 +45,71 @@ def test_sampler_on_device_and_full_hot_path():
     want = oracle.eloc_matrix_free(hp.xy, hp.yz, hp.coeff, k_np.astype(np.uint64), psi)
     got = e[:, 0] + 1j * e[:, 1]
     assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) < 1e-9
+
+
+@pytest.mark.parametrize("mol", ["LiH", "H2O", "N2"])
+def test_fused_log_psi_matches_reference_and_torch(mol):
+    """naqs_net_logpsi (amp_kernel + MFMA phase_kernel) vs the reference's log psi and vs the PyTorch
+    modules on the same weights: float32 network, different summation order -> 5e-5 absolute."""
+    import os
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    fused = FusedLogPsi(wf)
+    keys = keys_to_device(z["eval_keys"], wf.device)
+    lp = fused.log_psi(keys)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(lp.cpu().numpy() - z["eval_log_psi"])) < 5e-5
+    with torch.no_grad():
+        lp_t = wf.log_psi(torch.tensor(z["eval_states"], device="cuda"))
+    assert torch.max(torch.abs(lp - lp_t)).item() < 2e-5
+    # every tile height of the MFMA kernel, and a batch that is not a multiple of the tile
+    for rb in ("1", "2", "3", "4"):
+        os.environ["NAQS_PHASE_RB"] = rb
+        try:
+            lp_rb = fused.log_psi(keys[:-3])
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["NAQS_PHASE_RB"]
+        assert torch.max(torch.abs(lp_rb - lp_t[:-3])).item() < 2e-5, rb
+
+
+def test_fused_log_psi_unphysical_and_masking_modes():
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    from naqs_amd.nade import NadeMasking
+    z = golden("nade_LiH.npz")
+    for masking in (NadeMasking.FULL, NadeMasking.NONE, NadeMasking.PARTIAL):
+        hil, wf = make_wf("LiH", z, device="cuda", masking=masking)
+        fused = FusedLogPsi(wf)
+        keys_np = np.r_[z["eval_keys"][:50].astype(np.int64), np.array([0b111111, 0b1, 0], np.int64)]  # last 3 unphysical
+        keys = keys_to_device(keys_np, wf.device)
+        lp = fused.log_psi(keys).cpu().numpy()
+        with torch.no_grad():
+            lp_t = wf.log_psi(hil.idx2state(torch.tensor(keys_np, device="cuda"))).cpu().numpy()
+        same_inf = np.array_equal(np.isinf(lp[:, 0]), np.isinf(lp_t[:, 0]))
+        fin = np.isfinite(lp_t[:, 0])
+        assert same_inf and np.max(np.abs(lp[fin] - lp_t[fin])) < 2e-5, masking
+
+
+def test_fused_refresh_after_parameter_update():
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden("nade_H2O.npz")
+    hil, wf = make_wf("H2O", z, device="cuda")
+    fused = FusedLogPsi(wf)
+    keys = keys_to_device(z["eval_keys"], wf.device)
+    before = fused.log_psi(keys).clone()
+    with torch.no_grad():
+        for p in wf.model.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    fused.refresh()
+    after = fused.log_psi(keys)
+    with torch.no_grad():
+        want = wf.log_psi(torch.tensor(z["eval_states"], device="cuda"))
+    assert torch.max(torch.abs(after - want)).item() < 2e-5
+    assert torch.max(torch.abs(after - before)).item() > 1e-3
