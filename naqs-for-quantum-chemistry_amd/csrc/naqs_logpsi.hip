@@ -4,10 +4,11 @@
 //
 // Two kernels per call (the PyTorch-eager formulation of the same thing is ~200 launches):
 //
-//   amp_kernel    one thread = one (sample, orbital pair n).  The 2n prefix occupations are built
-//                 from key bits, spin-ordered (nade.py:519-530) and kept in registers; the pair's
-//                 MLP weights are wave-uniform (blockIdx.y = n), so they arrive through scalar
-//                 loads and feed v_fmac straight from SGPRs.  Symmetrisation (:585-586), the
+//   amp_kernel    one workgroup = 64 samples x one orbital pair n; its 4 waves split the hidden units.
+//                 The 2n prefix occupations are built from key bits, spin-ordered (nade.py:519-530)
+//                 and kept in registers; the pair's MLP weights are staged once per workgroup in LDS and
+//                 read back as broadcast 16-byte reads (scalar loads were measured 5x slower here: ten
+//                 pairs' weight sets thrash the small scalar cache).  Symmetrisation (:585-586), the
 //                 electron-budget mask (:426-474) and 0.5*log_softmax(2x) (activations.py:40-46)
 //                 are fused; the log-amplitude of the realised outcome goes to scratch[n][i].
 //   phase_kernel  the phase MLP (e.g. 18 -> 512 -> 512 -> 4) for a tile of BM samples per workgroup,
@@ -49,8 +50,8 @@ struct NetDims {
     int32_t Ha;                        // amplitude hidden width
     int32_t n_out_amp;                 // 5 with symmetry, 4 without
     uint8_t qa[MAXP], qb[MAXP];        // qubit (bit) index of the alpha / beta orbital of model pair n
-    int32_t amp_off[MAXP];             // offset (floats) of pair n's parameters in the flat buffer:
-                                       //   W1 [Ha][max(1,2n)], b1 [Ha], W2 [n_out][Ha], b2 [n_out]
+    int32_t amp_off[MAXP];             // offset (floats) of pair n's packed parameters: Ha rows of
+                                       //   [W1[j][0..nin) | b1[j] | W2[0..5)[j] | pad] (16-byte multiples), then b2 [8]
     // phase MLP, packed & zero-padded: layer l: W [Nout_pad][K_pad], bias [Nout_pad]
     int32_t n_lin;
     int32_t K_pad[MAXL], N_pad[MAXL], w_off[MAXL], b_off[MAXL];
@@ -60,21 +61,13 @@ struct NetDims {
 // ------------------------------------------------------------------------------------------------
 // amplitude conditionals
 // ------------------------------------------------------------------------------------------------
+constexpr int AMP_WAVES = 4;      // the hidden units of one block are split over the 4 waves of a workgroup
+
+// partial output sums of pair NB over hidden units [j0, j1): o[c] += W2[c][j] * relu(W1[j].x + b1[j])
 template <int NB>
-__device__ __forceinline__ float amp_block(const NetDims &d, const float *__restrict__ w, uint64_t key) {
+__device__ __forceinline__ void amp_partial(const NetDims &d, const float *__restrict__ w, uint32_t first,
+                                            uint32_t second, int j0, int j1, float (&o)[5]) {
     constexpr int NIN = NB == 0 ? 1 : 2 * NB;
-    // prefix occupations of pairs 0..NB-1 and the realised outcome of pair NB
-    uint32_t abits = 0, bbits = 0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
-        bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
-    }
-    const int occ = (int)((key >> d.qa[NB]) & 1ull) + 2 * (int)((key >> d.qb[NB]) & 1ull);
-    // spin ordering: the string with the smaller index goes first (nade.py:399-405, :519-530)
-    const bool swap = d.sym && abits > bbits;
-    const int x_order = !d.sym ? 2 : (abits > bbits ? 0 : (abits == bbits ? 1 : 2));
-    const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
     float x[NIN];
     if (NB == 0) {
         x[0] = 0.0f;
@@ -85,23 +78,28 @@ __device__ __forceinline__ float amp_block(const NetDims &d, const float *__rest
             x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
         }
     }
-    const int Ha = d.Ha, nout = d.n_out_amp;
-    const float *W1 = w + d.amp_off[NB];
-    const float *b1 = W1 + Ha * NIN;
-    const float *W2 = b1 + Ha;
-    const float *b2 = W2 + nout * Ha;
-    float o[5];
+    const int nout = d.n_out_amp;
+    constexpr int S = (NIN + 1 + 5 + 3) & ~3;          // packed row: W1[j][:], b1[j], W2[:][j], padded to 16 bytes
+    const float *rows = w;                             // this pair's rows, staged in LDS by the workgroup
+#pragma unroll 2
+    for (int j = j0; j < j1; ++j) {
+        const float *row = rows + j * S;               // same address in every lane -> LDS broadcast reads
+        // two interleaved accumulation chains keep the FMA pipe busier than one 2n-long dependent chain
+        float h0 = row[NIN], h1 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 5; ++c) o[c] = c < nout ? b2[c] : 0.0f;
-    for (int j = 0; j < Ha; ++j) {
-        float h = b1[j];
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) h = fmaf(W1[j * NIN + k], x[k], h);
-        h = fmaxf(h, 0.0f);
+        for (int k = 0; k + 1 < NIN; k += 2) { h0 = fmaf(row[k], x[k], h0); h1 = fmaf(row[k + 1], x[k + 1], h1); }
+        if (NIN & 1) h0 = fmaf(row[NIN - 1], x[NIN - 1], h0);
+        const float h = fmaxf(h0 + h1, 0.0f);
 #pragma unroll
         for (int c = 0; c < 5; ++c)
-            if (c < nout) o[c] = fmaf(W2[c * Ha + j], h, o[c]);
+            if (c < nout) o[c] = fmaf(row[NIN + 1 + c], h, o[c]);
     }
+}
+
+// symmetrise, mask, 0.5*log_softmax(2x), select the realised outcome
+__device__ __forceinline__ float amp_finish(const NetDims &d, int NB, const float (&o)[5], uint32_t abits,
+                                            uint32_t bbits, int occ) {
+    const int x_order = !d.sym ? 2 : (abits > bbits ? 0 : (abits == bbits ? 1 : 2));
     // symmetrise 5 -> 4 (nade.py:585-586): (o[0,1,1,2] + o[idx2sort[x_order]]) / 2
     float a4[4];
     if (d.sym) {
@@ -135,21 +133,59 @@ __device__ __forceinline__ float amp_block(const NetDims &d, const float *__rest
     return sel_ok ? 0.5f * ((sel - m) - logf(s)) : -INFINITY;
 }
 
-__global__ __launch_bounds__(256) void amp_kernel(const NetDims d, const float *__restrict__ w, int64_t M,
-                                                  const uint64_t *__restrict__ keys, float *__restrict__ scratch) {
-    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
-    if (i >= M) return;
-    const uint64_t key = keys[i];
-    const int n = blockIdx.y;            // wave-uniform -> the weights come through scalar loads
-    float la;
+// workgroup = 64 samples x one orbital pair n (blockIdx.y); its 4 waves split the hidden units
+__global__ __launch_bounds__(AMP_WAVES * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w, int64_t M,
+                                                               const uint64_t *__restrict__ keys,
+                                                               float *__restrict__ scratch) {
+    __shared__ float s_part[AMP_WAVES][5][WAVE];
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // this pair's packed rows + b2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const int nin_ = blockIdx.y == 0 ? 1 : 2 * (int)blockIdx.y;
+        const int total = d.Ha * ((nin_ + 1 + 5 + 3) & ~3) + 8;
+        const float *src = w + d.amp_off[blockIdx.y];
+        for (int e = threadIdx.x; e < total; e += AMP_WAVES * WAVE) s_w[e] = src[e];
+        __syncthreads();
+    }
+    const int64_t i = blockIdx.x * (int64_t)WAVE + lane;
+    const int n = blockIdx.y;            // workgroup-uniform -> the weights come through scalar loads
+    const uint64_t key = i < M ? keys[i] : 0ull;
+    // prefix occupations of pairs 0..n-1 and the realised outcome of pair n
+    uint32_t abits = 0, bbits = 0;
+    for (int k = 0; k < n; ++k) {
+        abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+        bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+    }
+    const int occ = (int)((key >> d.qa[n]) & 1ull) + 2 * (int)((key >> d.qb[n]) & 1ull);
+    // spin ordering: the string with the smaller index goes first (nade.py:399-405, :519-530)
+    const bool swap = d.sym && abits > bbits;
+    const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
+    const int per = (d.Ha + AMP_WAVES - 1) / AMP_WAVES;
+    const int j0 = min(d.Ha, wave * per), j1 = min(d.Ha, j0 + per);
+    float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     switch (n) {
-#define CASE(NB) case NB: la = amp_block<NB>(d, w, key); break;
+#define CASE(NB) case NB: amp_partial<NB>(d, s_w, first, second, j0, j1, o); break;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
         CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
 #undef CASE
-        default: la = 0.0f;
+        default: break;
     }
-    scratch[(int64_t)n * M + i] = la;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s_part[wave][c][lane] = o[c];
+    __syncthreads();
+    if (wave == 0 && i < M) {
+        const int nin = n == 0 ? 1 : 2 * n;
+        const float *b2 = s_w + d.Ha * ((nin + 1 + 5 + 3) & ~3);
+        float t[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            float v = c < d.n_out_amp ? b2[c] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < AMP_WAVES; ++q) v += s_part[q][c][lane];      // fixed order
+            t[c] = v;
+        }
+        scratch[(int64_t)n * M + i] = amp_finish(d, n, t, abits, bbits, occ);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,6 +306,25 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
 }
 
 // re-pack the flat state_dict-order parameters into the kernels' layout
+// amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]] ->
+// Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
+__global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ src, int Ha, int nin, int nout,
+                                                       float *__restrict__ dst) {
+    const int S = (nin + 1 + 5 + 3) & ~3, total = Ha * S + 8;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        float v = 0.0f;
+        if (e < Ha * S) {
+            const int j = e / S, c = e - j * S;
+            if (c < nin) v = src[j * nin + c];
+            else if (c == nin) v = src[Ha * nin + j];
+            else if (c - nin - 1 < nout) v = src[Ha * nin + Ha + (c - nin - 1) * Ha + j];
+        } else if (e - Ha * S < nout) {
+            v = src[Ha * nin + Ha + nout * Ha + (e - Ha * S)];
+        }
+        dst[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_phase_kernel(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
                                                          float *__restrict__ Wd, float *__restrict__ bd) {
     const int total = N_pad * K_pad;
@@ -291,7 +346,8 @@ struct naqs_net {
     naqs_net_config_t cfg{};
     NetDims dims{};
     int64_t n_params = 0;
-    int64_t amp_params = 0;                 // floats of all amplitude blocks (copied verbatim)
+    int64_t amp_params = 0;                 // floats of all amplitude blocks in the flat source
+    int64_t amp_src_off[MAXP] = {};         // per pair: offset in the flat source
     std::vector<int64_t> phase_src_off;     // per phase linear layer: offset in the flat source
     std::vector<int> phase_K, phase_N;
     float *d_w = nullptr;                   // [amp params | packed phase layers]
@@ -339,17 +395,19 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     d.Ha = cfg->amp_hidden;
     d.n_out_amp = d.sym ? 5 : 4;
     for (int n = 0; n < P; ++n) { d.qa[n] = (uint8_t)cfg->qubit2model[2 * n]; d.qb[n] = (uint8_t)cfg->qubit2model[2 * n + 1]; }
-    int64_t off = 0;
+    int64_t off = 0, poff = 0;
     for (int n = 0; n < P; ++n) {
-        d.amp_off[n] = (int32_t)off;
+        net->amp_src_off[n] = off;
+        d.amp_off[n] = (int32_t)poff;
         const int nin = n == 0 ? 1 : 2 * n;
         off += (int64_t)d.Ha * nin + d.Ha + (int64_t)d.n_out_amp * d.Ha + d.n_out_amp;
+        poff += (int64_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
     }
     net->amp_params = off;
     // phase block: 2(P-1) -> hidden... -> 4
     int K = std::max(1, 2 * (P - 1));
     d.n_lin = cfg->n_phase_hidden + 1;
-    int64_t src = off, dst = off;
+    int64_t src = off, dst = poff;
     int max_k = 0;
     for (int l = 0; l < d.n_lin; ++l) {
         const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : 4;
@@ -414,8 +472,14 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(net->d_w, flat_dev, (size_t)net->amp_params * sizeof(float), hipMemcpyDeviceToDevice, s));
     const NetDims &d = net->dims;
+    for (int n = 0; n < d.P; ++n) {
+        const int nin = n == 0 ? 1 : 2 * n;
+        const int total = d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
+        hipLaunchKernelGGL(pack_amp_kernel, dim3((total + 255) / 256), dim3(256), 0, s, flat_dev + net->amp_src_off[n], d.Ha, nin,
+                           d.n_out_amp, net->d_w + d.amp_off[n]);
+        HIP_TRY(hipGetLastError());
+    }
     for (int l = 0; l < d.n_lin; ++l) {
         const int total = d.N_pad[l] * d.K_pad[l] + d.N_pad[l];
         hipLaunchKernelGGL(pack_phase_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
@@ -445,7 +509,8 @@ NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_de
         net->cap_M = cap;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)d.P), dim3(256), 0, s, d, net->d_w, M,
+    const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + WAVE - 1) / WAVE), (unsigned)d.P), dim3(AMP_WAVES * WAVE), amp_lds, s, d, net->d_w, M,
                        keys_dev, net->d_scratch);
     HIP_TRY(hipGetLastError());
 
