@@ -1,0 +1,384 @@
+"""VMC energy optimisation: the counterpart of the reference's ``OptimizerBase`` /
+``PartialSamplingOptimizer`` (src/optimizer/energy.py:43-538, :731-1056) on top of the MI355X
+local-energy path.
+
+Same constructor keywords (experiments/_base.py:209-246), method names and log / checkpoint
+formats; what changes is where the work happens:
+
+  * ``calculate_local_energy`` is one call into ``libnaqs_hip.so`` (matrix-free, f64, on the GPU)
+    instead of update_H + get_H + sparse_dense_mv on the host (energy.py:219-263);
+  * samples, log psi, weights, E_loc and the VMC loss stay on the device for the whole step
+    (the reference moves every network output to the CPU, nade.py:194);
+  * multi-GPU (``torch.distributed`` initialised, backend nccl = RCCL on ROCm): every rank draws the
+    same unique-sample table (same generator seed), evaluates E_loc and back-propagates the loss for
+    its contiguous shard of rows, and the only collectives are an all-reduce of the four energy
+    accumulators and one of the flat gradient buffer.  The reference has no distributed code.
+
+Reference quirk NOT mirrored: the full-sample reordering bug (hamiltonian.py:100-105) —
+E_loc here is always in sample order.  Energies are reported from float64 E_loc (the reference
+rounds E_loc to float32 first, energy.py:260-261).
+"""
+import math
+import os
+import time
+from collections import Counter
+from enum import Enum
+
+import numpy as np
+import torch
+
+from .hamiltonian import PauliHamiltonian, keys_to_device
+from .nade import MaxBatchSizeExceededError
+
+
+class LogKey(Enum):                       # src/optimizer/utils.py:9-17
+    E = "Energy"
+    E_LOC = "Local energy"
+    E_LOC_VAR = "Local energy variance"
+    N_UNIQUE_SAMP = "Number of unique samples"
+    TIME = "Time"
+
+    def __str__(self):
+        return self.value
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced row shards: rank r gets [n*r//world, n*(r+1)//world)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def vmc_loss(log_psi, e_loc, weights, e_mean):
+    """2 * Re sum_i w_i * log psi_i * (E_loc_i - <E>)  with log psi = (log|psi|, phase) and complex
+    E_loc = (Re, Im): energy.py:328-329 with complex.py:49-58 written out."""
+    ec = e_loc - e_mean
+    return 2.0 * (weights * (log_psi[:, 0] * ec[:, 0] - log_psi[:, 1] * ec[:, 1])).sum()
+
+
+class OptimizerBase:
+    def __init__(self, wavefunction, qubit_hamiltonian, pre_compute_H=True, n_electrons=None,
+                 n_alpha_electrons=None, n_beta_electrons=None, n_fixed_electrons=None, n_excitations_max=None,
+                 reweight_samples_by_psi=False, normalise_psi=False, normalize_grads=False, grad_clip_factor=3,
+                 grad_clip_memory_length=50, optimizer=torch.optim.Adam, optimizer_args={'lr': 1e-3},
+                 scheduler=None, scheduler_args=None, save_loc='./', pauli_hamiltonian_fname=None,
+                 overwrite_pauli_hamiltonian=False, pauli_hamiltonian_dtype=np.float32, verbose=False, seed=None):
+        if grad_clip_factor is not None:
+            raise NotImplementedError("gradient clipping is unused by the reference's run path (_base.py:224)")
+        if n_fixed_electrons not in (None, 0) or n_excitations_max is not None:
+            raise NotImplementedError("frozen-core / excitation-limited runs are out of scope")
+        self.wavefunction = wavefunction
+        self.hilbert = wavefunction.hilbert
+        self.qubit_hamiltonian = qubit_hamiltonian
+        self.device = wavefunction.device
+        self.reweight_samples_by_psi = reweight_samples_by_psi
+        self.normalise_psi = normalise_psi
+        self.n_electrons, self.n_alpha_electrons, self.n_beta_electrons = n_electrons, n_alpha_electrons, n_beta_electrons
+        self.n_fixed_electrons, self.n_excitations_max = n_fixed_electrons, n_excitations_max
+        self.subspace_args = {}
+        self.optimizer_callable, self.optimizer_args = optimizer, optimizer_args
+        self.scheduler_callable, self.scheduler_args = scheduler, scheduler_args
+        self.normalize_grads = normalize_grads
+        self.save_loc = save_loc
+        self.verbose = verbose
+        self.pauli_hamiltonian_fname = pauli_hamiltonian_fname
+        self.overwrite_pauli_hamiltonian = False          # no matrix cache to write (matrix-free)
+        self.pauli_hamiltonian = PauliHamiltonian.get(self.hilbert, qubit_hamiltonian, verbose=verbose,
+                                                      dtype=pauli_hamiltonian_dtype, device=self.device)
+        self.generator = torch.Generator(device=self.device)
+        if seed is not None:
+            self.generator.manual_seed(int(seed))
+        else:
+            self.generator.manual_seed(torch.initial_seed() % (2 ** 63))
+        self.sampled_idxs = Counter()
+        self.track_sampled_idxs = True
+        self.reset_log()
+        self.reset_optimizer()
+
+    # ---- bookkeeping (energy.py:141-187) ----
+    def reset_log(self):
+        self.log = {LogKey.E: [], LogKey.E_LOC: [], LogKey.E_LOC_VAR: [], LogKey.N_UNIQUE_SAMP: [], LogKey.TIME: []}
+        self.n_steps = self.n_epochs = 0
+        self.run_time = 0
+
+    def reset_optimizer(self, cond_idx=None):
+        if isinstance(self.optimizer_args, dict):
+            self.optimizer = self.optimizer_callable(self.wavefunction.conditional_parameters(cond_idx),
+                                                     **self.optimizer_args)
+        else:       # list of per-group arguments: group 0 = network, group 1 = look-up tables (energy.py:167-172)
+            groups = []
+            for idx, a in enumerate(self.optimizer_args):
+                a = dict(a)
+                a['params'] = self.wavefunction.parameters(idx)
+                groups.append(a)
+            self.optimizer = self.optimizer_callable(groups)
+        self.scheduler = (self.scheduler_callable(self.optimizer, **self.scheduler_args)
+                          if self.scheduler_callable is not None else None)
+
+    # ---- the hot path ----
+    @torch.no_grad()
+    def calculate_local_energy(self, states_idx, psi=None, set_unsampled_states_to_zero=True, ret_complex=False,
+                               log_psi=None, row_begin=0, n_rows=None):
+        """E_loc of the sampled states (energy.py:219-263).  ``psi``: [M, 2] (Re, Im) like the
+        reference, or pass ``log_psi`` [M, 2] = (log|psi|, phase) directly (better conditioned).
+        Un-sampled connected states contribute zero — the only mode the reference implements.
+        Returns a float64 device tensor [n_rows, 2], or a complex128 numpy array with ret_complex."""
+        if not set_unsampled_states_to_zero:
+            raise NotImplementedError()
+        keys = keys_to_device(states_idx, self.device)
+        if psi is None and log_psi is None:
+            log_psi = self.wavefunction.log_psi(self.hilbert.idx2state(keys))
+        if log_psi is not None:
+            e = self.pauli_hamiltonian.local_energy(keys, log_psi.detach().to(self.device), kind="log_psi",
+                                                    row_begin=row_begin, n_rows=n_rows)
+        else:
+            e = self.pauli_hamiltonian.local_energy(keys, psi.detach().to(self.device), kind="psi",
+                                                    row_begin=row_begin, n_rows=n_rows)
+        if ret_complex:
+            v = e.cpu().numpy()
+            return v[:, 0] + 1j * v[:, 1]
+        return e
+
+    @torch.no_grad()
+    def calculate_energy(self, normalise_psi=None):
+        """<psi|H|psi> over the whole restricted space (energy.py:189-217); small spaces only."""
+        states, idx = self.hilbert.get_subspace(ret_states=True, ret_idxs=True)
+        keys = keys_to_device(idx, self.device)
+        lp = self.wavefunction.log_psi(states.to(self.device)).reshape(-1, 2)
+        e = self.pauli_hamiltonian.local_energy(keys, lp, kind="log_psi")
+        p = (2.0 * lp[:, 0].double()).exp()
+        sums = self.pauli_hamiltonian.reduce(p, e)
+        energy = sums[0] / (sums[3] if normalise_psi else 1.0)
+        return float(energy.item())
+
+    def _SGD_step(self, states, states_idx, log_psi=None, sample_weights=None, log_psi_eval=None,
+                  regularisation_loss=None, n_samps=None, e_loc_clip_factor=None):
+        """One VMC step for the sampled states (energy.py:273-377): E_loc (no grad) -> loss
+        2 Re sum w log psi (E_loc - <E>) -> backward -> optimiser step -> (<E>, Var)."""
+        dist = _dist()
+        world, rank = (dist.get_world_size(), dist.get_rank()) if dist else (1, 0)
+        keys = keys_to_device(states_idx, self.device)
+        M = keys.shape[0]
+        if self.track_sampled_idxs:
+            self.sampled_idxs.update(keys.cpu().numpy().tolist())
+        # shard of rows this rank owns (the whole table when single-process)
+        b, e_ = shard_bounds(M, rank, world)
+        if log_psi is not None:
+            # reference-style call: log psi of the whole table, carrying gradients
+            lp_all, lp_mine = log_psi.reshape(-1, 2), log_psi.reshape(-1, 2)[b:e_]
+        else:
+            # gradients only for the owned rows; the table needed for the psi look-ups is evaluated
+            # without autograd (the rows of other ranks are theirs to differentiate)
+            lp_mine = self.wavefunction.log_psi(states[b:e_]).reshape(-1, 2)
+            if world == 1:
+                lp_all = lp_mine
+            else:
+                with torch.no_grad():
+                    lp_all = self.wavefunction.log_psi(states).reshape(-1, 2)
+        if sample_weights is None:
+            if not self.reweight_samples_by_psi:
+                raise NotImplementedError("Re-weighting by the number of samples is not yet implemented.")
+            sample_weights = lp_all.detach()[..., 0].exp().pow(2)
+            if self.normalise_psi:
+                sample_weights = sample_weights / sample_weights.sum()
+        w = sample_weights.reshape(-1).to(self.device, torch.float64)
+
+        e_loc = self.calculate_local_energy(keys, log_psi=lp_all, row_begin=b, n_rows=e_ - b)
+        sums = self.pauli_hamiltonian.reduce(w[b:e_], e_loc)            # sum w Re, sum w Im, sum w Re^2, sum w
+        if dist:
+            dist.all_reduce(sums)
+        e_mean = torch.stack([sums[0], sums[1]])                        # (sum w E_loc), like energy.py:328 (w not renormalised)
+
+        loss = vmc_loss(lp_mine, e_loc.to(lp_mine.dtype), w[b:e_].to(lp_mine.dtype), e_mean.to(lp_mine.dtype))
+        self.optimizer.zero_grad()
+        if self.normalize_grads:
+            loss = loss / loss.detach().abs()
+        if regularisation_loss is not None:
+            loss = loss + regularisation_loss
+        loss.backward()
+        self.last_loss = loss.detach()
+        if dist:
+            params = [p for g in self.optimizer.param_groups for p in g['params'] if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)                                       # shards SUM to the full-batch gradient
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+        with torch.no_grad():                                           # energy.py:367-377
+            energy = sums[0] / sums[3]
+            variance = sums[2] / sums[3] - energy * energy
+        return float(energy.item()), float(variance.item())
+
+    # ---- checkpoints / logs: same keys as the reference (energy.py:400-538) ----
+    def _fmt(self, fname):
+        if os.path.splitext(fname)[-1] != '.pth':
+            fname += '.pth'
+        if not os.path.isabs(fname):
+            fname = os.path.join(self.save_loc, fname)
+        return fname
+
+    def save(self, fname="energy_optimizer", quiet=False):
+        dist = _dist()
+        if dist and dist.get_rank() != 0:
+            return
+        fname = self._fmt(fname)
+        d = os.path.dirname(fname)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        wf_fname = self.wavefunction.save(os.path.splitext(fname)[0] + '_naqs', quiet)
+        torch.save({'optimizer:state_dict': self.optimizer.state_dict(), 'run_time': self.run_time,
+                    'n_steps': self.n_steps, 'n_epochs': self.n_epochs, 'log': self.log,
+                    'sampled_idxs': self.sampled_idxs, 'wavefunction:fname': wf_fname,
+                    'hamiltonian_fname': self.pauli_hamiltonian_fname}, fname)
+        if not quiet:
+            print(f"Saving checkpoint {fname}...done.")
+
+    def load(self, fname="energy_optimizer", quiet=False):
+        fname = self._fmt(fname)
+        ck = torch.load(fname, map_location=self.device, weights_only=False)
+        try:
+            self.wavefunction.load(ck['wavefunction:fname'])
+        except Exception:
+            print(f"\twavefunction not found (expected at {ck['wavefunction:fname']})")
+        try:
+            self.optimizer.load_state_dict(ck['optimizer:state_dict'])
+        except Exception:
+            print("\tOptimizer could not be loaded.")
+        self.log, self.n_steps, self.n_epochs = ck['log'], ck['n_steps'], ck['n_epochs']
+        self.run_time, self.sampled_idxs = ck['run_time'], ck['sampled_idxs']
+        if not quiet:
+            print(f"Loading checkpoint {fname}...done.")
+
+    def save_log(self, fname="log", quiet=False):
+        import pandas as pd
+        fname = os.path.splitext(os.path.join(self.save_loc, fname))[0] + ".pkl"
+        os.makedirs(os.path.dirname(fname) or ".", exist_ok=True)
+        df = None
+        for key, value in self.log.items():
+            dk = pd.DataFrame(value, columns=["Iteration", key])
+            df = dk if df is None else pd.merge(df, dk, how="outer", on="Iteration")
+        if df is not None:
+            df.sort_values("Iteration").reset_index(drop=True).to_pickle(fname)
+            if not quiet:
+                print("Log saved to", fname)
+
+
+class PartialSamplingOptimizer(OptimizerBase):
+    """Optimise with partial sampling of the Hilbert space (energy.py:731-1056)."""
+
+    def __init__(self, n_samples, n_samples_max=1e9, n_unq_samples_min=1000, n_unq_samples_max=1e6,
+                 log_exact_energy=True, **kwargs):
+        kwargs['reweight_samples_by_psi'] = False
+        super().__init__(**kwargs)
+        self.log_exact_energy = log_exact_energy
+        self.n_samples = int(n_samples)
+        self.n_samples_max = int(n_samples_max)
+        self.n_unq_samples_min = int(n_unq_samples_min)
+        self.n_unq_samples_max = int(n_unq_samples_max)
+
+    def get_n_samples(self):
+        return self.n_samples
+
+    def pre_flatten(self, n_epochs, *args, **kwargs):
+        if n_epochs:
+            raise NotImplementedError("pre_flatten with n_epochs > 0 (unused: n_pretrain=0, experiments/run.py:14)")
+
+    def get_samples(self, last_action=0):
+        """Adaptive sample count (energy.py:936-971): x10 while too few unique samples, /10 when too many
+        or when the unique-prefix tree exceeds ``n_unq_samples_max``."""
+        action = 0
+        try:
+            states, counts, probs = self.wavefunction.sample(
+                self.n_samples, ret_log_psi=False, max_batch_size=self.n_unq_samples_max, generator=self.generator)
+            n_unq, completed = len(states), True
+        except MaxBatchSizeExceededError:
+            print("MaxBatchSizeExceededError")
+            n_unq, completed, action = self.n_unq_samples_max + 1, False, -1
+        if ((self.n_samples != self.n_unq_samples_min) and (self.n_samples != self.n_samples_max)) or not completed:
+            if n_unq < self.n_unq_samples_min and last_action >= 0:
+                action = 1
+                self.n_samples = int(min(self.n_samples * 10, self.n_samples_max))
+                print(f"\t...{n_unq} unique samples generated --> increasing batch size to "
+                      f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
+            elif n_unq > self.n_unq_samples_max and last_action <= 0:
+                action = -1
+                self.n_samples = int(max(self.n_samples / 10, self.n_unq_samples_min))
+                print(f"\t...{n_unq} unique samples generated --> decreasing batch size to "
+                      f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
+        if action != 0:
+            return self.get_samples(action)
+        return states, counts, probs
+
+    def solve_H(self, n_samps=None, ret_n_samps=True):
+        """Lowest eigenpair of H restricted to the sampled states (energy.py:762-786)."""
+        import scipy.sparse.linalg as spla
+        if n_samps is None:
+            n_samps = self.get_n_samples()
+        with torch.no_grad():
+            states, counts, probs = self.wavefunction.sample(n_samps, ret_log_psi=False, generator=self.generator)
+        n_unq = len(states)
+        if n_unq > 10000:
+            print(f"Limiting number of sampled states from {n_unq} is to most likely 10000.")
+            states = states[torch.argsort(counts)[-10000:]]
+        keys = self.hilbert.state2idx(states).squeeze(-1)
+        H = self.pauli_hamiltonian.get_H(keys)
+        if H.shape[0] < 3:
+            w, v = np.linalg.eigh(H.toarray())
+            val, vec = w[0], v[:, 0]
+        else:
+            w, v = spla.eigsh(H.astype(np.float64), k=1, which='SA')
+            val, vec = w[0], v[:, 0]
+        vec = vec * np.sign(vec[0])
+        return (float(val), vec[0], n_unq) if ret_n_samps else (float(val), vec[0])
+
+    def run(self, n_epochs, save_freq=None, save_final=False, reset_log=False, reset_optimizer=False,
+            output_freq=50):
+        if reset_log:
+            self.reset_log()
+        if reset_optimizer:
+            self.reset_optimizer()
+        run_time_at_last_log, steps_at_last_log = self.run_time, self.n_steps
+        print("Training NAQS energy.  Samples will be weighted by their frequency.")
+        if self.n_steps == 0:
+            self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=False)
+        for _ in range(n_epochs):
+            t0 = time.time()
+            states, counts, probs = self.get_samples()
+            weights = counts.double() / counts.sum().double()                         # energy.py:993
+            keys = self.hilbert.state2idx(states).squeeze(-1)
+            e, var = self._SGD_step(states, keys, None, sample_weights=weights)
+            self.n_steps += 1
+            self.run_time += time.time() - t0
+            self.log[LogKey.E_LOC].append((self.n_steps, e))
+            self.log[LogKey.E_LOC_VAR].append((self.n_steps, var))
+            self.log[LogKey.N_UNIQUE_SAMP].append((self.n_steps, len(weights)))
+            self.log[LogKey.TIME].append((self.n_steps, self.run_time))
+            self.n_epochs += 1
+            if (self.n_epochs % output_freq == 0) or (self.n_epochs == 1):
+                energy = self.calculate_energy(normalise_psi=True) if self.log_exact_energy else None
+                self.log[LogKey.E].append((self.n_steps, energy))
+                recent = [x[1] for x in self.log[LogKey.E_LOC][-min(output_freq, self.n_epochs):]]
+                tpe = (self.run_time - run_time_at_last_log) / output_freq
+                run_time_at_last_log = self.run_time
+                n_steps_in = self.n_steps - steps_at_last_log
+                steps_at_last_log = self.n_steps
+                n = counts.sum().item()
+                samp = f"{n:.1f}" if n < 1e3 else (f"{n / 1e3:.1f}k" if n < 1e6 else
+                                                   (f"{n / 1e6:.1f}M" if n < 1e9 else f"{n / 1e9:.1f}B"))
+                e_str = "N/A" if energy is None else f"{energy:.5f}"
+                print(f"Epoch {self.n_epochs} ({n_steps_in} SGD steps with {samp} samples ({len(weights)} unq.) : "
+                      f"<E>={e_str}, <E_loc>={np.mean(recent):.5f} +\\- {np.std(recent):.5f}, "
+                      f"var(<E_loc>)={var:.5f}, epoch time={tpe:.2f}s, total time={self.run_time:.1f}s")
+            if save_freq is not None and self.n_epochs % save_freq == 0:
+                self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=True)
+        if save_final:
+            self.save(quiet=False)

@@ -1,0 +1,136 @@
+"""Host logic of the VMC step on CPU (kernels replaced by the oracle-backed test stand-in):
+one _SGD_step against the reference's recorded step, the adaptive sampling loop, checkpoints, and
+the multi-process path (gloo, world_size 2) against the single-process result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, golden
+from naqs_amd import packing
+from test_nade import ELECTRONS, make_wf
+
+ADAM = [{'lr': 1e-3, 'betas': (0.9, 0.99), 'weight_decay': 0, 'eps': 1e-15, 'amsgrad': False}, {'lr': 1e-2}]
+
+
+def make_opt(mol, tmp, monkeypatch=None, seed=3, **kw):
+    import oracle_backend
+    from naqs_amd.optimizer import PartialSamplingOptimizer
+    if monkeypatch is not None:
+        oracle_backend.install(monkeypatch)
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z)
+    N, na, nb = ELECTRONS[mol]
+    ham = packing.load_packed(os.path.join(GOLDEN, f"ham_{mol}.npz"))
+    args = dict(n_samples=2000, n_samples_max=1e12, n_unq_samples_min=10, n_unq_samples_max=1e5, log_exact_energy=False,
+                wavefunction=wf, qubit_hamiltonian=ham, pre_compute_H=False, n_electrons=na + nb, n_alpha_electrons=na,
+                n_beta_electrons=nb, normalise_psi=True, grad_clip_factor=None, optimizer=torch.optim.Adam,
+                optimizer_args=[dict(a) for a in ADAM], save_loc=str(tmp), pauli_hamiltonian_dtype=np.float64, seed=seed)
+    args.update(kw)
+    return z, hil, wf, PartialSamplingOptimizer(**args)
+
+
+@pytest.mark.parametrize("mol", ["LiH", "H2O"])
+def test_sgd_step_matches_reference_step(mol, tmp_path, monkeypatch):
+    """Same samples, same weights, same Adam: energy, variance and the parameters AFTER the step
+    must match what the reference recorded (tests/golden/make_golden.py, energy.py:273-377)."""
+    z, hil, wf, opt = make_opt(mol, tmp_path, monkeypatch)
+    states = torch.tensor(z["samp_states"])
+    counts = torch.tensor(z["samp_counts"])
+    keys = hil.state2idx(states).squeeze(-1)
+    E, var = opt._SGD_step(states, keys, None, sample_weights=counts.double() / counts.sum().double())
+    assert abs(E - float(z["sgd_E"])) < 2e-5 * max(1, abs(E))            # reference rounds E_loc to float32
+    assert abs(var - float(z["sgd_Var"])) < 1e-3 * max(1, abs(var))
+    assert abs(opt.last_loss.item() - float(z["sgd_loss"])) < 1e-4 * max(1, abs(float(z["sgd_loss"])))
+    for name, p in wf.model.named_parameters():
+        after = z["sd_after:" + name]
+        assert np.max(np.abs(p.detach().numpy() - after)) < 2e-5, name    # lr = 1e-3 first Adam step
+
+
+def test_run_loop_decreases_energy_and_logs(tmp_path, monkeypatch, capsys):
+    from naqs_amd.optimizer import LogKey
+    z, hil, wf, opt = make_opt("LiH", tmp_path, monkeypatch, n_samples=20000)
+    opt.run(n_epochs=30, save_freq=None, save_final=True, output_freq=10)
+    e = [x[1] for x in opt.log[LogKey.E_LOC]]
+    assert len(e) == 30 and opt.n_steps == 30 and np.mean(e[-5:]) < np.mean(e[:5]) - 0.05
+    assert os.path.exists(tmp_path / "opt_0steps.pth") and os.path.exists(tmp_path / "energy_optimizer.pth")
+    assert "Epoch 10" in capsys.readouterr().out
+    ck = torch.load(tmp_path / "energy_optimizer.pth", weights_only=False)
+    assert set(ck) == {'optimizer:state_dict', 'run_time', 'n_steps', 'n_epochs', 'log', 'sampled_idxs',
+                       'wavefunction:fname', 'hamiltonian_fname'}
+    # resume
+    z2, hil2, wf2, opt2 = make_opt("LiH", tmp_path, None)
+    opt2.load()
+    assert opt2.n_steps == 30 and len(opt2.log[LogKey.E_LOC]) == 30
+    s = torch.tensor(z["eval_states"][:8])
+    with torch.no_grad():
+        assert torch.allclose(wf.log_psi(s), wf2.log_psi(s))
+    opt.save_log(quiet=True)
+    import pandas as pd
+    df = pd.read_pickle(tmp_path / "log.pkl")
+    assert "Iteration" in df.columns and len(df) == 30
+
+
+def test_adaptive_sample_count(tmp_path, monkeypatch, capsys):
+    """get_samples (energy.py:936-971): too few unique samples -> x10; too many -> /10."""
+    z, hil, wf, opt = make_opt("LiH", tmp_path, monkeypatch, n_samples=10, n_unq_samples_min=50, n_unq_samples_max=1000)
+    states, counts, probs = opt.get_samples()
+    assert opt.n_samples > 10 and len(states) >= 50
+    assert "increasing batch size" in capsys.readouterr().out
+    z, hil, wf, opt = make_opt("LiH", tmp_path, None, n_samples=10 ** 7, n_unq_samples_min=5, n_unq_samples_max=60)
+    states, counts, probs = opt.get_samples()
+    assert opt.n_samples < 10 ** 7 and len(states) <= 60
+
+
+def test_shard_bounds_tile():
+    from naqs_amd.optimizer import shard_bounds
+    for n in (0, 1, 7, 10000, 50001):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+
+
+def _worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "naqs-for-quantum-chemistry_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle_backend
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle_backend.install(__import__("naqs_amd.optimizer").optimizer)
+    z, hil, wf, opt = make_opt("LiH", os.path.join(tmp, f"r{rank}"), None, seed=11, n_samples=5000)
+    res = []
+    for _ in range(3):
+        states, counts, probs = opt.get_samples()
+        keys = hil.state2idx(states).squeeze(-1)
+        res.append(opt._SGD_step(states, keys, None, sample_weights=counts.double() / counts.sum().double()))
+    params = torch.cat([p.detach().reshape(-1) for p in wf.model.parameters()])
+    if rank == 0:
+        torch.save({"res": res, "params": params}, out)
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    assert all(torch.equal(g, gathered[0]) for g in gathered), "ranks diverged"
+    dist.destroy_process_group()
+
+
+def test_two_process_step_equals_single_process(tmp_path):
+    """world_size 2 over gloo: replicated sampler, row-sharded E_loc + loss, all-reduce of the energy
+    accumulators and of the gradient -> same energies / parameters as one process (up to f32 sum order)."""
+    import torch.multiprocessing as mp
+    import socket
+    outs = []
+    for world in (1, 2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"w{world}.pt")
+        mp.spawn(_worker, args=(world, port, str(tmp_path / f"w{world}"), out), nprocs=world, join=True)
+        outs.append(torch.load(out, weights_only=False))
+    for (e1, v1), (e2, v2) in zip(outs[0]["res"], outs[1]["res"]):
+        assert abs(e1 - e2) < 1e-6 * max(1, abs(e1)) and abs(v1 - v2) < 1e-5 * max(1, abs(v1))
+    assert torch.max(torch.abs(outs[0]["params"] - outs[1]["params"])).item() < 2e-5
