@@ -26,7 +26,19 @@ class OracleHamiltonian:
         return torch.stack([(w * eloc[:, 0]).sum(), (w * eloc[:, 1]).sum(), (w * eloc[:, 0] ** 2).sum(), w.sum()])
 
     def get_H(self, idxs):
-        raise NotImplementedError
+        from scipy.sparse import csr_matrix
+        k = (idxs.cpu().numpy() if torch.is_tensor(idxs) else np.asarray(idxs)).astype(np.int64).view(np.uint64).reshape(-1)
+        hij, _ = oracle.get_hij(k, self.packed.xy, self.packed.yz, self.packed.coeff)
+        xy_g = np.unique(self.packed.xy)
+        hij = hij.reshape(len(k), len(xy_g))
+        order = np.argsort(k, kind="stable")
+        ks = k[order]
+        j = k[:, None] ^ xy_g[None, :]
+        pos = np.searchsorted(ks, j)
+        pos[pos == len(ks)] = 0
+        hit = ks[pos] == j
+        rows = np.broadcast_to(np.arange(len(k))[:, None], j.shape)[hit]
+        return csr_matrix((hij[hit], (rows, order[pos[hit]])), shape=(len(k), len(k)))
 
 
 def install(monkeypatch_or_module):

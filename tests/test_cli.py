@@ -1,0 +1,98 @@
+"""The experiment harness and the input formats either side of the hot path (CPU; kernels replaced
+by the oracle-backed test stand-in)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PKG
+
+LIH_DIR = os.path.join(GOLDEN, "molecules", "LiH")
+
+
+def test_load_molecule_reads_hdf5_and_pkl_without_openfermion_or_h5py():
+    from naqs_amd.system import load_molecule
+    mol, qh = load_molecule(LIH_DIR, verbose=False)
+    assert (mol.n_qubits, mol.n_electrons, mol.multiplicity, mol.n_orbitals) == (12, 4, 1, 6)
+    assert (mol.get_n_alpha_electrons(), mol.get_n_beta_electrons()) == (2, 2)
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    assert abs(mol.fci_energy - kat["fci"]["LiH"]) < 1e-9        # HDF5 value == eigenvalue through the reference path
+    assert mol.hf_energy > mol.ccsd_energy > mol.fci_energy - 1e-4
+    assert len(qh.terms) == 631 and mol.basis == "sto-3g"
+
+
+def test_hdf5_reader_rejects_garbage(tmp_path):
+    from naqs_amd.hdf5_lite import read_hdf5
+    p = tmp_path / "x.hdf5"
+    p.write_bytes(b"not an hdf5 file at all")
+    with pytest.raises(ValueError):
+        read_hdf5(str(p))
+
+
+def test_set_global_seed_draw_order():
+    import random
+    import torch
+    from naqs_amd.system import set_global_seed
+    assert set_global_seed(111) == 111
+    a = (random.random(), np.random.rand(), torch.rand(1).item())
+    set_global_seed(111)
+    assert a == (random.random(), np.random.rand(), torch.rand(1).item())
+    random.seed(111)
+    s1, s2 = random.randint(0, 2 ** 32), random.randint(0, 2 ** 32)   # numpy is seeded twice; the second wins (Q12)
+    set_global_seed(111)
+    np_first = np.random.rand()
+    np.random.seed(s2 % 2 ** 32)
+    assert np_first == np.random.rand()
+
+
+def test_parser_accepts_the_reference_command_lines():
+    sys.path.insert(0, PKG)
+    from experiments._base import get_parser
+    p = get_parser(n_hid=128, n_samps=1e7)
+    # experiments/bash/naqs/batch_train.sh:14
+    a = p.parse_args("-o data/naqs/N2_s111 -m molecules/N2 -single_phase -n1 -n_layer 1 -n_hid 64 -n_layer_phase 2 "
+                     "-n_hid_phase 512 -s 111 -n_train 10000 -output_freq 25 -save_freq -1".split())
+    assert (a.molecule, a.number, a.n_hid, a.n_hid_phase, a.n_layer_phase, a.single_phase, a.seed) == \
+           ("molecules/N2", 1, 64, 512, 2, True, 111)
+    assert a.n_samps == 10 ** 7 and a.lr == -1 and not a.no_amp_sym and not a.phase_sym
+    a = p.parse_args("-m molecules/N2_1.5 -full_mask_psi -c -r -v".split())
+    assert a.full_mask_psi and a.cont and a.resetOpt and a.verbose
+    with pytest.raises(TypeError):
+        get_parser(not_an_option=1)
+
+
+def test_cli_end_to_end_on_lih(tmp_path, monkeypatch, capsys):
+    sys.path.insert(0, PKG)
+    import oracle_backend
+    from experiments import _base
+    oracle_backend.install(monkeypatch)
+    out = str(tmp_path / "run")
+    res = _base.run(n_hid=128, argv=["-m", LIH_DIR, "-o", out, "-single_phase", "-n_hid", "16", "-n_hid_phase", "32",
+                                     "-n_layer_phase", "2", "-n_samps", "100000", "-n_unq_samps_min", "10",
+                                     "-n_unq_samps_max", "100000", "-n_train", "60", "-output_freq", "20", "-s", "7"])
+    txt = capsys.readouterr().out
+    assert "lr --> 5e-4" in txt and "Epoch 20" in txt                   # default schedule: two halves (_base.py:303-320)
+    assert os.path.exists(os.path.join(out, "summary.txt")) and os.path.exists(os.path.join(out, "log.pkl"))
+    assert os.path.exists(os.path.join(out, "energy_optimizer.pth")) and os.path.exists(os.path.join(out, "opt_0steps.pth"))
+    r = res[0]
+    assert abs(r["fci"] + 7.784460280267) < 1e-9
+    assert r["eig"] >= r["fci"] - 1e-9                                   # variational: subspace diag is above FCI
+    assert r["final"] < -3.5                                             # 60 small steps from random init (starts near -2 Ha)
+    # continuing picks the checkpoint up
+    _base.run(n_hid=128, argv=["-m", LIH_DIR, "-o", out, "-c", "-single_phase", "-n_hid", "16", "-n_hid_phase", "32",
+                               "-n_layer_phase", "2", "-n_samps", "100000", "-n_unq_samps_min", "10", "-n_train", "4",
+                               "-lr", "0.001", "-s", "7"])
+    assert "Loading checkpoint" in capsys.readouterr().out
+
+
+def test_cli_rejects_out_of_scope_options(tmp_path, monkeypatch):
+    sys.path.insert(0, PKG)
+    import oracle_backend
+    from experiments import _base
+    oracle_backend.install(monkeypatch)
+    with pytest.raises(NotImplementedError):
+        _base.run(argv=["-m", LIH_DIR, "-o", str(tmp_path), "-n_lut", "2"])
+    with pytest.raises(Exception):
+        _base.run(argv=["-m", LIH_DIR, "-o", str(tmp_path), "-no_mask_psi", "-full_mask_psi"])
