@@ -150,10 +150,9 @@ def main():
     def step():
         fused.log_psi(keys, out=log_psi)               # teacher-forced evaluation, float32 [M, 2]
         ham.local_energy(keys, log_psi, kind="log_psi", out=eloc)
-        s = ham.reduce(weights, eloc)
+        ham.reduce(weights, eloc, out=acc)
         if world > 1:
-            dist.all_reduce(s)
-        acc.copy_(s)
+            dist.all_reduce(acc)
 
     def fence():
         if world > 1:

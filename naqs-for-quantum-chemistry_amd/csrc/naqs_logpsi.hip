@@ -4,7 +4,7 @@
 //
 // Two kernels per call (the PyTorch-eager formulation of the same thing is ~200 launches):
 //
-//   amp_kernel    one workgroup = 64 samples x one orbital pair n; its 4 waves split the hidden units.
+//   amp_kernel    one workgroup = 4 tiles of 64 samples x one orbital pair n; 4 waves per tile split the hidden units.
 //                 The 2n prefix occupations are built from key bits, spin-ordered (nade.py:519-530)
 //                 and kept in registers; the pair's MLP weights are staged once per workgroup in LDS and
 //                 read back as broadcast 16-byte reads (scalar loads were measured 5x slower here: ten
@@ -15,7 +15,8 @@
 //                 every layer on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, the
 //                 reference's precision).  Activations stay in LDS between layers (one buffer: the
 //                 MFMA accumulators hold a layer's output until every wave has finished reading its
-//                 input), weights stream from L2 as 16-byte loads in the MFMA operand layout, bias +
+//                 input), weights are pre-tiled in the MFMA operand layout and stream from L2 as contiguous
+//                 1 KiB wave loads, bias +
 //                 ReLU are fused into the write-back, and the epilogue adds the N/2 log-amplitudes in
 //                 fixed order and stores (log|psi|, phase).
 //
@@ -52,7 +53,7 @@ struct NetDims {
     uint8_t qa[MAXP], qb[MAXP];        // qubit (bit) index of the alpha / beta orbital of model pair n
     int32_t amp_off[MAXP];             // offset (floats) of pair n's packed parameters: Ha rows of
                                        //   [W1[j][0..nin) | b1[j] | W2[0..5)[j] | pad] (16-byte multiples), then b2 [8]
-    // phase MLP, packed & zero-padded: layer l: W [Nout_pad][K_pad], bias [Nout_pad]
+    // phase MLP, zero-padded and tiled: layer l: W [N_pad/16][K_pad/16][64 lanes][4], bias [N_pad]
     int32_t n_lin;
     int32_t K_pad[MAXL], N_pad[MAXL], w_off[MAXL], b_off[MAXL];
     int32_t ld;                        // LDS row stride (floats)
@@ -61,7 +62,14 @@ struct NetDims {
 // ------------------------------------------------------------------------------------------------
 // amplitude conditionals
 // ------------------------------------------------------------------------------------------------
-constexpr int AMP_WAVES = 4;      // the hidden units of one block are split over the 4 waves of a workgroup
+#ifndef NAQS_AMP_TILES
+#define NAQS_AMP_TILES 4
+#endif
+#ifndef NAQS_AMP_SPLIT
+#define NAQS_AMP_SPLIT 4
+#endif
+constexpr int AMP_TILES = NAQS_AMP_TILES;   // 64-sample tiles per workgroup sharing one staged weight set
+constexpr int AMP_SPLIT = NAQS_AMP_SPLIT;   // waves splitting the hidden units of one tile
 
 // partial output sums of pair NB over hidden units [j0, j1): o[c] += W2[c][j] * relu(W1[j].x + b1[j])
 template <int NB>
@@ -81,7 +89,7 @@ __device__ __forceinline__ void amp_partial(const NetDims &d, const float *__res
     const int nout = d.n_out_amp;
     constexpr int S = (NIN + 1 + 5 + 3) & ~3;          // packed row: W1[j][:], b1[j], W2[:][j], padded to 16 bytes
     const float *rows = w;                             // this pair's rows, staged in LDS by the workgroup
-#pragma unroll 2
+#pragma unroll 4
     for (int j = j0; j < j1; ++j) {
         const float *row = rows + j * S;               // same address in every lane -> LDS broadcast reads
         // two interleaved accumulation chains keep the FMA pipe busier than one 2n-long dependent chain
@@ -133,22 +141,27 @@ __device__ __forceinline__ float amp_finish(const NetDims &d, int NB, const floa
     return sel_ok ? 0.5f * ((sel - m) - logf(s)) : -INFINITY;
 }
 
-// workgroup = 64 samples x one orbital pair n (blockIdx.y); its 4 waves split the hidden units
-__global__ __launch_bounds__(AMP_WAVES * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w, int64_t M,
-                                                               const uint64_t *__restrict__ keys,
-                                                               float *__restrict__ scratch) {
-    __shared__ float s_part[AMP_WAVES][5][WAVE];
+// workgroup = AMP_TILES x AMP_SPLIT waves for one orbital pair n (blockIdx.y): the pair's packed weights are
+// staged once, wave (t, q) runs hidden-unit slice q for the 64 samples of tile t, the AMP_SPLIT partial
+// outputs of a tile meet in LDS in fixed order.  (The kernel is latency-bound: splitting the hidden units
+// over more waves was measured 2x faster than giving each wave all of them.)
+__global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w,
+                                                                           int64_t M, const uint64_t *__restrict__ keys,
+                                                                           float *__restrict__ scratch) {
+    __shared__ float s_part[AMP_TILES][AMP_SPLIT][5][WAVE];
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // this pair's packed rows + b2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = wave / AMP_SPLIT, q = wave % AMP_SPLIT;
+    const int n = blockIdx.y;            // workgroup-uniform
+    const int nin = n == 0 ? 1 : 2 * n;
+    const int S = (nin + 1 + 5 + 3) & ~3;
     {
-        const int nin_ = blockIdx.y == 0 ? 1 : 2 * (int)blockIdx.y;
-        const int total = d.Ha * ((nin_ + 1 + 5 + 3) & ~3) + 8;
-        const float *src = w + d.amp_off[blockIdx.y];
-        for (int e = threadIdx.x; e < total; e += AMP_WAVES * WAVE) s_w[e] = src[e];
-        __syncthreads();
+        const int total = d.Ha * S + 8;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(w + d.amp_off[n]);      // offsets are multiples of 4 floats
+        f32x4 *dst = reinterpret_cast<f32x4 *>(s_w);
+        for (int e = threadIdx.x; e < total / 4; e += AMP_TILES * AMP_SPLIT * WAVE) dst[e] = src[e];
     }
-    const int64_t i = blockIdx.x * (int64_t)WAVE + lane;
-    const int n = blockIdx.y;            // workgroup-uniform -> the weights come through scalar loads
+    const int64_t i = ((int64_t)blockIdx.x * AMP_TILES + tile) * WAVE + lane;
     const uint64_t key = i < M ? keys[i] : 0ull;
     // prefix occupations of pairs 0..n-1 and the realised outcome of pair n
     uint32_t abits = 0, bbits = 0;
@@ -160,9 +173,10 @@ __global__ __launch_bounds__(AMP_WAVES * WAVE) void amp_kernel(const NetDims d, 
     // spin ordering: the string with the smaller index goes first (nade.py:399-405, :519-530)
     const bool swap = d.sym && abits > bbits;
     const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
-    const int per = (d.Ha + AMP_WAVES - 1) / AMP_WAVES;
-    const int j0 = min(d.Ha, wave * per), j1 = min(d.Ha, j0 + per);
+    const int per = (d.Ha + AMP_SPLIT - 1) / AMP_SPLIT;
+    const int j0 = min(d.Ha, q * per), j1 = min(d.Ha, j0 + per);
     float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                     // weights staged
     switch (n) {
 #define CASE(NB) case NB: amp_partial<NB>(d, s_w, first, second, j0, j1, o); break;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
@@ -171,17 +185,16 @@ __global__ __launch_bounds__(AMP_WAVES * WAVE) void amp_kernel(const NetDims d, 
         default: break;
     }
 #pragma unroll
-    for (int c = 0; c < 5; ++c) s_part[wave][c][lane] = o[c];
+    for (int c = 0; c < 5; ++c) s_part[tile][q][c][lane] = o[c];
     __syncthreads();
-    if (wave == 0 && i < M) {
-        const int nin = n == 0 ? 1 : 2 * n;
-        const float *b2 = s_w + d.Ha * ((nin + 1 + 5 + 3) & ~3);
+    if (q == 0 && i < M) {
+        const float *b2 = s_w + d.Ha * S;
         float t[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             float v = c < d.n_out_amp ? b2[c] : 0.0f;
 #pragma unroll
-            for (int q = 0; q < AMP_WAVES; ++q) v += s_part[q][c][lane];      // fixed order
+            for (int u = 0; u < AMP_SPLIT; ++u) v += s_part[tile][u][c][lane];      // fixed order
             t[c] = v;
         }
         scratch[(int64_t)n * M + i] = amp_finish(d, n, t, abits, bbits, occ);
@@ -191,9 +204,15 @@ __global__ __launch_bounds__(AMP_WAVES * WAVE) void amp_kernel(const NetDims d, 
 // ------------------------------------------------------------------------------------------------
 // phase MLP on the f32 matrix cores
 // ------------------------------------------------------------------------------------------------
-constexpr int PH_THREADS = 512;                  // 8 waves = 2 per SIMD: one computes while the other waits on loads
+#ifndef NAQS_PH_THREADS
+#define NAQS_PH_THREADS 512
+#endif
+#ifndef NAQS_PH_CBT
+#define NAQS_PH_CBT 4
+#endif
+constexpr int PH_THREADS = NAQS_PH_THREADS;      // 8 waves = 2 per SIMD: one computes while the other waits on loads
 constexpr int PH_WAVES = PH_THREADS / WAVE;
-constexpr int CBT = 4;                           // 16-column blocks per wave per pass
+constexpr int CBT = NAQS_PH_CBT;                 // 16-column blocks per wave per pass
 
 // K loop of one linear layer for one wave: RB row blocks x NC column blocks of 16x16 outputs.
 // Operand layout of v_mfma_f32_16x16x4_f32: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15].
@@ -201,22 +220,48 @@ constexpr int CBT = 4;                           // 16-column blocks per wave pe
 // operands, so MFMA j contracts {k0+j, k0+4+j, k0+8+j, k0+12+j} — over a 16-wide chunk every k is
 // visited exactly once.
 template <int RB, int NC>
+__device__ __forceinline__ void mlp_load(const float *__restrict__ a_ptr, int ld, const float *__restrict__ w_ptr,
+                                         int K_pad, int k0, f32x4 (&a)[RB], f32x4 (&b)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) b[c] = *reinterpret_cast<const f32x4 *>(w_ptr + ((size_t)c * K_pad + k0) * 16);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const f32x4 *>(a_ptr + rb * 16 * ld + k0);
+}
+
+template <int RB, int NC>
+__device__ __forceinline__ void mlp_mfma(const f32x4 (&a)[RB], const f32x4 (&b)[NC], f32x4 (&acc)[RB][CBT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][j], b[c][j], acc[rb][c], 0, 0, 0);
+}
+
+template <int RB, int NC>
 __device__ __forceinline__ void mlp_accumulate(const float *__restrict__ a_ptr, int ld,
                                                const float *__restrict__ w_ptr, int K_pad, f32x4 (&acc)[RB][CBT]) {
-    for (int k0 = 0; k0 < K_pad; k0 += 16) {
-        f32x4 a[RB], b[NC];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const f32x4 *>(a_ptr + rb * 16 * ld + k0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) b[c] = *reinterpret_cast<const f32x4 *>(w_ptr + (size_t)c * 16 * K_pad + k0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][j], b[c][j], acc[rb][c], 0, 0, 0);
+    // register double buffering: the loads of chunk k+1 (L2 -> VGPR weights, LDS activations) are in
+    // flight while the 4*RB*NC MFMAs of chunk k issue; K_pad is a multiple of 16, chunks are 16 wide
+    f32x4 a0[RB], b0[NC], a1[RB], b1[NC];
+    mlp_load<RB, NC>(a_ptr, ld, w_ptr, K_pad, 0, a0, b0);
+    int k0 = 0;
+    // sched_barrier(0): hipcc otherwise sinks the prefetch loads to the end of the MFMA block (seen in
+    // the ISA), which puts their full L2 latency back on the critical path
+    for (; k0 + 32 <= K_pad; k0 += 32) {
+        mlp_load<RB, NC>(a_ptr, ld, w_ptr, K_pad, k0 + 16, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mlp_mfma<RB, NC>(a0, b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional (clamped to the last chunk): a branch here makes the compiler's s_waitcnt merge
+        // conservative (vmcnt(0) on the just-issued loads)
+        mlp_load<RB, NC>(a_ptr, ld, w_ptr, K_pad, min(k0 + 32, K_pad - 16), a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mlp_mfma<RB, NC>(a1, b1, acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (k0 < K_pad) mlp_mfma<RB, NC>(a0, b0, acc);       // odd number of chunks: the last one is already loaded
 }
 
 // one linear layer for RB*16 rows held in LDS: buf[rows][ld] (K_pad valid floats per row) ->
@@ -234,13 +279,54 @@ __device__ __forceinline__ void mlp_layer(float *__restrict__ buf, int ld, int K
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int c = 0; c < CBT; ++c) acc[rb][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ncb == 1) {
+        // a layer with <= 16 outputs (the last one: 512 -> 4) has a single column block: instead of leaving it
+        // to one wave (a serial tail of K/4 * RB MFMAs while 7 waves idle), the waves split K and the partial
+        // tiles are summed through LDS in fixed order
+        constexpr int BM = RB * 16;
+        const int chunks = K_pad >> 4, cpw = (chunks + PH_WAVES - 1) / PH_WAVES;
+        const int kbeg = min(chunks, wave * cpw) << 4, klen = (min(chunks, (wave + 1) * cpw) << 4) - kbeg;
+        if (klen > 0)
+            mlp_accumulate<RB, 1>(buf + m * ld + 4 * kq + kbeg, ld, W + (size_t)kbeg * 16 + lane * 4, klen, acc);
+        __syncthreads();                                  // everyone is done reading the input
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[(wave * BM + rb * 16 + kq * 4 + r) * 16 + m] = acc[rb][0][r];
+        __syncthreads();
+        constexpr int PER = (BM * 16 + PH_THREADS - 1) / PH_THREADS;      // outputs per thread (BM*16 may exceed the block)
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = u * PH_THREADS + wave * WAVE + lane;
+            v[u] = 0.0f;
+            if (t < BM * 16) {
+                v[u] = bias[t & 15];
+#pragma unroll
+                for (int q = 0; q < PH_WAVES; ++q) v[u] += buf[q * BM * 16 + t];
+                if (relu) v[u] = fmaxf(v[u], 0.0f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = u * PH_THREADS + wave * WAVE + lane;
+            if (t < BM * 16) buf[(t >> 4) * ld + (t & 15)] = v[u];
+        }
+        __syncthreads();
+        return;
+    }
     const int cb0 = wave * CBT;
     const int my_cb = min(CBT, max(0, ncb - cb0));       // wave-uniform
     const float *a_ptr = buf + m * ld + 4 * kq;
-    const float *w_ptr = W + (size_t)(cb0 * 16 + m) * K_pad + 4 * kq;
-    if (my_cb == 4) mlp_accumulate<RB, 4>(a_ptr, ld, w_ptr, K_pad, acc);
-    else if (my_cb == 3) mlp_accumulate<RB, 3>(a_ptr, ld, w_ptr, K_pad, acc);
-    else if (my_cb == 2) mlp_accumulate<RB, 2>(a_ptr, ld, w_ptr, K_pad, acc);
+    // weights are pre-tiled in the MFMA operand order: [column block][16-wide k chunk][lane][4 floats],
+    // so one wave-wide 16-byte load is one contiguous 1 KiB block (a row-major [N][K] weight would make the
+    // 16 rows of a load 2 KiB apart: two L2 channels take all the traffic of every CU at once)
+    const float *w_ptr = W + (size_t)cb0 * K_pad * 16 + lane * 4;
+    if (my_cb == CBT) mlp_accumulate<RB, CBT>(a_ptr, ld, w_ptr, K_pad, acc);
+    else if (my_cb >= 4) mlp_accumulate<RB, (CBT > 4 ? 4 : 1)>(a_ptr, ld, w_ptr, K_pad, acc);   // partial passes: rare
+    else if (my_cb == 3) mlp_accumulate<RB, (CBT > 3 ? 3 : 1)>(a_ptr, ld, w_ptr, K_pad, acc);
+    else if (my_cb == 2) mlp_accumulate<RB, (CBT > 2 ? 2 : 1)>(a_ptr, ld, w_ptr, K_pad, acc);
     else if (my_cb == 1) mlp_accumulate<RB, 1>(a_ptr, ld, w_ptr, K_pad, acc);
     __syncthreads();                                      // everyone is done reading the input
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -273,6 +359,11 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int P = d.P, ld = d.ld;
 
+    // log-amplitude sum of this thread's row: issued now, consumed in the epilogue (latency hidden under the MLP)
+    float la = 0.0f;
+    if (tid < BM && row0 + tid < M)
+        for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
+
     // layer-0 input: [alpha occupations of pairs 0..P-2 | beta ...] as +-1 (no spin ordering for the
     // phase block, nade.py:531-537), zero-padded to K_pad[0]; rows past M are zero
     const int K0 = d.K_pad[0];
@@ -298,8 +389,6 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
         if (i < M) {
             const uint64_t key = keys[i];
             const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
-            float la = 0.0f;
-            for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + i];   // fixed order: block 0..P-1
             out[i] = make_float2(la, buf[tid * ld + occ]);
         }
     }
@@ -330,7 +419,10 @@ __global__ __launch_bounds__(256) void pack_phase_kernel(const float *__restrict
     const int total = N_pad * K_pad;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total + N_pad; e += gridDim.x * 256) {
         if (e < total) {
-            const int n = e / K_pad, k = e - n * K_pad;
+            // e = ((cb * KC + kc) * 64 + kq * 16 + nn) * 4 + j   <-   W[cb*16 + nn][kc*16 + kq*4 + j]
+            const int j = e & 3, nn = (e >> 2) & 15, kq = (e >> 6) & 3, blk = e >> 8;
+            const int KC = K_pad >> 4, cb = blk / KC, kc = blk - cb * KC;
+            const int n = cb * 16 + nn, k = kc * 16 + kq * 4 + j;
             Wd[e] = (n < N && k < K) ? src[n * K + k] : 0.0f;
         } else {
             const int n = e - total;
@@ -510,7 +602,7 @@ NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + WAVE - 1) / WAVE), (unsigned)d.P), dim3(AMP_WAVES * WAVE), amp_lds, s, d, net->d_w, M,
+    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, net->d_w, M,
                        keys_dev, net->d_scratch);
     HIP_TRY(hipGetLastError());
 

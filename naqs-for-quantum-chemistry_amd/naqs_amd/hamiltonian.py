@@ -98,10 +98,11 @@ class DevicePauliHamiltonian:
         _lib.check(st, "naqs_eloc")
         return out
 
-    def reduce(self, weights, eloc):
+    def reduce(self, weights, eloc, out=None):
         """-> float64 device tensor [4] = (sum w Re E, sum w Im E, sum w Re(E)^2, sum w)."""
         w = weights.to(device=self.device, dtype=torch.float64).contiguous()
-        out = torch.empty(4, dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.empty(4, dtype=torch.float64, device=self.device)
         st = self._lib.naqs_eloc_reduce(self._h, eloc.shape[0], w.data_ptr(), eloc.contiguous().data_ptr(),
                                         out.data_ptr(), _stream_ptr(self.device))
         _lib.check(st, "naqs_eloc_reduce")
