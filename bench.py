@@ -27,6 +27,7 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+PROF_STRIDE = 10
 MFMA_F32_PEAK_TF = 157.3   # f32-in/f32-acc MFMA dense peak (MI355X_MICROARCH.md: = the f32 vector rate)
 
 
@@ -149,8 +150,7 @@ def main():
 
     def step():
         fused.log_psi(keys, out=log_psi)               # teacher-forced evaluation, float32 [M, 2]
-        ham.local_energy(keys, log_psi, kind="log_psi", out=eloc)
-        ham.reduce(weights, eloc, out=acc)
+        ham.local_energy(keys, log_psi, kind="log_psi", out=eloc, weights=weights, sums_out=acc)
         if world > 1:
             dist.all_reduce(acc)
 
@@ -162,8 +162,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ham.prof_enable(args.steps)
-    fused.prof_enable(args.steps)
+    # kernel durations: hipEvent pairs on the launch stream around every PROF_STRIDE-th launch of the timed
+    # region (an event pair costs ~4 us of queue time; recording all of them slows the step by ~15 %)
+    stride = max(1, min(PROF_STRIDE, args.steps // 8))
+    ham.prof_enable(args.steps // stride + 1, stride)
+    fused.prof_enable(args.steps // stride + 1, stride)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -195,6 +198,15 @@ def main():
         mlp_roof = {"bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": mlp_tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "phase_kernel (f32 MFMA 16x16x4)",
                     "kernel_us": t_mlp * 1e6, "algorithmic_flops_per_launch": flops}
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (tools/collect_pmc.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 corrections applied there)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            eloc_roof["traffic"] = pmc["eloc_kernel"]["hbm_bytes_per_launch"]
+            mlp_roof["traffic"] = pmc["phase_kernel"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         dominant, other = (mlp_roof, eloc_roof) if t_mlp >= t_kernel else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]

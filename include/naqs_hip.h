@@ -110,6 +110,14 @@ int naqs_eloc(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *ps
               int64_t row_begin, int64_t n_rows, double *eloc_dev, void *stream);
 
 /*
+ * naqs_eloc followed by naqs_eloc_reduce over the produced rows, enqueued by one call:
+ * w_dev[n_rows] are the weights of the produced rows, out4_dev as below.
+ */
+int naqs_eloc_reduced(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                      int64_t row_begin, int64_t n_rows, const double *w_dev, double *eloc_dev,
+                      double *out4_dev, void *stream);
+
+/*
  * Weighted sums over n local energies, deterministic order:
  *   out4_dev = { sum w Re(E), sum w Im(E), sum w Re(E)^2, sum w }
  * from which <E> and Var follow as in _SGD_step (src/optimizer/energy.py:367-377).
@@ -140,6 +148,9 @@ int naqs_csr_mv(int64_t rows, const double *data_dev, const int32_t *indices_dev
 int naqs_prof_enable(naqs_ham_t *h, int max_records);
 /* Synchronises the recorded events: total milliseconds and number of launches since enable. */
 int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches);
+/* Record only every stride-th launch (default 1): an event pair costs a few microseconds of queue time,
+ * so a sparse sample keeps the timed region representative. */
+int naqs_prof_stride(naqs_ham_t *h, int stride);
 
 
 /* ================================================================================================
@@ -178,6 +189,7 @@ int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float 
 /* HIP-event timing of the phase-MLP kernel, like naqs_prof_enable / naqs_prof_read. */
 int naqs_net_prof_enable(naqs_net_t *net, int max_records);
 int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches);
+int naqs_net_prof_stride(naqs_net_t *net, int stride);
 
 #ifdef __cplusplus
 }

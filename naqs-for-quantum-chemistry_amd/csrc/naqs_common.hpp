@@ -46,17 +46,18 @@ inline int env_int(const char *name, int dflt) {
 struct EventRing {
     hipEvent_t *ev = nullptr;
     int cap = 0, used = 0;
+    int stride = 1, tick = 0;            // record every stride-th launch (an event pair costs ~4 us of queue time)
     int enable(int max_records) {
         for (int i = 0; i < cap; ++i) (void)hipEventDestroy(ev[i]);
         std::free(ev);
-        ev = nullptr; cap = used = 0;
+        ev = nullptr; cap = used = 0; tick = 0;
         if (max_records <= 0) return NAQS_OK;
         ev = static_cast<hipEvent_t *>(std::calloc((size_t)2 * max_records, sizeof(hipEvent_t)));
         if (!ev) return NAQS_ERR_NOMEM;
         for (int i = 0; i < 2 * max_records; ++i) { HIP_TRY(hipEventCreate(&ev[i])); cap = i + 1; }
         return NAQS_OK;
     }
-    bool armed() const { return used + 2 <= cap; }
+    bool armed() { return used + 2 <= cap && (tick++ % stride) == 0; }
     int begin(hipStream_t s) { HIP_TRY(hipEventRecord(ev[used], s)); return NAQS_OK; }
     int end(hipStream_t s) { HIP_TRY(hipEventRecord(ev[used + 1], s)); used += 2; return NAQS_OK; }
     int read(double *total_ms, int64_t *launches) {

@@ -46,13 +46,22 @@ using naqs::DeviceGuard;
 using naqs::env_int;
 
 constexpr int BLOCK = 256;                 // helper kernels: 4 waves, one per SIMD of a CU
-constexpr int QUEUE_CAP = 192;             // per-wave hit queue: < 64 carried + 2 x 64 pushed per iteration
-constexpr int LDS_BUDGET = 64 * 1024;      // per-workgroup staging budget (160 KiB/CU -> >= 2 WGs/CU)
+#ifndef NAQS_LIGHT_BATCH
+#define NAQS_LIGHT_BATCH 2
+#endif
+constexpr int LIGHT_BATCH = NAQS_LIGHT_BATCH;             // 64-group chunks probed together (all loads in flight before any is used)
+constexpr int QUEUE_CAP = 64 * (LIGHT_BATCH + 1);   // per-wave hit queue: < 64 carried + LIGHT_BATCH x 64 pushed per batch
+constexpr int LDS_BUDGET = 78 * 1024;      // per-workgroup dynamic LDS budget (160 KiB/CU -> 2 WGs/CU)
 constexpr int HEAVY_TERMS = 8;             // groups with more terms than this are "heavy"
 
+// Open-addressing hash table of the sample keys, rebuilt every call WITHOUT clearing it: each slot
+// carries the 8-bit epoch of the call that wrote it next to the 24-bit sample index, and a slot whose
+// epoch is not the current one counts as empty.  (The table is zeroed when it is allocated and when
+// the epoch wraps, every 255 calls.)  32-bit keys: one 8-byte word  key << 32 | epoch << 24 | index.
+constexpr uint32_t IDX_MASK = 0x00FFFFFFu;
 template <typename KT> struct Slot;
-template <> struct Slot<uint32_t> { unsigned long long kv; };              // key << 32 | index
-template <> struct Slot<uint64_t> { unsigned long long key; uint32_t val; uint32_t pad; };
+template <> struct Slot<uint32_t> { unsigned long long kv; };
+template <> struct Slot<uint64_t> { unsigned long long key; uint32_t val; uint32_t pad; };   // val = epoch << 24 | index
 
 __device__ __forceinline__ int popc(uint32_t x) { return __popc(x); }
 __device__ __forceinline__ int popc(uint64_t x) { return __popcll(x); }
@@ -62,60 +71,81 @@ __device__ __forceinline__ uint32_t hash_key(uint64_t k, int bits) {
     return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - bits));
 }
 
-// ------------------------------------------------------------------------------------------------
-// prep: narrow the keys, build the hash table, bring psi to f64 (re, im).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hash_insert(Slot<uint32_t> *tab, int bits, uint32_t key, uint32_t idx) {
+__device__ __forceinline__ void hash_insert(Slot<uint32_t> *tab, int bits, uint32_t tag, uint32_t key, uint32_t idx) {
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t h = hash_key(key, bits);
-    const unsigned long long packed = ((unsigned long long)key << 32) | idx;
+    const unsigned long long want = ((unsigned long long)key << 32) | tag | idx;
+    unsigned long long old = tab[h].kv;
     for (;;) {
-        unsigned long long old = atomicCAS(&tab[h].kv, ~0ull, packed);
-        if (old == ~0ull) return;
-        h = (h + 1) & mask;
+        if (((uint32_t)old & ~IDX_MASK) == tag) {          // taken in this epoch -> next slot
+            h = (h + 1) & mask;
+            old = tab[h].kv;
+            continue;
+        }
+        const unsigned long long prev = atomicCAS(&tab[h].kv, old, want);
+        if (prev == old) return;
+        old = prev;                                         // lost the race for this slot: look again
     }
 }
-__device__ __forceinline__ void hash_insert(Slot<uint64_t> *tab, int bits, uint64_t key, uint32_t idx) {
+__device__ __forceinline__ void hash_insert(Slot<uint64_t> *tab, int bits, uint32_t tag, uint64_t key, uint32_t idx) {
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t h = hash_key(key, bits);
+    uint32_t old = tab[h].val;
     for (;;) {
-        unsigned long long old = atomicCAS(&tab[h].key, ~0ull, (unsigned long long)key);
-        if (old == ~0ull) { tab[h].val = idx; return; }
-        h = (h + 1) & mask;
+        if ((old & ~IDX_MASK) == tag) {
+            h = (h + 1) & mask;
+            old = tab[h].val;
+            continue;
+        }
+        const uint32_t prev = atomicCAS(&tab[h].val, old, tag | idx);
+        if (prev == old) { tab[h].key = (unsigned long long)key; return; }   // claimed: readers run in a later kernel
+        old = prev;
     }
 }
 
-// returns the table index of `key`, or -1
-__device__ __forceinline__ int hash_find(const Slot<uint32_t> *__restrict__ tab, int bits, uint32_t key) {
+// first probe (the load that matters for latency) and its resolution, split so that callers can put
+// several probes in flight before looking at any of them
+__device__ __forceinline__ unsigned long long probe_load(const Slot<uint32_t> *__restrict__ tab, uint32_t h) { return tab[h].kv; }
+__device__ __forceinline__ int probe_resolve(const Slot<uint32_t> *__restrict__ tab, int bits, uint32_t tag, uint32_t key,
+                                             uint32_t h, unsigned long long kv) {
     const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = hash_key(key, bits);
     for (;;) {
-        const unsigned long long kv = tab[h].kv;
-        if (kv == ~0ull) return -1;
-        if ((uint32_t)(kv >> 32) == key) return (int)(uint32_t)kv;
+        if (((uint32_t)kv & ~IDX_MASK) != tag) return -1;
+        if ((uint32_t)(kv >> 32) == key) return (int)((uint32_t)kv & IDX_MASK);
         h = (h + 1) & mask;
+        kv = tab[h].kv;
     }
 }
-__device__ __forceinline__ int hash_find(const Slot<uint64_t> *__restrict__ tab, int bits, uint64_t key) {
+struct Slot64Val { unsigned long long key; uint32_t val; };
+__device__ __forceinline__ Slot64Val probe_load(const Slot<uint64_t> *__restrict__ tab, uint32_t h) {
+    const Slot<uint64_t> s = tab[h];
+    return Slot64Val{s.key, s.val};
+}
+__device__ __forceinline__ int probe_resolve(const Slot<uint64_t> *__restrict__ tab, int bits, uint32_t tag, uint64_t key,
+                                             uint32_t h, Slot64Val s) {
     const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = hash_key(key, bits);
     for (;;) {
-        const Slot<uint64_t> s = tab[h];
-        if (s.key == ~0ull) return -1;
-        if (s.key == key) return (int)s.val;
+        if ((s.val & ~IDX_MASK) != tag) return -1;
+        if (s.key == key) return (int)(s.val & IDX_MASK);
         h = (h + 1) & mask;
+        s = probe_load(tab, h);
     }
+}
+template <typename KT>
+__device__ __forceinline__ int hash_find(const Slot<KT> *__restrict__ tab, int bits, uint32_t tag, KT key) {
+    const uint32_t h = hash_key(key, bits);
+    return probe_resolve(tab, bits, tag, key, h, probe_load(tab, h));
 }
 
 template <typename KT>
 __global__ __launch_bounds__(BLOCK) void prep_kernel(int64_t M, const uint64_t *__restrict__ keys,
                                                      const void *__restrict__ psi_in, int psi_kind,
                                                      KT *__restrict__ keys_out, double2 *__restrict__ psi_out,
-                                                     Slot<KT> *__restrict__ tab, int bits) {
+                                                     Slot<KT> *__restrict__ tab, int bits, uint32_t tag) {
     for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < M; i += (int64_t)gridDim.x * BLOCK) {
         const KT k = (KT)keys[i];
         keys_out[i] = k;
-        hash_insert(tab, bits, k, (uint32_t)i);
+        hash_insert(tab, bits, tag, k, (uint32_t)i);
         double a, b;
         if (psi_kind == NAQS_PSI_F32 || psi_kind == NAQS_LOGPSI_F32) {
             const float2 v = reinterpret_cast<const float2 *>(psi_in)[i];
@@ -154,6 +184,7 @@ struct ElocParams {
     const double2 *psi;      // [M]
     const Slot<KT> *tab;
     int32_t bits;
+    uint32_t tag;            // epoch << 24 of this call's hash table entries
     // rows to produce
     int64_t row_begin, n_rows;
     int32_t rows_per_block;
@@ -281,17 +312,20 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
             int idx = -1;
             if (g < p.light_begin) {
                 const KT j = key ^ xy[g];
-                if (physical(j)) idx = hash_find(tab, p.bits, j);
+                if (physical(j)) idx = hash_find<KT>(tab, p.bits, p.tag, j);
             }
+            // every hit lane fetches its psi_j now (one round trip for all hits of the chunk); the wave then
+            // walks the hits and gets (psi_j) by lane broadcast instead of a dependent load per hit
+            double2 pj_mine = make_double2(0.0, 0.0);
+            if (idx >= 0) pj_mine = psi[idx];
             unsigned long long m = __ballot(idx >= 0);
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
-                const int ib = __shfl(idx, b, WAVE);
-                const double2 pj = psi[ib];
+                const double pjx = __shfl(pj_mine.x, b, WAVE), pjy = __shfl(pj_mine.y, b, WAVE);
                 const double h = sign_sum_strided<KT>(key, yz, cf, rp[g0 + b], rp[g0 + b + 1], lane);
-                sr += h * pj.x;
-                si += h * pj.y;
+                sr += h * pjx;
+                si += h * pjy;
             }
         }
 
@@ -317,16 +351,25 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
                 qn += __popcll(hits);
             }
         };
-        for (int g0 = p.light_begin; g0 < p.Kxy; g0 += 2 * WAVE) {
-            const int gA = g0 + lane, gB = gA + WAVE;
-            KT jA = 0, jB = 0;
-            bool pA = false, pB = false;
-            if (gA < p.Kxy) { jA = key ^ xy[gA]; pA = physical(jA); }
-            if (gB < p.Kxy) { jB = key ^ xy[gB]; pB = physical(jB); }
-            const int idxA = pA ? hash_find(tab, p.bits, jA) : -1;
-            const int idxB = pB ? hash_find(tab, p.bits, jB) : -1;
-            push(gA, idxA);
-            push(gB, idxB);
+        for (int g0 = p.light_begin; g0 < p.Kxy; g0 += LIGHT_BATCH * WAVE) {
+            // all LIGHT_BATCH probes of a lane are issued before the first one is looked at: one L2 round trip
+            // per 256 groups instead of one per 64
+            KT j[LIGHT_BATCH];
+            uint32_t hh[LIGHT_BATCH];
+            bool ph[LIGHT_BATCH];
+            decltype(probe_load(tab, 0u)) first[LIGHT_BATCH];
+#pragma unroll
+            for (int u = 0; u < LIGHT_BATCH; ++u) {
+                const int g = g0 + u * WAVE + lane;
+                j[u] = 0; hh[u] = 0; ph[u] = false;
+                if (g < p.Kxy) { j[u] = key ^ xy[g]; ph[u] = physical(j[u]); }
+                if (ph[u]) { hh[u] = hash_key(j[u], p.bits); first[u] = probe_load(tab, hh[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < LIGHT_BATCH; ++u) {
+                const int idx = ph[u] ? probe_resolve(tab, p.bits, p.tag, j[u], hh[u], first[u]) : -1;
+                push(g0 + u * WAVE + lane, idx);
+            }
             __builtin_amdgcn_wave_barrier();
             while (qn >= WAVE) {
                 qn -= WAVE;
@@ -344,6 +387,7 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
             p.eloc[r] = make_double2(q.x, -q.y);   // conj, energy.py:248
         }
     }
+
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,6 +480,7 @@ struct naqs_ham {
     double2 *d_psi = nullptr;
     void *d_tab = nullptr;
     int64_t tab_slots = 0;
+    uint32_t epoch = 0;                      // of the hash table entries (1..255; 0 = freshly zeroed)
     int cu_count = 256;
     naqs::EventRing prof;
 };
@@ -462,6 +507,8 @@ int ensure_scratch(naqs_ham *h, int64_t M) {
     HIP_TRY(hipMalloc(&h->d_keys, cap * kb));
     HIP_TRY(hipMalloc((void **)&h->d_psi, cap * sizeof(double2)));
     HIP_TRY(hipMalloc(&h->d_tab, h->tab_slots * slot));
+    HIP_TRY(hipMemset(h->d_tab, 0, h->tab_slots * slot));
+    h->epoch = 0;
     h->cap_M = cap;
     return NAQS_OK;
 }
@@ -486,14 +533,20 @@ int upload_tables(naqs_ham *h, const std::vector<uint64_t> &xy_g, const std::vec
 
 template <typename KT>
 int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
-                int64_t row_begin, int64_t n_rows, double *eloc_dev, hipStream_t s) {
+                int64_t row_begin, int64_t n_rows, double *eloc_dev, const double *w_dev, double *out4_dev,
+                hipStream_t s) {
     const int bits = table_bits(M);
     auto *tab = reinterpret_cast<Slot<KT> *>(h->d_tab);
-    HIP_TRY(hipMemsetAsync(tab, 0xFF, (size_t)(1ll << bits) * sizeof(Slot<KT>), s));
+    // no per-call clearing: entries are tagged with the call's epoch; zero the table when the 8-bit epoch wraps
+    if (++h->epoch > 255u) {
+        HIP_TRY(hipMemsetAsync(tab, 0, (size_t)h->tab_slots * sizeof(Slot<KT>), s));
+        h->epoch = 1;
+    }
+    const uint32_t tag = h->epoch << 24;
     {
         const int grid = (int)std::min<int64_t>((M + BLOCK - 1) / BLOCK, 4 * h->cu_count);
         hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
-                           reinterpret_cast<KT *>(h->d_keys), h->d_psi, tab, bits);
+                           reinterpret_cast<KT *>(h->d_keys), h->d_psi, tab, bits, tag);
         HIP_TRY(hipGetLastError());
     }
 
@@ -509,7 +562,7 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
     p.n_alpha = h->n_alpha; p.n_beta = h->n_beta;
     p.keys = reinterpret_cast<const KT *>(h->d_keys);
     p.psi = h->d_psi;
-    p.tab = tab; p.bits = bits;
+    p.tab = tab; p.bits = bits; p.tag = tag;
     p.row_begin = row_begin; p.n_rows = n_rows;
     p.eloc = reinterpret_cast<double2 *>(eloc_dev);
 
@@ -536,8 +589,13 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
 
     const bool prof = h->prof.armed();
     if (prof) { int st = h->prof.begin(s); if (st != NAQS_OK) return st; }
-#define NAQS_LAUNCH(ST, NTHREADS) \
-    hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS>), dim3(grid), dim3(NTHREADS), lds, s, p)
+#define NAQS_LAUNCH(ST, NTHREADS)                                                                                   \
+    do {                                                                                                            \
+        if (lds > 64 * 1024)  /* above the default dynamic-LDS limit */                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_kernel<KT, ST, NTHREADS>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);                       \
+        hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS>), dim3(grid), dim3(NTHREADS), lds, s, p);                 \
+    } while (0)
 #define NAQS_LAUNCH_NT(ST)                                   \
     do {                                                     \
         if (nt == 1024) NAQS_LAUNCH(ST, 1024);               \
@@ -551,6 +609,14 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
 #undef NAQS_LAUNCH
     HIP_TRY(hipGetLastError());
     if (prof) { int st = h->prof.end(s); if (st != NAQS_OK) return st; }
+    if (w_dev) {
+        // (A reduction fused into eloc_kernel behind a last-workgroup ticket was measured: the extra
+        // barrier/fence code at the kernel tail slowed the whole kernel by 30-40 % on gfx950/ROCm 7.2 even
+        // when it was not executed, so the sums stay a separate 1-workgroup launch.)
+        hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(RED_BLOCK), 0, s, n_rows, w_dev,
+                           reinterpret_cast<const double2 *>(eloc_dev), out4_dev);
+        HIP_TRY(hipGetLastError());
+    }
     return NAQS_OK;
 }
 
@@ -699,22 +765,39 @@ NAQS_API int naqs_ham_reserve(naqs_ham_t *h, int64_t M) {
     return ensure_scratch(h, M);
 }
 
-NAQS_API int naqs_eloc(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
-                       int64_t row_begin, int64_t n_rows, double *eloc_dev, void *stream) {
+static int eloc_common(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                       int64_t row_begin, int64_t n_rows, double *eloc_dev, const double *w_dev, double *out4_dev,
+                       void *stream) {
     if (!h || M < 0 || row_begin < 0 || n_rows < 0 || row_begin + n_rows > M) return NAQS_ERR_INVALID;
     if (psi_kind < NAQS_PSI_F32 || psi_kind > NAQS_LOGPSI_F64) return NAQS_ERR_INVALID;
-    if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
-    if (n_rows == 0) return NAQS_OK;
-    if (!keys_dev || !psi_dev || !eloc_dev) return NAQS_ERR_INVALID;
+    if (M > (int64_t)IDX_MASK) return NAQS_ERR_UNSUPPORTED;          // 24-bit sample index in a hash slot
+    if ((w_dev == nullptr) != (out4_dev == nullptr)) return NAQS_ERR_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DeviceGuard guard;
     int st = guard.init(h->device);
     if (st != NAQS_OK) return st;
+    if (n_rows == 0) {
+        if (out4_dev) HIP_TRY(hipMemsetAsync(out4_dev, 0, 4 * sizeof(double), s));
+        return NAQS_OK;
+    }
+    if (!keys_dev || !psi_dev || !eloc_dev) return NAQS_ERR_INVALID;
     st = ensure_scratch(h, M);
     if (st != NAQS_OK) return st;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return h->key_bits == 32
-               ? launch_eloc<uint32_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, s)
-               : launch_eloc<uint64_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, s);
+               ? launch_eloc<uint32_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s)
+               : launch_eloc<uint64_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s);
+}
+
+NAQS_API int naqs_eloc(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                       int64_t row_begin, int64_t n_rows, double *eloc_dev, void *stream) {
+    return eloc_common(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, nullptr, nullptr, stream);
+}
+
+NAQS_API int naqs_eloc_reduced(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                               int64_t row_begin, int64_t n_rows, const double *w_dev, double *eloc_dev,
+                               double *out4_dev, void *stream) {
+    if (!w_dev || !out4_dev) return NAQS_ERR_INVALID;
+    return eloc_common(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, w_dev, out4_dev, stream);
 }
 
 NAQS_API int naqs_eloc_reduce(naqs_ham_t *h, int64_t n, const double *w_dev, const double *eloc_dev,
@@ -790,4 +873,11 @@ NAQS_API int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches) 
     int st = guard.init(h->device);
     if (st != NAQS_OK) return st;
     return h->prof.read(total_ms, launches);
+}
+
+NAQS_API int naqs_prof_stride(naqs_ham_t *h, int stride) {
+    if (!h || stride < 1) return NAQS_ERR_INVALID;
+    h->prof.stride = stride;
+    h->prof.tick = 0;
+    return NAQS_OK;
 }

@@ -641,3 +641,10 @@ NAQS_API int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *laun
     if (st != NAQS_OK) return st;
     return net->prof.read(total_ms, launches);
 }
+
+NAQS_API int naqs_net_prof_stride(naqs_net_t *net, int stride) {
+    if (!net || stride < 1) return NAQS_ERR_INVALID;
+    net->prof.stride = stride;
+    net->prof.tick = 0;
+    return NAQS_OK;
+}

@@ -28,12 +28,15 @@ SIGNATURES = {
     "naqs_ham_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64 * 8)]),
     "naqs_ham_reserve": (ctypes.c_int, [c_vp, c_i64]),
     "naqs_eloc": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp]),
+    "naqs_eloc_reduced": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_eloc_reduce": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_popcount_parity": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "naqs_get_hij": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "naqs_csr_mv": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "naqs_prof_stride": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "naqs_net_prof_stride": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_net_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "naqs_net_destroy": (ctypes.c_int, [c_vp]),
     "naqs_net_param_count": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),

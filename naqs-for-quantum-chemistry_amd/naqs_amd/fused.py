@@ -70,8 +70,9 @@ class FusedLogPsi:
         _lib.check(st, "naqs_net_logpsi")
         return out
 
-    def prof_enable(self, n):
+    def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")
+        _lib.check(self._lib.naqs_net_prof_stride(self._h, int(stride)), "naqs_net_prof_stride")
 
     def prof_read(self):
         ms, n = ctypes.c_double(0), ctypes.c_int64(0)

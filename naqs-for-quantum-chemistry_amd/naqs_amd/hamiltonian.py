@@ -72,7 +72,7 @@ class DevicePauliHamiltonian:
     def reserve(self, M):
         _lib.check(self._lib.naqs_ham_reserve(self._h, int(M)), "naqs_ham_reserve")
 
-    def local_energy(self, keys, wf, kind="psi", row_begin=0, n_rows=None, out=None):
+    def local_energy(self, keys, wf, kind="psi", row_begin=0, n_rows=None, out=None, weights=None, sums_out=None):
         """E_loc for table rows [row_begin, row_begin+n_rows) -> float64 tensor [n_rows, 2] (Re, Im).
 
         keys : int64 device tensor [M] (bit pattern of the uint64 keys), unique, physical
@@ -93,6 +93,18 @@ class DevicePauliHamiltonian:
             raise TypeError(f"unsupported wave-function kind/dtype: {kind}/{wf.dtype}")
         if out is None:
             out = torch.empty((n_rows, 2), dtype=torch.float64, device=self.device)
+        if weights is not None:
+            # fused: E_loc and (sum w Re E, sum w Im E, sum w Re(E)^2, sum w) of the produced rows in one launch
+            w = weights.to(device=self.device, dtype=torch.float64).contiguous()
+            if w.shape[0] != n_rows:
+                raise ValueError("weights must cover exactly the produced rows")
+            if sums_out is None:
+                sums_out = torch.empty(4, dtype=torch.float64, device=self.device)
+            st = self._lib.naqs_eloc_reduced(self._h, M, keys.data_ptr(), wf.data_ptr(), code, int(row_begin),
+                                             int(n_rows), w.data_ptr(), out.data_ptr(), sums_out.data_ptr(),
+                                             _stream_ptr(self.device))
+            _lib.check(st, "naqs_eloc_reduced")
+            return out, sums_out
         st = self._lib.naqs_eloc(self._h, M, keys.data_ptr(), wf.data_ptr(), code, int(row_begin), int(n_rows),
                                  out.data_ptr(), _stream_ptr(self.device))
         _lib.check(st, "naqs_eloc")
@@ -119,8 +131,9 @@ class DevicePauliHamiltonian:
         return out
 
     # ---- measurement ---------------------------------------------------------------------------
-    def prof_enable(self, max_records):
+    def prof_enable(self, max_records, stride=1):
         _lib.check(self._lib.naqs_prof_enable(self._h, int(max_records)), "naqs_prof_enable")
+        _lib.check(self._lib.naqs_prof_stride(self._h, int(stride)), "naqs_prof_stride")
 
     def prof_read(self):
         ms, n = ctypes.c_double(0), ctypes.c_int64(0)

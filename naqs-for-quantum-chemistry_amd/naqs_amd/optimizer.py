@@ -186,8 +186,9 @@ class OptimizerBase:
                 sample_weights = sample_weights / sample_weights.sum()
         w = sample_weights.reshape(-1).to(self.device, torch.float64)
 
-        e_loc = self.calculate_local_energy(keys, log_psi=lp_all, row_begin=b, n_rows=e_ - b)
-        sums = self.pauli_hamiltonian.reduce(w[b:e_], e_loc)            # sum w Re, sum w Im, sum w Re^2, sum w
+        # E_loc of the owned rows + (sum w Re, sum w Im, sum w Re^2, sum w) in one launch
+        e_loc, sums = self.pauli_hamiltonian.local_energy(keys, lp_all.detach(), kind="log_psi", row_begin=b,
+                                                          n_rows=e_ - b, weights=w[b:e_])
         if dist:
             dist.all_reduce(sums)
         e_mean = torch.stack([sums[0], sums[1]])                        # (sum w E_loc), like energy.py:328 (w not renormalised)

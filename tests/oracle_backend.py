@@ -13,13 +13,16 @@ class OracleHamiltonian:
         self.packed = packed
         self.device = torch.device("cpu")
 
-    def local_energy(self, keys, wf, kind="psi", row_begin=0, n_rows=None, out=None):
+    def local_energy(self, keys, wf, kind="psi", row_begin=0, n_rows=None, out=None, weights=None, sums_out=None):
         k = keys.cpu().numpy().astype(np.int64).view(np.uint64)
         v = wf.detach().cpu().numpy().astype(np.float64)
         psi = np.exp(v[:, 0] + 1j * v[:, 1]) if kind == "log_psi" else v[:, 0] + 1j * v[:, 1]
         e = oracle.eloc_matrix_free(self.packed.xy, self.packed.yz, self.packed.coeff, k, psi,
                                     row_begin=row_begin, n_rows=n_rows)
-        return torch.tensor(np.stack([e.real, e.imag], -1))
+        out = torch.tensor(np.stack([e.real, e.imag], -1))
+        if weights is not None:
+            return out, self.reduce(weights, out)
+        return out
 
     def reduce(self, weights, eloc):
         w = weights.double()

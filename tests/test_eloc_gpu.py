@@ -322,3 +322,41 @@ def test_reduce_matches_oracle(env):
     assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) < 1e-12
     E = got[0] / got[3]
     assert abs(E - z["sgd_E"]) < 2e-5 * abs(E)
+
+
+def test_fused_reduction_and_epoch_wrap(env):
+    """naqs_eloc_reduced == naqs_eloc + naqs_eloc_reduce; and 600 consecutive calls on one handle with
+    alternating sample sets cross the 8-bit epoch wrap of the never-cleared hash table twice."""
+    h = golden("ham_N2.npz")
+    z = golden("eloc_N2.npz")
+    ham = dev_ham(env, "N2")
+    keys_a, psi_a, want_a = z["small_keys"], z["small_psi_f32"], z["small_eloc_c128"]
+    space = all_keys(20, 7, 7)
+    keys_b = np.sort(np.random.RandomState(77).choice(space, 3000, replace=False))
+    lp = synth_logpsi(3000, 78)
+    psi_b = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    want_b = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys_b, psi_b)
+    ka = env["H"].keys_to_device(keys_a, ham.device)
+    kb = env["H"].keys_to_device(keys_b, ham.device)
+    wa = torch.as_tensor(psi_a, device=ham.device)
+    wb = torch.as_tensor(np.stack([psi_b.real, psi_b.imag], -1), device=ham.device)
+    w = torch.rand(len(keys_a), dtype=torch.float64, device=ham.device)
+    e, sums = ham.local_energy(ka, wa, weights=w)
+    ref = ham.reduce(w, e)
+    torch.cuda.synchronize()
+    assert torch.max(torch.abs(sums - ref) / ref.abs().clamp(min=1)).item() < 1e-12
+    for it in range(600):
+        if it % 2:
+            e = ham.local_energy(kb, wb)
+        else:
+            e, sums = ham.local_energy(ka, wa, weights=w)
+    torch.cuda.synchronize()
+    eb = ham.local_energy(kb, wb).cpu().numpy()
+    ea, sums = ham.local_energy(ka, wa, weights=w)
+    ea = ea.cpu().numpy()
+    assert rel_err(eb[:, 0] + 1j * eb[:, 1], want_b) < 1e-10
+    assert rel_err(ea[:, 0] + 1j * ea[:, 1], want_a) < 1e-10
+    assert torch.max(torch.abs(sums - ref) / ref.abs().clamp(min=1)).item() < 1e-12
+    # row shard + weights of the shard
+    e2, s2 = ham.local_energy(ka, wa, row_begin=500, n_rows=700, weights=w[500:1200])
+    assert torch.max(torch.abs(s2 - ham.reduce(w[500:1200], e2)) / s2.abs().clamp(min=1)).item() < 1e-12
