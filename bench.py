@@ -123,7 +123,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl")
 
     ham_p = packing.load_packed(os.path.join(ROOT, "tests", "golden", f"ham_{args.molecule}.npz"))
     ham = hamiltonian.DevicePauliHamiltonian(ham_p, device=dev)

@@ -38,7 +38,29 @@ class Molecule:
         return int((self.n_electrons - (self.multiplicity - 1)) // 2)
 
 
+class PackedMolecule:
+    """Molecule metadata carried by a packed-term ``.npz`` (tests/golden/ham_<mol>.npz)."""
+
+    def __init__(self, path):
+        with np.load(path) as z:
+            self.name = os.path.splitext(os.path.basename(path))[0]
+            self.n_qubits = int(z["n_qubits"])
+            self.n_electrons = int(z["n_electrons"]) if "n_electrons" in z else int(z["n_alpha"]) + int(z["n_beta"])
+            self.multiplicity = int(z["multiplicity"]) if "multiplicity" in z else 1
+            self.n_orbitals = self.n_qubits // 2
+            for k in ("hf_energy", "ccsd_energy", "fci_energy", "mp2_energy"):
+                setattr(self, k, float(z[k]) if k in z else None)
+        self.basis = self.description = None
+
+    get_n_alpha_electrons = Molecule.get_n_alpha_electrons
+    get_n_beta_electrons = Molecule.get_n_beta_electrons
+
+
 def load_molecule(fname, hamiltonian_fname=None, verbose=True):
+    if fname.endswith(".npz"):
+        # packed fixture instead of <dir>/<name>.hdf5 + <name>_qubit_hamiltonian.pkl
+        from .packing import load_packed
+        return PackedMolecule(fname), load_packed(fname)
     if os.path.isdir(fname):
         fname = os.path.join(fname, os.path.split(os.path.normpath(fname))[-1])
     print(f"Loading molecule from {fname}.hdf5", end="...")

@@ -81,10 +81,20 @@ class _StubHilbert:
         return idx
 
 
+def molecule_scalars(mol):
+    """n_electrons / multiplicity / reference energies from the molecule's HDF5 file (read with this repo's
+    own minimal reader — h5py is not installed)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "naqs-for-quantum-chemistry_amd"))
+    from naqs_amd.hdf5_lite import read_hdf5
+    v = read_hdf5(os.path.join(rh.REFERENCE, "molecules", mol, f"{mol}.hdf5"),
+                  keys=["n_electrons", "multiplicity", "hf_energy", "ccsd_energy", "fci_energy"])
+    return {k: np.float64(v[k]) if isinstance(v[k], float) else np.int64(v[k]) for k in v}
+
+
 def pack_hamiltonian(mol, ph, hilbert_N, out):
     na, nb = electrons(mol)
     np.savez_compressed(
-        out,
+        out, **molecule_scalars(mol),
         n_qubits=np.int64(hilbert_N), n_alpha=np.int64(na), n_beta=np.int64(nb),
         xy=ph.XY_sites_idx.astype(np.uint64), yz=ph.YZ_sites_idx.astype(np.uint64),
         coeff=ph.couplings.squeeze().astype(np.float64),
