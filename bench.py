@@ -41,8 +41,20 @@ def physical_keys(n_qubits, n_alpha, n_beta):
 def make_batch(ham, M, seed):
     """keys = sort(RandomState(1234).choice(all physical keys, M)); synthetic
     psi: log|psi| ~ N(-ln(M)/2, 2), phase ~ U[0, 2pi)."""
-    space = physical_keys(ham.n_qubits, ham.n_alpha, ham.n_beta)
-    keys = np.sort(np.random.RandomState(1234 + seed).choice(space, M, replace=False))
+    n_orb = ham.n_qubits // 2
+    from math import comb
+    if comb(n_orb, ham.n_alpha) * comb(n_orb, ham.n_beta) <= 2_000_000:
+        space = physical_keys(ham.n_qubits, ham.n_alpha, ham.n_beta)
+        keys = np.sort(np.random.RandomState(1234 + seed).choice(space, M, replace=False))
+    else:
+        # config C4 (Li2O: 41 409 225 states): M distinct keys, alpha part = random n_alpha-subset of the even
+        # bits, beta part = random n_beta-subset of the odd bits
+        rs0 = np.random.RandomState(1234 + seed)
+        ev, od, out = np.arange(0, ham.n_qubits, 2), np.arange(1, ham.n_qubits, 2), set()
+        while len(out) < M:
+            a, b_ = rs0.choice(ev, ham.n_alpha, replace=False), rs0.choice(od, ham.n_beta, replace=False)
+            out.add(int(sum(1 << int(q) for q in a) | sum(1 << int(q) for q in b_)))
+        keys = np.sort(np.array(list(out), np.uint64))
     rs = np.random.RandomState(4321 + seed)
     log_psi = np.stack([rs.normal(-0.5 * np.log(M), 2.0, M), rs.uniform(0, 2 * np.pi, M)], -1).astype(np.float32)
     counts = rs.poisson(5, M) + 1
@@ -191,7 +203,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "eloc_kernel",
                      "kernel_us": t_kernel * 1e6, "algorithmic_bytes_per_launch": b_alg}
         # phase MLP: 2*(K*N) flops per layer and sample (18->512->512->4 for N2), f32 matrix cores
-        dims = [2 * (ham.n_qubits // 2 - 1), 512, 512, 4]
+        dims = [max(1, 2 * (ham.n_qubits // 2 - 1)), 512, 512, 4]
         flops = 2.0 * M * sum(a * b for a, b in zip(dims, dims[1:]))
         t_mlp = mlp_ms / max(mlp_launches, 1) * 1e-3
         mlp_tf = flops / t_mlp / 1e12 if t_mlp > 0 else 0.0
@@ -203,15 +215,16 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            eloc_roof["traffic"] = pmc["eloc_kernel"]["hbm_bytes_per_launch"]
-            mlp_roof["traffic"] = pmc["phase_kernel"]["hbm_bytes_per_launch"]
+            if args.molecule == "N2" and M == 10000:           # the PMC passes were taken on this workload
+                eloc_roof["traffic"] = pmc["eloc_kernel"]["hbm_bytes_per_launch"]
+                mlp_roof["traffic"] = pmc["phase_kernel"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         dominant, other = (mlp_roof, eloc_roof) if t_mlp >= t_kernel else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]
         out = {
-            "metric": "unique samples/sec through E_loc + log-psi eval (N2, 20 qubits)",
+            "metric": f"unique samples/sec through E_loc + log-psi eval ({args.molecule}, {ham.n_qubits} qubits)",
             "value": world * M * args.steps / dt,
             "unit": "unique samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

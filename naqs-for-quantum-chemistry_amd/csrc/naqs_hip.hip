@@ -137,12 +137,13 @@ __device__ __forceinline__ int hash_find(const Slot<KT> *__restrict__ tab, int b
     return probe_resolve(tab, bits, tag, key, h, probe_load(tab, h));
 }
 
+constexpr int PREP_BLOCK = 64;   // one wave per workgroup: M = 10^4 still spreads over 157 CUs
 template <typename KT>
-__global__ __launch_bounds__(BLOCK) void prep_kernel(int64_t M, const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(PREP_BLOCK) void prep_kernel(int64_t M, const uint64_t *__restrict__ keys,
                                                      const void *__restrict__ psi_in, int psi_kind,
                                                      KT *__restrict__ keys_out, double2 *__restrict__ psi_out,
                                                      Slot<KT> *__restrict__ tab, int bits, uint32_t tag) {
-    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < M; i += (int64_t)gridDim.x * BLOCK) {
+    for (int64_t i = blockIdx.x * (int64_t)PREP_BLOCK + threadIdx.x; i < M; i += (int64_t)gridDim.x * PREP_BLOCK) {
         const KT k = (KT)keys[i];
         keys_out[i] = k;
         hash_insert(tab, bits, tag, k, (uint32_t)i);
@@ -544,8 +545,8 @@ int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
     }
     const uint32_t tag = h->epoch << 24;
     {
-        const int grid = (int)std::min<int64_t>((M + BLOCK - 1) / BLOCK, 4 * h->cu_count);
-        hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
+        const int grid = (int)std::min<int64_t>((M + PREP_BLOCK - 1) / PREP_BLOCK, 16 * h->cu_count);
+        hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(PREP_BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
                            reinterpret_cast<KT *>(h->d_keys), h->d_psi, tab, bits, tag);
         HIP_TRY(hipGetLastError());
     }

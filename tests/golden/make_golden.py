@@ -119,6 +119,50 @@ def gen_ham_only(mol):
           f"Kyz={len(ph._unique_YZ_sites_idx)}")
 
 
+def gen_li2o_subset():
+    """Li2O (30 qubits, int64 idx dtype): the reference's Hilbert/update_H cannot be instantiated here
+    (2^30-entry look-up tables), but its Cython kernels can be driven directly — the pipeline of
+    update_H (hamiltonian.py:301-337) on a clustered sample set with the reference's own
+    popcount_parity / get_Hij_cy / sparse_dense_mv, the particle-number test standing in for the 2^N table."""
+    from scipy.sparse import csr_matrix
+    mol = "Li2O"
+    qh = rh.load_qubit_hamiltonian(mol)
+    N = rh.n_qubits_of(qh)
+    ph = object.__new__(_PauliHamiltonianDynamic)
+    ph.hilbert, ph.qubit_hamiltonian = _StubHilbert(N), qh
+    ph.n_excitations_max, ph.dtype, ph.verbose = None, np.float64, False
+    XY, YZ, cpl = ph._PauliHamiltonianDynamic__calc_coupling_info()
+    uXY, u2aXY = np.unique(XY, return_inverse=True)
+    uYZ, u2aYZ = np.unique(YZ, return_inverse=True)
+    # clustered samples: a random walk over connected physical states from one determinant
+    rs = np.random.RandomState(2024)
+    amask, bmask = sum(1 << q for q in range(0, N, 2)), sum(1 << q for q in range(1, N, 2))
+    base = sum(1 << q for q in range(14))
+    keys, frontier = {base}, [base]
+    while len(keys) < 1500:
+        k = frontier[rs.randint(len(frontier))]
+        j = k ^ int(uXY[rs.randint(len(uXY))])
+        if bin(j & amask).count("1") == 7 and bin(j & bmask).count("1") == 7 and j not in keys:
+            keys.add(j)
+            frontier.append(j)
+    keys = np.sort(np.array(list(keys), np.int64))
+    M, Kxy = len(keys), len(uXY)
+    P = popcount_parity(np.bitwise_and(keys[:, None], uYZ[None, :]))
+    Hij = get_Hij_cy(keys, uXY, u2aXY, P, u2aYZ, cpl.squeeze())
+    j_full = np.bitwise_xor(keys[:, None], uXY[None, :]).ravel()
+    pos = np.searchsorted(keys, j_full)
+    pos[pos == M] = 0
+    hit = keys[pos] == j_full                      # sampled (hence physical) connected states only
+    rows = np.repeat(np.arange(M), Kxy)[hit]
+    H = csr_matrix((Hij[hit], (rows, pos[hit])), shape=(M, M))
+    log_psi, psi = synthetic_psi(M, 1.5, seed=99)
+    v = cplx.torch_to_numpy(psi)
+    e = (sparse_dense_mv(H, v) / v).conj()
+    np.savez_compressed(os.path.join(HERE, "eloc_Li2O_subset.npz"), keys=keys.astype(np.uint64),
+                        psi_f32=psi.numpy(), log_psi_f32=log_psi.numpy(), eloc_c128=e, nnz=np.int64(H.nnz))
+    print(f"[eloc] Li2O subset: M={M} nnz={H.nnz} <E_loc>={e.real.mean():.6f}")
+
+
 def wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking=NadeMasking.PARTIAL):
     # experiments/_base.py:150-187 with the published flags (batch_train.sh:14)
     return dict(qubit_ordering=-1, masking=masking, num_lut=0, input_encoding=InputEncoding.BINARY,
@@ -298,6 +342,7 @@ def main():
     gen_molecule("H2O", {"c1": (300, 1.0)}, (64, 32, 2), kat=kat)
     gen_molecule("N2", {"small": (2000, 2.0), "c2": (10000, 2.0)}, (64, 512, 2), kat=kat, time_it=True)
     gen_ham_only("Li2O")
+    gen_li2o_subset()
     for mol in N2_SWEEP:
         gen_ham_only(mol)
     with open(os.path.join(HERE, "kat.json"), "w") as f:

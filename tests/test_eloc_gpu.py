@@ -82,6 +82,16 @@ def test_eloc_matches_reference_golden(env, mol, tag):
     assert np.max(np.abs(e.real - z[f"{tag}_eloc_f32"][:, 0]) / np.maximum(1, np.abs(e.real))) < 2e-6
 
 
+def test_li2o_subset_matches_reference_cython_kernels(env):
+    """Config-4 Hamiltonian, golden from the reference's Cython kernels (int64 idx dtype path)."""
+    z = golden("eloc_Li2O_subset.npz")
+    ham = dev_ham(env, "Li2O")
+    e = run_eloc(env, ham, z["keys"], z["psi_f32"])
+    assert rel_err(e, z["eloc_c128"]) < 1e-10
+    e = run_eloc(env, ham, z["keys"], z["log_psi_f32"], kind="log_psi")
+    assert rel_err(e, z["eloc_c128"]) < 2e-5          # log-psi route recomputes psi from float32 (log|psi|, phase)
+
+
 @pytest.mark.parametrize("mol", ["LiH", "H2O", "N2"])
 def test_inner_ring_bit_exact(env, mol):
     z = golden(f"eloc_{mol}.npz")

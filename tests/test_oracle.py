@@ -136,3 +136,13 @@ def test_fci_known_answer(mol):
     w = spla.eigsh(H, k=1, which="SA", return_eigenvectors=False)[0]
     assert abs(w - kat["fci"][mol]) < 1e-9
     assert H.nnz == kat["nnz"][mol]
+
+
+def test_li2o_subset_vs_reference_cython_kernels():
+    """30 qubits / int64 keys: E_loc from the reference's own popcount_parity + get_Hij_cy + sparse_dense_mv
+    driven directly (tests/golden/make_golden.py:gen_li2o_subset)."""
+    h, z = golden("ham_Li2O.npz"), golden("eloc_Li2O_subset.npz")
+    e = oracle.eloc_matrix_free(h["xy"], h["yz"], h["coeff"], z["keys"], z["psi_f32"])
+    assert rel_err(e, z["eloc_c128"]) < 1e-12
+    e = oracle.eloc_staged(30, 7, 7, h["xy"], h["yz"], h["coeff"], z["keys"], z["psi_f32"])
+    assert rel_err(e, z["eloc_c128"]) < 1e-12
