@@ -57,6 +57,10 @@ struct NetDims {
     int32_t n_lin;
     int32_t K_pad[MAXL], N_pad[MAXL], w_off[MAXL], b_off[MAXL];
     int32_t ld;                        // LDS row stride (floats)
+    // the same MLP split in 3 bf16 planes for the bf16 matrix cores (phase_kernel_bf16x3):
+    // layer l: planes [3][N_pad/16][Kh_pad/32][64 lanes][8 bf16] at wh_off (in bf16 units), bias (f32) at b_off
+    int32_t Kh_pad[MAXL], wh_off[MAXL];
+    int32_t ldh;                       // LDS row stride of one activation plane (bf16 units)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -394,6 +398,214 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// phase MLP on the bf16 matrix cores with f32-equivalent accuracy ("bf16x3"): every f32 value is split
+// into three bf16 planes x = x1 + x2 + x3 (8 + 8 + 8 mantissa bits: exact), and a product is formed from
+// the six cross terms a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2 (each exact in f32; the three dropped
+// terms are <= 2^-24 |ab|, below f32 rounding), accumulated in f32 by v_mfma_f32_16x16x32_bf16.
+// bf16 MFMA is 16x the f32 MFMA rate, so 6 of them per product are still ~2.7x faster.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short ushort_t;
+
+__device__ __forceinline__ ushort_t f32_to_bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (ushort_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(ushort_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ void split3(float x, ushort_t &h1, ushort_t &h2, ushort_t &h3) {
+    h1 = f32_to_bf16_rne(x);
+    const float r1 = x - bf16_to_f32(h1);
+    h2 = f32_to_bf16_rne(r1);
+    const float r2 = r1 - bf16_to_f32(h2);
+    h3 = f32_to_bf16_rne(r2);
+}
+
+template <int RB, int NC>
+__device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
+                                                 const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
+                                                 f32x4 (&acc)[RB][CBT]) {
+    // a_ptr: this lane's row/k-group inside plane 0 of the activation tile; w_ptr: this lane's 8 weights of
+    // column block 0, chunk 0, plane 0.  Chunks are 32 wide (one MFMA K).
+    for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
+        bf16x8 a[3][RB], b[3][NC];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                b[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + ((size_t)c * Kh_pad + k0) * 16);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                a[p][rb] = *reinterpret_cast<const bf16x8 *>(a_ptr + p * plane_stride + rb * 16 * ldh + k0);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x4 v = acc[rb][c];
+                // smallest terms first
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b[1][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][rb], b[0][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[2][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b[0][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[1][c], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[0][c], v, 0, 0, 0);
+                acc[rb][c] = v;
+            }
+    }
+}
+
+// one layer: planes[3][BM][ldh] (bf16) -> planes (hidden layers) or f32 out[BM][16] in the same LDS (last layer)
+template <int RB>
+__device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int ldh, int Kh_pad, int N_pad,
+                                            const ushort_t *__restrict__ W, const float *__restrict__ bias, bool last,
+                                            int wave, int lane) {
+    constexpr int BM = RB * 16;
+    const int m = lane & 15, kg = lane >> 4;
+    const int ncb = N_pad >> 4;
+    const int plane_stride = BM * ldh;
+    const size_t wplane = (size_t)N_pad * Kh_pad;
+    f32x4 acc[RB][CBT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int c = 0; c < CBT; ++c) acc[rb][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const ushort_t *a_ptr = planes + m * ldh + 8 * kg;
+    if (ncb == 1) {
+        // <= 16 outputs: the waves split K, partial tiles are summed through LDS in fixed order
+        const int chunks = Kh_pad >> 5, cpw = (chunks + PH_WAVES - 1) / PH_WAVES;
+        const int kbeg = min(chunks, wave * cpw) << 5, klen = (min(chunks, (wave + 1) * cpw) << 5) - kbeg;
+        if (klen > 0)
+            mlp_accumulate_h<RB, 1>(a_ptr + kbeg, ldh, plane_stride, W + (size_t)kbeg * 16 + lane * 8, klen, wplane, acc);
+        // NB: inside mlp_accumulate_h the chunk offset is ((c*Kh_pad + k0)*16) with the *layer's* Kh_pad only for
+        // c > 0; with NC == 1 the sub-range length may be passed as Kh_pad.
+        __syncthreads();
+        float *part = reinterpret_cast<float *>(planes);          // inputs are dead: reuse as f32 scratch
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * BM + rb * 16 + kg * 4 + r) * 16 + m] = acc[rb][0][r];
+        __syncthreads();
+        constexpr int PER = (BM * 16 + PH_THREADS - 1) / PH_THREADS;
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = u * PH_THREADS + wave * WAVE + lane;
+            v[u] = 0.0f;
+            if (t < BM * 16) {
+                v[u] = bias[t & 15];
+#pragma unroll
+                for (int q = 0; q < PH_WAVES; ++q) v[u] += part[q * BM * 16 + t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = u * PH_THREADS + wave * WAVE + lane;
+            if (t < BM * 16) {
+                if (last) part[t] = v[u];                          // f32 [BM][16]
+                else {
+                    ushort_t h1, h2, h3;
+                    split3(fmaxf(v[u], 0.0f), h1, h2, h3);
+                    const int o = (t >> 4) * ldh + (t & 15);
+                    planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    const int cb0 = wave * CBT;
+    const int my_cb = min(CBT, max(0, ncb - cb0));       // wave-uniform
+    const ushort_t *w_ptr = W + (size_t)cb0 * Kh_pad * 16 + lane * 8;
+    if (my_cb == CBT) mlp_accumulate_h<RB, CBT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb >= 4) mlp_accumulate_h<RB, (CBT > 4 ? 4 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb == 3) mlp_accumulate_h<RB, (CBT > 3 ? 3 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb == 2) mlp_accumulate_h<RB, (CBT > 2 ? 2 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb == 1) mlp_accumulate_h<RB, 1>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    __syncthreads();                                      // everyone is done reading the input
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the three planes
+#pragma unroll
+    for (int c = 0; c < CBT; ++c) {
+        if (c < my_cb) {
+            const int col = (cb0 + c) * 16 + m;
+            const float bv = bias[col];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ushort_t h1, h2, h3;
+                    split3(fmaxf(acc[rb][c][r] + bv, 0.0f), h1, h2, h3);
+                    const int o = (rb * 16 + kg * 4 + r) * ldh + col;
+                    planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
+                }
+        }
+    }
+    __syncthreads();
+}
+
+template <int RB>
+__global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims d, const float *__restrict__ w,
+                                                                  const ushort_t *__restrict__ wh, int64_t M,
+                                                                  const uint64_t *__restrict__ keys,
+                                                                  const float *__restrict__ scratch,
+                                                                  float2 *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
+    constexpr int BM = RB * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int P = d.P, ldh = d.ldh;
+
+    float la = 0.0f;
+    if (tid < BM && row0 + tid < M)
+        for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
+
+    // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero)
+    const int K0 = d.Kh_pad[0];
+    for (int e = tid; e < BM * K0; e += PH_THREADS) {
+        const int r = e / K0, k = e - r * K0;
+        const int64_t i = row0 + r;
+        ushort_t v = 0;
+        if (i < M && k < 2 * (P - 1)) {
+            const uint64_t key = keys[i];
+            const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
+            v = ((key >> q) & 1ull) ? (ushort_t)0x3F80 : (ushort_t)0xBF80;      // +1.0 / -1.0
+        }
+        planes[r * ldh + k] = v;
+        planes[BM * ldh + r * ldh + k] = 0;
+        planes[2 * BM * ldh + r * ldh + k] = 0;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < d.n_lin; ++l)
+        mlp_layer_h<RB>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane);
+
+    if (tid < BM) {
+        const int64_t i = row0 + tid;
+        if (i < M) {
+            const uint64_t key = keys[i];
+            const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
+            out[i] = make_float2(la, reinterpret_cast<const float *>(planes)[tid * 16 + occ]);
+        }
+    }
+}
+
+// f32 [N][K] -> three bf16 planes, zero-padded and tiled [plane][N_pad/16][Kh_pad/32][64 lanes][8]
+__global__ __launch_bounds__(256) void pack_phase_bf16_kernel(const float *__restrict__ src, int K, int N, int Kh_pad,
+                                                              int N_pad, ushort_t *__restrict__ Wd) {
+    const int total = N_pad * Kh_pad;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        // e = ((cb * KC + kc) * 64 + kg * 16 + nn) * 8 + j   <-   W[cb*16 + nn][kc*32 + kg*8 + j]
+        const int j = e & 7, nn = (e >> 3) & 15, kg = (e >> 7) & 3, blk = e >> 9;
+        const int KC = Kh_pad >> 5, cb = blk / KC, kc = blk - cb * KC;
+        const int n = cb * 16 + nn, k = kc * 32 + kg * 8 + j;
+        const float x = (n < N && k < K) ? src[n * K + k] : 0.0f;
+        ushort_t h1, h2, h3;
+        split3(x, h1, h2, h3);
+        Wd[e] = h1; Wd[(size_t)total + e] = h2; Wd[2 * (size_t)total + e] = h3;
+    }
+}
+
 // re-pack the flat state_dict-order parameters into the kernels' layout
 // amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]] ->
 // Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
@@ -443,6 +655,8 @@ struct naqs_net {
     std::vector<int64_t> phase_src_off;     // per phase linear layer: offset in the flat source
     std::vector<int> phase_K, phase_N;
     float *d_w = nullptr;                   // [amp params | packed phase layers]
+    unsigned short *d_wh = nullptr;         // phase layers as 3 bf16 planes (phase_kernel_bf16x3)
+    int64_t wh_elems = 0;
     int64_t w_floats = 0;
     float *d_scratch = nullptr;             // [P][cap_M] log-amplitude contributions
     int64_t cap_M = 0;
@@ -517,6 +731,20 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         K = Nout;
     }
     d.ld = max_k + 4;                       // +4 floats: consecutive rows start one 16-byte LDS slot apart
+    {   // bf16x3 layout: K padded to the 32-wide bf16 MFMA chunk
+        int64_t hoff = 0;
+        int Kh = std::max(1, 2 * (P - 1)), max_kh = 0;
+        for (int l = 0; l < d.n_lin; ++l) {
+            const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : 4;
+            d.Kh_pad[l] = (Kh + 31) & ~31;
+            d.wh_off[l] = (int32_t)hoff;
+            hoff += 3ll * d.N_pad[l] * d.Kh_pad[l];
+            max_kh = std::max(max_kh, std::max(d.Kh_pad[l], d.N_pad[l]));
+            Kh = Nout;
+        }
+        d.ldh = max_kh + 8;                 // +16 bytes: consecutive rows start one LDS slot apart
+        net->wh_elems = hoff;
+    }
     net->n_params = src;
     net->w_floats = dst;
 
@@ -526,6 +754,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cu_count = prop.multiProcessorCount;
         if (hipMalloc((void **)&net->d_w, (size_t)net->w_floats * sizeof(float)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        if (st == NAQS_OK && hipMalloc((void **)&net->d_wh, (size_t)net->wh_elems * sizeof(unsigned short)) != hipSuccess) st = NAQS_ERR_NOMEM;
         // the activation tile of 48/64 rows x 516 floats exceeds the 64 KiB default of dynamic LDS
         const int lds_max = 4 * 16 * d.ld * (int)sizeof(float);
         if (lds_max > 160 * 1024) st = NAQS_ERR_UNSUPPORTED;
@@ -534,6 +763,10 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 2);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4 * 3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+            const int ldsh = 3 * 16 * d.ldh * (int)sizeof(unsigned short);      // per 16 rows
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
         }
     }
     if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
@@ -547,6 +780,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     (void)guard.init(net->device);
     (void)net->prof.enable(0);
     if (net->d_w) (void)hipFree(net->d_w);
+    if (net->d_wh) (void)hipFree(net->d_wh);
     if (net->d_scratch) (void)hipFree(net->d_scratch);
     delete net;
     return NAQS_OK;
@@ -578,6 +812,11 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
                            flat_dev + net->phase_src_off[(size_t)l], net->phase_K[(size_t)l], net->phase_N[(size_t)l],
                            d.K_pad[l], d.N_pad[l], net->d_w + d.w_off[l], net->d_w + d.b_off[l]);
         HIP_TRY(hipGetLastError());
+        const int total_h = d.N_pad[l] * d.Kh_pad[l];
+        hipLaunchKernelGGL(pack_phase_bf16_kernel, dim3((total_h + 255) / 256), dim3(256), 0, s,
+                           flat_dev + net->phase_src_off[(size_t)l], net->phase_K[(size_t)l], net->phase_N[(size_t)l],
+                           d.Kh_pad[l], d.N_pad[l], net->d_wh + d.wh_off[l]);
+        HIP_TRY(hipGetLastError());
     }
     net->have_weights = true;
     return NAQS_OK;
@@ -607,19 +846,32 @@ NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     HIP_TRY(hipGetLastError());
 
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
+    const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA
+    const size_t lds_h16 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
+    const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;
+    const int rb_max = use_h ? 3 : 4;
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
-    if (rb < 1 || rb > 4) rb = (int)std::min<int64_t>(4, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
+    if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
     const int bm = rb * 16;
     const unsigned grid = (unsigned)((M + bm - 1) / bm);
-    const size_t lds = (size_t)bm * d.ld * sizeof(float);
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
-    switch (rb) {
-        case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
-        case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
-        case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
-        default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+    if (use_h) {
+        const size_t lds = rb * lds_h16;
+        switch (rb) {
+            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out); break;
+            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out); break;
+            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out); break;
+        }
+    } else {
+        const size_t lds = (size_t)bm * d.ld * sizeof(float);
+        switch (rb) {
+            case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+            case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+            case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+            default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+        }
     }
     HIP_TRY(hipGetLastError());
     if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }

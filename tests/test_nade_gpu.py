@@ -113,3 +113,47 @@ def test_fused_refresh_after_parameter_update():
         want = wf.log_psi(torch.tensor(z["eval_states"], device="cuda"))
     assert torch.max(torch.abs(after - want)).item() < 2e-5
     assert torch.max(torch.abs(after - before)).item() > 1e-3
+
+
+def test_bf16x3_phase_kernel_is_f32_equivalent():
+    """The default phase kernel runs on the bf16 matrix cores with every f32 operand split into three bf16
+    planes (six exact cross products per multiply, f32 accumulation).  Against a float64 evaluation of the
+    same network its error must be of the same size as the exact-f32 MFMA kernel's (NAQS_PHASE_MODE=0)."""
+    import os
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden("nade_N2.npz")
+    hil, wf = make_wf("N2", z, device="cuda")
+    with torch.no_grad():                       # make the phase outputs O(10) so that relative errors are visible
+        for p in wf.model.phase_layers.parameters():
+            p.mul_(1.5)
+    fused = FusedLogPsi(wf)
+    keys_np = z["samp_keys"][:4096].astype(np.int64)
+    keys = keys_to_device(keys_np, wf.device)
+    # float64 reference of the phase MLP on the CPU
+    states = hil.idx2state(torch.tensor(keys_np)).double()
+    x = states[:, wf.qubit2model_permutation]
+    P = 10
+    h = torch.cat([x[:, 0:2 * (P - 1):2], x[:, 1:2 * (P - 1):2]], 1)
+    lins = [l for l in wf.model.phase_layers[0].linears()]
+    for i, lin in enumerate(lins):
+        h = h @ lin.weight.detach().double().cpu().T + lin.bias.detach().double().cpu()
+        if i + 1 < len(lins):
+            h = torch.relu(h)
+    occ = ((x[:, 2 * (P - 1)] > 0).long() + 2 * (x[:, 2 * (P - 1) + 1] > 0).long())
+    ref = h.gather(1, occ.view(-1, 1)).squeeze(1).numpy()
+    errs = {}
+    for mode in ("0", "1"):
+        os.environ["NAQS_PHASE_MODE"] = mode
+        try:
+            lp = fused.log_psi(keys)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["NAQS_PHASE_MODE"]
+        errs[mode] = np.abs(lp[:, 1].cpu().numpy().astype(np.float64) - ref)
+    scale = np.abs(ref).max()
+    print("phase error vs float64: f32 MFMA max %.3e mean %.3e | bf16x3 max %.3e mean %.3e | scale %.3f"
+          % (errs["0"].max(), errs["0"].mean(), errs["1"].max(), errs["1"].mean(), scale))
+    assert errs["0"].max() < 5e-6 * scale and errs["1"].max() < 5e-6 * scale, (errs["0"].max(), errs["1"].max(), scale)
+    assert errs["1"].mean() < 2.0 * errs["0"].mean() + 1e-9, (errs["0"].mean(), errs["1"].mean())
