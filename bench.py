@@ -162,8 +162,8 @@ def main():
     acc = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def step():
-        fused.log_psi(keys, out=log_psi)               # teacher-forced evaluation, float32 [M, 2]
-        ham.local_energy(keys, log_psi, kind="log_psi", out=eloc, weights=weights, sums_out=acc)
+        # one library call: amp_kernel (+ hash build) -> phase kernel (+ psi in f64) -> eloc_kernel -> reduce_kernel
+        fused.log_psi_and_local_energy(ham, keys, weights=weights, log_psi_out=log_psi, eloc_out=eloc, sums_out=acc)
         if world > 1:
             dist.all_reduce(acc)
 
@@ -245,7 +245,7 @@ def main():
             "dtype": "f32 network (bf16x3-split MFMA, f32-equivalent) / f64 E_loc", "data": "synthetic",
             "config": {"workload": f"{args.molecule} STO-3G ({ham.n_qubits} qubits, K={ham.K} Pauli terms, "
                                    f"Kxy={ham.Kxy}), {M} unique samples per GPU, 1xMI355X per rank",
-                       "stages": "fused NADE log-psi eval (amp 1x64, phase 2x512) + hash build + matrix-free E_loc "
+                       "stages": "fused NADE log-psi eval (amp 1x64, phase 2x512; builds the key hash + psi table) + matrix-free E_loc "
                                  "(f64) + weighted energy reduction"
                                  + (" + RCCL all-reduce of 4 accumulators" if world > 1 else ""),
                        "input": "unique sampled bit-strings (keys + int8 occupations) resident in HBM; random-init network",

@@ -186,6 +186,16 @@ int naqs_net_param_count(const naqs_net_t *net, int64_t *count);
 int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream);
 /* logpsi_dev: float [M][2] = (log|psi|, phase) for M keys. */
 int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream);
+/*
+ * The whole hot path of one VMC evaluation in one call: log psi of the M keys (naqs_net_logpsi) and their
+ * local energies against the same table (naqs_eloc with NAQS_LOGPSI_F32 over all rows, + naqs_eloc_reduce
+ * when w_dev/out4_dev are given).  The amplitude kernel inserts the keys into the E_loc hash table and the
+ * phase kernel writes psi in float64, so the E_loc stage needs no preparation kernel of its own.
+ * net and ham must live on the same device.  Results are identical to the two separate calls.
+ */
+int naqs_logpsi_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev,
+                     const double *w_dev, float *logpsi_dev, double *eloc_dev, double *out4_dev, void *stream);
+
 /* HIP-event timing of the phase-MLP kernel, like naqs_prof_enable / naqs_prof_read. */
 int naqs_net_prof_enable(naqs_net_t *net, int max_records);
 int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches);

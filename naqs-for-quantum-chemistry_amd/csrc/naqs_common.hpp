@@ -75,4 +75,11 @@ struct EventRing {
     }
 };
 
+struct ElocFeed;
+// implemented in naqs_hip.hip; used by the fused entry point naqs_logpsi_eloc
+int eloc_begin(naqs_ham *h, int64_t M, hipStream_t s, ElocFeed *feed);
+int eloc_main(naqs_ham *h, int64_t M, const ElocFeed &feed, double *eloc_dev, const double *w_dev, double *out4_dev,
+              hipStream_t s);
+int ham_device(const naqs_ham *h);
+
 }  // namespace naqs

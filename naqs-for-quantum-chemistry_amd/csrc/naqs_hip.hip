@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "naqs_common.hpp"
+#include "naqs_hash.hpp"
 
 namespace naqs { thread_local hipError_t g_last_hip = hipSuccess; }
 
@@ -54,88 +55,7 @@ constexpr int QUEUE_CAP = 64 * (LIGHT_BATCH + 1);   // per-wave hit queue: < 64 
 constexpr int LDS_BUDGET = 78 * 1024;      // per-workgroup dynamic LDS budget (160 KiB/CU -> 2 WGs/CU)
 constexpr int HEAVY_TERMS = 8;             // groups with more terms than this are "heavy"
 
-// Open-addressing hash table of the sample keys, rebuilt every call WITHOUT clearing it: each slot
-// carries the 8-bit epoch of the call that wrote it next to the 24-bit sample index, and a slot whose
-// epoch is not the current one counts as empty.  (The table is zeroed when it is allocated and when
-// the epoch wraps, every 255 calls.)  32-bit keys: one 8-byte word  key << 32 | epoch << 24 | index.
-constexpr uint32_t IDX_MASK = 0x00FFFFFFu;
-template <typename KT> struct Slot;
-template <> struct Slot<uint32_t> { unsigned long long kv; };
-template <> struct Slot<uint64_t> { unsigned long long key; uint32_t val; uint32_t pad; };   // val = epoch << 24 | index
-
-__device__ __forceinline__ int popc(uint32_t x) { return __popc(x); }
-__device__ __forceinline__ int popc(uint64_t x) { return __popcll(x); }
-
-__device__ __forceinline__ uint32_t hash_key(uint32_t k, int bits) { return (k * 0x9E3779B1u) >> (32 - bits); }
-__device__ __forceinline__ uint32_t hash_key(uint64_t k, int bits) {
-    return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - bits));
-}
-
-__device__ __forceinline__ void hash_insert(Slot<uint32_t> *tab, int bits, uint32_t tag, uint32_t key, uint32_t idx) {
-    const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = hash_key(key, bits);
-    const unsigned long long want = ((unsigned long long)key << 32) | tag | idx;
-    unsigned long long old = tab[h].kv;
-    for (;;) {
-        if (((uint32_t)old & ~IDX_MASK) == tag) {          // taken in this epoch -> next slot
-            h = (h + 1) & mask;
-            old = tab[h].kv;
-            continue;
-        }
-        const unsigned long long prev = atomicCAS(&tab[h].kv, old, want);
-        if (prev == old) return;
-        old = prev;                                         // lost the race for this slot: look again
-    }
-}
-__device__ __forceinline__ void hash_insert(Slot<uint64_t> *tab, int bits, uint32_t tag, uint64_t key, uint32_t idx) {
-    const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = hash_key(key, bits);
-    uint32_t old = tab[h].val;
-    for (;;) {
-        if ((old & ~IDX_MASK) == tag) {
-            h = (h + 1) & mask;
-            old = tab[h].val;
-            continue;
-        }
-        const uint32_t prev = atomicCAS(&tab[h].val, old, tag | idx);
-        if (prev == old) { tab[h].key = (unsigned long long)key; return; }   // claimed: readers run in a later kernel
-        old = prev;
-    }
-}
-
-// first probe (the load that matters for latency) and its resolution, split so that callers can put
-// several probes in flight before looking at any of them
-__device__ __forceinline__ unsigned long long probe_load(const Slot<uint32_t> *__restrict__ tab, uint32_t h) { return tab[h].kv; }
-__device__ __forceinline__ int probe_resolve(const Slot<uint32_t> *__restrict__ tab, int bits, uint32_t tag, uint32_t key,
-                                             uint32_t h, unsigned long long kv) {
-    const uint32_t mask = (1u << bits) - 1u;
-    for (;;) {
-        if (((uint32_t)kv & ~IDX_MASK) != tag) return -1;
-        if ((uint32_t)(kv >> 32) == key) return (int)((uint32_t)kv & IDX_MASK);
-        h = (h + 1) & mask;
-        kv = tab[h].kv;
-    }
-}
-struct Slot64Val { unsigned long long key; uint32_t val; };
-__device__ __forceinline__ Slot64Val probe_load(const Slot<uint64_t> *__restrict__ tab, uint32_t h) {
-    const Slot<uint64_t> s = tab[h];
-    return Slot64Val{s.key, s.val};
-}
-__device__ __forceinline__ int probe_resolve(const Slot<uint64_t> *__restrict__ tab, int bits, uint32_t tag, uint64_t key,
-                                             uint32_t h, Slot64Val s) {
-    const uint32_t mask = (1u << bits) - 1u;
-    for (;;) {
-        if ((s.val & ~IDX_MASK) != tag) return -1;
-        if (s.key == key) return (int)(s.val & IDX_MASK);
-        h = (h + 1) & mask;
-        s = probe_load(tab, h);
-    }
-}
-template <typename KT>
-__device__ __forceinline__ int hash_find(const Slot<KT> *__restrict__ tab, int bits, uint32_t tag, KT key) {
-    const uint32_t h = hash_key(key, bits);
-    return probe_resolve(tab, bits, tag, key, h, probe_load(tab, h));
-}
+using namespace naqs;   // Slot, hash_insert, probe_load, probe_resolve, hash_find, popc (naqs_hash.hpp)
 
 constexpr int PREP_BLOCK = 64;   // one wave per workgroup: M = 10^4 still spreads over 157 CUs
 template <typename KT>
@@ -532,24 +452,41 @@ int upload_tables(naqs_ham *h, const std::vector<uint64_t> &xy_g, const std::vec
     return NAQS_OK;
 }
 
-template <typename KT>
-int launch_eloc(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
-                int64_t row_begin, int64_t n_rows, double *eloc_dev, const double *w_dev, double *out4_dev,
-                hipStream_t s) {
-    const int bits = table_bits(M);
-    auto *tab = reinterpret_cast<Slot<KT> *>(h->d_tab);
+// one call = begin (scratch, epoch) -> feed (prep_kernel here, or a producer kernel of naqs_logpsi.hip) -> main
+int eloc_begin_impl(naqs_ham *h, int64_t M, hipStream_t s, naqs::ElocFeed *feed) {
+    int st = ensure_scratch(h, M);
+    if (st != NAQS_OK) return st;
+    const size_t slot = h->key_bits == 32 ? sizeof(Slot<uint32_t>) : sizeof(Slot<uint64_t>);
     // no per-call clearing: entries are tagged with the call's epoch; zero the table when the 8-bit epoch wraps
     if (++h->epoch > 255u) {
-        HIP_TRY(hipMemsetAsync(tab, 0, (size_t)h->tab_slots * sizeof(Slot<KT>), s));
+        HIP_TRY(hipMemsetAsync(h->d_tab, 0, (size_t)h->tab_slots * slot, s));
         h->epoch = 1;
     }
-    const uint32_t tag = h->epoch << 24;
-    {
-        const int grid = (int)std::min<int64_t>((M + PREP_BLOCK - 1) / PREP_BLOCK, 16 * h->cu_count);
-        hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(PREP_BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
-                           reinterpret_cast<KT *>(h->d_keys), h->d_psi, tab, bits, tag);
-        HIP_TRY(hipGetLastError());
-    }
+    feed->tab = h->d_tab;
+    feed->keys_narrow = h->d_keys;
+    feed->psi = h->d_psi;
+    feed->bits = table_bits(M);
+    feed->tag = h->epoch << 24;
+    feed->key_bits = h->key_bits;
+    return NAQS_OK;
+}
+
+template <typename KT>
+int launch_prep(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
+                const naqs::ElocFeed &f, hipStream_t s) {
+    const int grid = (int)std::min<int64_t>((M + PREP_BLOCK - 1) / PREP_BLOCK, 16 * h->cu_count);
+    hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(PREP_BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
+                       reinterpret_cast<KT *>(h->d_keys), h->d_psi, reinterpret_cast<Slot<KT> *>(f.tab), f.bits, f.tag);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+template <typename KT>
+int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_begin, int64_t n_rows, double *eloc_dev,
+                const double *w_dev, double *out4_dev, hipStream_t s) {
+    const int bits = f.bits;
+    const uint32_t tag = f.tag;
+    auto *tab = reinterpret_cast<Slot<KT> *>(f.tab);
 
     ElocParams<KT> p;
     p.xy_g = reinterpret_cast<const KT *>(h->d_xy);
@@ -782,12 +719,27 @@ static int eloc_common(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const
         return NAQS_OK;
     }
     if (!keys_dev || !psi_dev || !eloc_dev) return NAQS_ERR_INVALID;
-    st = ensure_scratch(h, M);
+    naqs::ElocFeed feed;
+    st = eloc_begin_impl(h, M, s, &feed);
     if (st != NAQS_OK) return st;
-    return h->key_bits == 32
-               ? launch_eloc<uint32_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s)
-               : launch_eloc<uint64_t>(h, M, keys_dev, psi_dev, psi_kind, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s);
+    st = h->key_bits == 32 ? launch_prep<uint32_t>(h, M, keys_dev, psi_dev, psi_kind, feed, s)
+                           : launch_prep<uint64_t>(h, M, keys_dev, psi_dev, psi_kind, feed, s);
+    if (st != NAQS_OK) return st;
+    return h->key_bits == 32 ? launch_main<uint32_t>(h, M, feed, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s)
+                             : launch_main<uint64_t>(h, M, feed, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s);
 }
+
+// hooks for the fused log-psi + E_loc entry point in naqs_logpsi.hip
+int naqs::eloc_begin(naqs_ham *h, int64_t M, hipStream_t s, naqs::ElocFeed *feed) {
+    if (!h || !feed || M <= 0 || M > (int64_t)IDX_MASK) return NAQS_ERR_INVALID;
+    return eloc_begin_impl(h, M, s, feed);
+}
+int naqs::eloc_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &feed, double *eloc_dev, const double *w_dev,
+                    double *out4_dev, hipStream_t s) {
+    return h->key_bits == 32 ? launch_main<uint32_t>(h, M, feed, 0, M, eloc_dev, w_dev, out4_dev, s)
+                             : launch_main<uint64_t>(h, M, feed, 0, M, eloc_dev, w_dev, out4_dev, s);
+}
+int naqs::ham_device(const naqs_ham *h) { return h->device; }
 
 NAQS_API int naqs_eloc(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
                        int64_t row_begin, int64_t n_rows, double *eloc_dev, void *stream) {

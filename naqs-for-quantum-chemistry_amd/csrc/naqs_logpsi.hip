@@ -30,11 +30,13 @@
 #include <vector>
 
 #include "naqs_common.hpp"
+#include "naqs_hash.hpp"
 
 namespace {
 
 using naqs::WAVE;
 using naqs::DeviceGuard;
+using naqs::ElocFeed;
 
 constexpr int MAXP = NAQS_NET_MAX_PAIRS;
 constexpr int MAXL = NAQS_NET_MAX_PHASE_LAYERS + 1;   // linear layers of the phase block
@@ -151,7 +153,7 @@ __device__ __forceinline__ float amp_finish(const NetDims &d, int NB, const floa
 // over more waves was measured 2x faster than giving each wave all of them.)
 __global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w,
                                                                            int64_t M, const uint64_t *__restrict__ keys,
-                                                                           float *__restrict__ scratch) {
+                                                                           float *__restrict__ scratch, const ElocFeed feed) {
     __shared__ float s_part[AMP_TILES][AMP_SPLIT][5][WAVE];
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // this pair's packed rows + b2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,6 +169,12 @@ __global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const
     }
     const int64_t i = ((int64_t)blockIdx.x * AMP_TILES + tile) * WAVE + lane;
     const uint64_t key = i < M ? keys[i] : 0ull;
+    // fused log-psi + E_loc call: the (light) n == 0 workgroups also narrow the keys and build the hash table
+    // of the E_loc stage, which then needs no prep kernel
+    if (feed.tab != nullptr && n == 0 && q == 0 && i < M) {
+        if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, i, key);
+        else naqs::feed_key<uint64_t>(feed, i, key);
+    }
     // prefix occupations of pairs 0..n-1 and the realised outcome of pair n
     uint32_t abits = 0, bbits = 0;
     for (int k = 0; k < n; ++k) {
@@ -356,7 +364,7 @@ template <int RB>
 __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, const float *__restrict__ w, int64_t M,
                                                            const uint64_t *__restrict__ keys,
                                                            const float *__restrict__ scratch,
-                                                           float2 *__restrict__ out) {
+                                                           float2 *__restrict__ out, const ElocFeed feed) {
     extern __shared__ __attribute__((aligned(16))) float buf[];
     constexpr int BM = RB * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,7 +401,9 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
         if (i < M) {
             const uint64_t key = keys[i];
             const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
-            out[i] = make_float2(la, buf[tid * ld + occ]);
+            const float ph = buf[tid * ld + occ];
+            out[i] = make_float2(la, ph);
+            if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
         }
     }
 }
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
                                                                   const ushort_t *__restrict__ wh, int64_t M,
                                                                   const uint64_t *__restrict__ keys,
                                                                   const float *__restrict__ scratch,
-                                                                  float2 *__restrict__ out) {
+                                                                  float2 *__restrict__ out, const ElocFeed feed) {
     extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
     constexpr int BM = RB * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -585,7 +595,9 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
         if (i < M) {
             const uint64_t key = keys[i];
             const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
-            out[i] = make_float2(la, reinterpret_cast<const float *>(planes)[tid * 16 + occ]);
+            const float ph = reinterpret_cast<const float *>(planes)[tid * 16 + occ];
+            out[i] = make_float2(la, ph);
+            if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
         }
     }
 }
@@ -822,7 +834,8 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     return NAQS_OK;
 }
 
-NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream) {
+static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
+                           const ElocFeed &feed) {
     if (!net || M < 0 || (M > 0 && (!keys_dev || !logpsi_dev))) return NAQS_ERR_INVALID;
     if (!net->have_weights) return NAQS_ERR_INVALID;
     if (M == 0) return NAQS_OK;
@@ -842,7 +855,7 @@ NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
     hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, net->d_w, M,
-                       keys_dev, net->d_scratch);
+                       keys_dev, net->d_scratch, feed);
     HIP_TRY(hipGetLastError());
 
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
@@ -860,22 +873,49 @@ NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     if (use_h) {
         const size_t lds = rb * lds_h16;
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out); break;
-            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out); break;
-            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out); break;
+            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
+            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
+            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
         }
     } else {
         const size_t lds = (size_t)bm * d.ld * sizeof(float);
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
-            case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
-            case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
-            default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out); break;
+            case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
         }
     }
     HIP_TRY(hipGetLastError());
     if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
     return NAQS_OK;
+}
+
+NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream) {
+    ElocFeed none{};
+    return net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, none);
+}
+
+NAQS_API int naqs_logpsi_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev,
+                              const double *w_dev, float *logpsi_dev, double *eloc_dev, double *out4_dev,
+                              void *stream) {
+    if (!net || !ham || M < 0 || (w_dev == nullptr) != (out4_dev == nullptr)) return NAQS_ERR_INVALID;
+    if (M > 0 && (!keys_dev || !logpsi_dev || !eloc_dev)) return NAQS_ERR_INVALID;
+    if (naqs::ham_device(ham) != net->device) return NAQS_ERR_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    if (M == 0) {
+        if (out4_dev) HIP_TRY(hipMemsetAsync(out4_dev, 0, 4 * sizeof(double), s));
+        return NAQS_OK;
+    }
+    ElocFeed feed{};
+    st = naqs::eloc_begin(ham, M, s, &feed);
+    if (st != NAQS_OK) return st;
+    st = net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, feed);      // amp kernel feeds keys, phase kernel feeds psi
+    if (st != NAQS_OK) return st;
+    return naqs::eloc_main(ham, M, feed, eloc_dev, w_dev, out4_dev, s);
 }
 
 NAQS_API int naqs_net_prof_enable(naqs_net_t *net, int max_records) {

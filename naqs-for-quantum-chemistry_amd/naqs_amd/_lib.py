@@ -42,6 +42,7 @@ SIGNATURES = {
     "naqs_net_param_count": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "naqs_net_set_weights": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "naqs_net_logpsi": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "naqs_logpsi_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_net_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }

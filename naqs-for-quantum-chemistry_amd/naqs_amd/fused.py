@@ -70,6 +70,25 @@ class FusedLogPsi:
         _lib.check(st, "naqs_net_logpsi")
         return out
 
+    def log_psi_and_local_energy(self, ham, keys, weights=None, log_psi_out=None, eloc_out=None, sums_out=None):
+        """keys -> (log psi float32 [M, 2], E_loc float64 [M, 2][, sums float64 [4]]) in one library call
+        (``naqs_logpsi_eloc``): the E_loc stage is fed by the log-psi kernels, no preparation kernel."""
+        M = keys.shape[0]
+        if log_psi_out is None:
+            log_psi_out = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+        if eloc_out is None:
+            eloc_out = torch.empty((M, 2), dtype=torch.float64, device=self.device)
+        w_ptr = s_ptr = None
+        if weights is not None:
+            weights = weights.to(device=self.device, dtype=torch.float64).contiguous()
+            if sums_out is None:
+                sums_out = torch.empty(4, dtype=torch.float64, device=self.device)
+            w_ptr, s_ptr = weights.data_ptr(), sums_out.data_ptr()
+        st = self._lib.naqs_logpsi_eloc(self._h, ham._h, M, keys.contiguous().data_ptr(), w_ptr,
+                                        log_psi_out.data_ptr(), eloc_out.data_ptr(), s_ptr, _stream_ptr(self.device))
+        _lib.check(st, "naqs_logpsi_eloc")
+        return (log_psi_out, eloc_out, sums_out) if weights is not None else (log_psi_out, eloc_out)
+
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")
         _lib.check(self._lib.naqs_net_prof_stride(self._h, int(stride)), "naqs_net_prof_stride")

@@ -157,3 +157,31 @@ def test_bf16x3_phase_kernel_is_f32_equivalent():
           % (errs["0"].max(), errs["0"].mean(), errs["1"].max(), errs["1"].mean(), scale))
     assert errs["0"].max() < 5e-6 * scale and errs["1"].max() < 5e-6 * scale, (errs["0"].max(), errs["1"].max(), scale)
     assert errs["1"].mean() < 2.0 * errs["0"].mean() + 1e-9, (errs["0"].mean(), errs["1"].mean())
+
+
+@pytest.mark.parametrize("mol", ["LiH", "N2"])
+def test_fused_logpsi_eloc_equals_separate_calls(mol):
+    """naqs_logpsi_eloc (keys inserted by the amplitude kernel, psi written by the phase kernel, no prep kernel)
+    == naqs_net_logpsi followed by naqs_eloc(+reduce): bit-identical, also across repeated calls (epochs)."""
+    import os
+    from test_nade import make_wf
+    from naqs_amd import hamiltonian, packing
+    from naqs_amd.fused import FusedLogPsi
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    fused = FusedLogPsi(wf)
+    ham = hamiltonian.DevicePauliHamiltonian(packing.load_packed(os.path.join(GOLDEN, f"ham_{mol}.npz")))
+    keys = hamiltonian.keys_to_device(z["samp_keys"], wf.device)
+    w = torch.as_tensor(z["samp_counts"].astype(np.float64), device=wf.device)
+    lp = fused.log_psi(keys)
+    e, sums = ham.local_energy(keys, lp, kind="log_psi", weights=w)
+    for _ in range(3):
+        lp2, e2, sums2 = fused.log_psi_and_local_energy(ham, keys, weights=w)
+    torch.cuda.synchronize()
+    assert torch.equal(lp, lp2) and torch.equal(e, e2) and torch.equal(sums, sums2)
+    lp3, e3 = fused.log_psi_and_local_energy(ham, keys)
+    assert torch.equal(e, e3)
+    # and against the reference's E_loc for these samples (float32 psi there -> 2e-5)
+    want = z["sgd_eloc_c128"]
+    got = e.cpu().numpy()
+    assert np.max(np.abs(got[:, 0] + 1j * got[:, 1] - want) / np.maximum(1, np.abs(want))) < 2e-5
