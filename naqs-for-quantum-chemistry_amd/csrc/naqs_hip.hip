@@ -548,9 +548,12 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
     HIP_TRY(hipGetLastError());
     if (prof) { int st = h->prof.end(s); if (st != NAQS_OK) return st; }
     if (w_dev) {
-        // (A reduction fused into eloc_kernel behind a last-workgroup ticket was measured: the extra
-        // barrier/fence code at the kernel tail slowed the whole kernel by 30-40 % on gfx950/ROCm 7.2 even
-        // when it was not executed, so the sums stay a separate 1-workgroup launch.)
+        // Measured alternatives, both slower than this separate ~6 us launch (any tiny kernel costs 4-6 us of
+        // queue time here, whatever it does): (1) the sums fused into eloc_kernel behind a last-workgroup ticket
+        // (per-workgroup partials with write-through stores, parallel final add): 36.9 us vs 20.4 + 6.2 — every
+        // workgroup pays a serial tail (weight load, LDS row sums, store drain, ticket round trip); with
+        // agent-scope release fences instead of write-through stores 94 us (an L2 write-back per workgroup);
+        // (2) a two-level multi-workgroup reduce kernel: 6.2 us, no better than one workgroup.
         hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(RED_BLOCK), 0, s, n_rows, w_dev,
                            reinterpret_cast<const double2 *>(eloc_dev), out4_dev);
         HIP_TRY(hipGetLastError());
