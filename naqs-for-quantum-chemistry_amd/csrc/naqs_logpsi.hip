@@ -43,16 +43,6 @@ constexpr int MAXL = NAQS_NET_MAX_PHASE_LAYERS + 1;   // linear layers of the ph
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef NAQS_PH_THREADS
-#define NAQS_PH_THREADS 512
-#endif
-#ifndef NAQS_PH_CBT
-#define NAQS_PH_CBT 4
-#endif
-constexpr int PH_THREADS = NAQS_PH_THREADS;      // 8 waves = 2 per SIMD: one computes while the other waits on loads
-constexpr int PH_WAVES = PH_THREADS / WAVE;
-constexpr int CBT = NAQS_PH_CBT;                 // 16-column blocks per wave per pass
-
 struct NetDims {
     int32_t P;                         // orbital pairs
     int32_t n_alpha, n_beta;           // < 0: unrestricted
@@ -223,65 +213,18 @@ __global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const
     }
 }
 
-// one (sample, pair n) item evaluated by a single thread, weights straight from global memory (lanes of a wave
-// share n almost always, so the 16-byte weight loads are wave-uniform and hit L1)
-__device__ __forceinline__ float amp_item(const NetDims &d, const float *__restrict__ w, uint64_t key, int n) {
-    uint32_t abits = 0, bbits = 0;
-    for (int k = 0; k < n; ++k) {
-        abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
-        bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
-    }
-    const int occ = (int)((key >> d.qa[n]) & 1ull) + 2 * (int)((key >> d.qb[n]) & 1ull);
-    const bool swap = d.sym && abits > bbits;
-    const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
-    const int nin = n == 0 ? 1 : 2 * n;
-    const float *rows = w + d.amp_off[n];
-    const float *b2 = rows + d.Ha * ((nin + 1 + 5 + 3) & ~3);
-    float o[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) o[c] = c < d.n_out_amp ? b2[c] : 0.0f;
-    switch (n) {
-#define CASE(NB) case NB: amp_partial<NB>(d, rows, first, second, 0, d.Ha, o); break;
-        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
-        CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
-#undef CASE
-        default: break;
-    }
-    return amp_finish(d, n, o, abits, bbits, occ);
-}
-
-// all N/2 amplitude conditionals of the BM rows of a phase-kernel workgroup (BM*P items over its threads, pair-
-// major so that a wave sees at most two different pairs); returns sum_n log-amp of row `tid` (tid < BM), summed
-// in fixed order n = 0..P-1.  Also feeds the E_loc hash table when the fused entry point asks for it.
-template <int BM>
-__device__ __forceinline__ float amp_rows(const NetDims &d, const float *__restrict__ w,
-                                          const uint64_t *__restrict__ keys, int64_t row0, int64_t M,
-                                          float *__restrict__ s_la, int tid, const ElocFeed &feed) {
-    const int P = d.P;
-    for (int item = tid; item < BM * P; item += PH_THREADS) {
-        const int n = item / BM, r = item - n * BM;
-        const int64_t i = row0 + r;
-        float v = 0.0f;
-        if (i < M) {
-            const uint64_t key = keys[i];
-            if (n == 0 && feed.tab != nullptr) {
-                if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, i, key);
-                else naqs::feed_key<uint64_t>(feed, i, key);
-            }
-            v = amp_item(d, w, key, n);
-        }
-        s_la[item] = v;
-    }
-    __syncthreads();
-    float la = 0.0f;
-    if (tid < BM)
-        for (int n = 0; n < P; ++n) la += s_la[n * BM + tid];
-    return la;
-}
-
 // ------------------------------------------------------------------------------------------------
 // phase MLP on the f32 matrix cores
 // ------------------------------------------------------------------------------------------------
+#ifndef NAQS_PH_THREADS
+#define NAQS_PH_THREADS 512
+#endif
+#ifndef NAQS_PH_CBT
+#define NAQS_PH_CBT 4
+#endif
+constexpr int PH_THREADS = NAQS_PH_THREADS;      // 8 waves = 2 per SIMD: one computes while the other waits on loads
+constexpr int PH_WAVES = PH_THREADS / WAVE;
+constexpr int CBT = NAQS_PH_CBT;                 // 16-column blocks per wave per pass
 
 // K loop of one linear layer for one wave: RB row blocks x NC column blocks of 16x16 outputs.
 // Operand layout of v_mfma_f32_16x16x4_f32: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15].
@@ -428,14 +371,10 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int P = d.P, ld = d.ld;
 
-    // log-amplitude sum of this thread's row: either evaluated right here (scratch == nullptr: one launch for the
-    // whole network) or read from the separate amp_kernel's output
+    // log-amplitude sum of this thread's row: issued now, consumed in the epilogue (latency hidden under the MLP)
     float la = 0.0f;
-    if (scratch == nullptr) {
-        la = amp_rows<BM>(d, w, keys, row0, M, buf + BM * ld, tid, feed);
-    } else if (tid < BM && row0 + tid < M) {
+    if (tid < BM && row0 + tid < M)
         for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
-    }
 
     // layer-0 input: [alpha occupations of pairs 0..P-2 | beta ...] as +-1 (no spin ordering for the
     // phase block, nade.py:531-537), zero-padded to K_pad[0]; rows past M are zero
@@ -628,11 +567,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     const int P = d.P, ldh = d.ldh;
 
     float la = 0.0f;
-    if (scratch == nullptr) {
-        la = amp_rows<BM>(d, w, keys, row0, M, reinterpret_cast<float *>(planes + 3 * BM * ldh), tid, feed);
-    } else if (tid < BM && row0 + tid < M) {
+    if (tid < BM && row0 + tid < M)
         for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
-    }
 
     // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero)
     const int K0 = d.Kh_pad[0];
@@ -832,15 +768,14 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         if (hipMalloc((void **)&net->d_w, (size_t)net->w_floats * sizeof(float)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMalloc((void **)&net->d_wh, (size_t)net->wh_elems * sizeof(unsigned short)) != hipSuccess) st = NAQS_ERR_NOMEM;
         // the activation tile of 48/64 rows x 516 floats exceeds the 64 KiB default of dynamic LDS
-        const int lds_amp16 = 16 * P * (int)sizeof(float);                  // in-kernel amplitude results per 16 rows
-        const int lds_max = 4 * (16 * d.ld * (int)sizeof(float) + lds_amp16);
+        const int lds_max = 4 * 16 * d.ld * (int)sizeof(float);
         if (lds_max > 160 * 1024) st = NAQS_ERR_UNSUPPORTED;
         if (st == NAQS_OK) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 2);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4 * 3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-            const int ldsh = 3 * 16 * d.ldh * (int)sizeof(unsigned short) + lds_amp16;      // per 16 rows
+            const int ldsh = 3 * 16 * d.ldh * (int)sizeof(unsigned short);      // per 16 rows
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsh);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ldsh);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
@@ -918,12 +853,7 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
         net->cap_M = cap;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // the amplitude conditionals run inside the phase kernel's workgroups (one launch for the whole network)
-    // unless NAQS_AMP_FUSED=0 asks for the separate amp_kernel
-    const bool amp_fused = naqs::env_int("NAQS_AMP_FUSED", 1) != 0;
-    const float *scratch_arg = amp_fused ? nullptr : net->d_scratch;
     const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-    if (!amp_fused)
     hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, net->d_w, M,
                        keys_dev, net->d_scratch, feed);
     HIP_TRY(hipGetLastError());
@@ -931,7 +861,7 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA
     const size_t lds_h16 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
-    const bool use_h = mode == 1 && 3 * (lds_h16 + 16 * d.P * sizeof(float)) <= 160 * 1024;
+    const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;
     const int rb_max = use_h ? 3 : 4;
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
     if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
@@ -941,19 +871,19 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
     if (use_h) {
-        const size_t lds = rb * lds_h16 + (size_t)bm * d.P * sizeof(float);
+        const size_t lds = rb * lds_h16;
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, scratch_arg, out, feed); break;
-            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, scratch_arg, out, feed); break;
-            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, scratch_arg, out, feed); break;
+            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
+            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
+            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
         }
     } else {
-        const size_t lds = (size_t)bm * d.ld * sizeof(float) + (size_t)bm * d.P * sizeof(float);
+        const size_t lds = (size_t)bm * d.ld * sizeof(float);
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, scratch_arg, out, feed); break;
-            case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, scratch_arg, out, feed); break;
-            case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, scratch_arg, out, feed); break;
-            default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, scratch_arg, out, feed); break;
+            case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
         }
     }
     HIP_TRY(hipGetLastError());
