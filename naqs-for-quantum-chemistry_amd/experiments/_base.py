@@ -101,6 +101,10 @@ def _samp_str(n):
             else f"{int(n / 1e9)}B")
 
 
+def _mol_name(path):
+    return os.path.splitext(os.path.split(os.path.normpath(path))[-1])[0]
+
+
 def _setup_distributed(farm):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -235,10 +239,10 @@ def run_from_parser(parser, argv=None):
         molecule_fname = mols[rank]
     exp_name = args.out
     if exp_name is None:
-        exp_name = os.path.join(_EXP_BASE_NAME, os.path.split(os.path.normpath(molecule_fname))[-1])
+        exp_name = os.path.join(_EXP_BASE_NAME, _mol_name(molecule_fname))
         exp_name += f"_{_samp_str(args.n_samps)}_samps"
     elif args.farm:
-        exp_name = os.path.join(exp_name, os.path.split(os.path.normpath(molecule_fname))[-1])
+        exp_name = os.path.join(exp_name, _mol_name(molecule_fname))
     for on, suffix in ((args.no_amp_sym, "_noAmpSym"), (args.phase_sym, "_phaseSym"), (args.no_restrictedH, "_no_restrictedH"),
                        (args.no_mask_psi, "_no_mask_psi"), (args.full_mask_psi, "_full_mask_psi")):
         if on:

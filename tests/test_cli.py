@@ -96,3 +96,25 @@ def test_cli_rejects_out_of_scope_options(tmp_path, monkeypatch):
         _base.run(argv=["-m", LIH_DIR, "-o", str(tmp_path), "-n_lut", "2"])
     with pytest.raises(Exception):
         _base.run(argv=["-m", LIH_DIR, "-o", str(tmp_path), "-no_mask_psi", "-full_mask_psi"])
+
+
+def test_farm_mode_gives_each_rank_its_own_molecule(tmp_path, monkeypatch, capsys):
+    """Config 5 (N2 bond-dissociation sweep): `--farm -m a,b,...` = one independent run per rank, no
+    communication (the reference pins one run per GPU from a shell loop, N2_energy_surface.sh:5-8)."""
+    sys.path.insert(0, PKG)
+    import oracle_backend
+    from experiments import _base
+    oracle_backend.install(monkeypatch)
+    mols = ",".join(os.path.join(GOLDEN, f"ham_{m}.npz") for m in ("LiH", "H2O"))
+    common = ["--farm", "-m", mols, "-o", str(tmp_path), "-single_phase", "-n_hid", "8", "-n_hid_phase", "8",
+              "-n_samps", "20000", "-n_unq_samps_min", "10", "-n_train", "4", "-lr", "0.001", "-s", "3"]
+    fci = {0: -7.784460280267, 1: -75.015530189592}
+    for rank in (0, 1):
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("RANK", str(rank))
+        res = _base.run(argv=common)
+        assert abs(res[0]["fci"] - fci[rank]) < 1e-9          # the packed fixture carries the HDF5 scalars
+        assert os.path.exists(os.path.join(str(tmp_path), "ham_LiH" if rank == 0 else "ham_H2O", "summary.txt"))
+    monkeypatch.setenv("RANK", "2")                            # more ranks than molecules: nothing to do
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    assert _base.run(argv=common) == []
