@@ -91,8 +91,19 @@ __device__ __forceinline__ int hash_find(const Slot<KT> *__restrict__ tab, int b
 }
 
 
+// Optional Bloom filter over the sample keys (one hash function, 2^19 bits = 64 KiB): the E_loc kernel keeps
+// a copy in LDS and only sends candidates whose bit is set to the hash table in L2.  Pays off when most
+// physical candidates are NOT in the sample set (large Hilbert spaces: Li2O, M = 5*10^4 of 4*10^7 states).
+constexpr int BLOOM_LOG2_BITS = 19;
+constexpr int BLOOM_WORDS = 1 << (BLOOM_LOG2_BITS - 5);
+__device__ __forceinline__ uint32_t bloom_bit(uint32_t k) { return (k * 0x85EBCA6Bu) >> (32 - BLOOM_LOG2_BITS); }
+__device__ __forceinline__ uint32_t bloom_bit(uint64_t k) {
+    return (uint32_t)((k * 0xC2B2AE3D27D4EB4Full) >> (64 - BLOOM_LOG2_BITS));
+}
+
 // what a producer kernel outside naqs_hip.hip needs to fill the E_loc scratch of a handle for one call
 struct ElocFeed {
+    uint32_t *bloom;      // BLOOM_WORDS words, zeroed for this call, or nullptr
     void *tab;            // Slot<uint32_t>* or Slot<uint64_t>*
     void *keys_narrow;    // uint32_t* or uint64_t* [M]
     double2 *psi;         // [M] (Re, Im) f64
@@ -105,6 +116,10 @@ template <typename KT>
 __device__ __forceinline__ void feed_key(const ElocFeed &f, int64_t i, uint64_t key) {
     reinterpret_cast<KT *>(f.keys_narrow)[i] = (KT)key;
     hash_insert(reinterpret_cast<Slot<KT> *>(f.tab), f.bits, f.tag, (KT)key, (uint32_t)i);
+    if (f.bloom != nullptr) {
+        const uint32_t b = bloom_bit((KT)key);
+        atomicOr(&f.bloom[b >> 5], 1u << (b & 31));
+    }
 }
 __device__ __forceinline__ void feed_psi(const ElocFeed &f, int64_t i, float log_amp, float phase) {
     const double amp = exp((double)log_amp);

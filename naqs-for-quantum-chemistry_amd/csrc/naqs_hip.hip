@@ -53,6 +53,7 @@ constexpr int BLOCK = 256;                 // helper kernels: 4 waves, one per S
 constexpr int LIGHT_BATCH = NAQS_LIGHT_BATCH;             // 64-group chunks probed together (all loads in flight before any is used)
 constexpr int QUEUE_CAP = 64 * (LIGHT_BATCH + 1);   // per-wave hit queue: < 64 carried + LIGHT_BATCH x 64 pushed per batch
 constexpr int LDS_BUDGET = 78 * 1024;      // per-workgroup dynamic LDS budget (160 KiB/CU -> 2 WGs/CU)
+constexpr int LDS_BUDGET_BLOOM = 152 * 1024;   // Bloom variant: one workgroup per CU
 constexpr int HEAVY_TERMS = 8;             // groups with more terms than this are "heavy"
 
 using namespace naqs;   // Slot, hash_insert, probe_load, probe_resolve, hash_find, popc (naqs_hash.hpp)
@@ -62,11 +63,16 @@ template <typename KT>
 __global__ __launch_bounds__(PREP_BLOCK) void prep_kernel(int64_t M, const uint64_t *__restrict__ keys,
                                                      const void *__restrict__ psi_in, int psi_kind,
                                                      KT *__restrict__ keys_out, double2 *__restrict__ psi_out,
-                                                     Slot<KT> *__restrict__ tab, int bits, uint32_t tag) {
+                                                     Slot<KT> *__restrict__ tab, int bits, uint32_t tag,
+                                                     uint32_t *__restrict__ bloom) {
     for (int64_t i = blockIdx.x * (int64_t)PREP_BLOCK + threadIdx.x; i < M; i += (int64_t)gridDim.x * PREP_BLOCK) {
         const KT k = (KT)keys[i];
         keys_out[i] = k;
         hash_insert(tab, bits, tag, k, (uint32_t)i);
+        if (bloom != nullptr) {
+            const uint32_t b = bloom_bit(k);
+            atomicOr(&bloom[b >> 5], 1u << (b & 31));
+        }
         double a, b;
         if (psi_kind == NAQS_PSI_F32 || psi_kind == NAQS_LOGPSI_F32) {
             const float2 v = reinterpret_cast<const float2 *>(psi_in)[i];
@@ -106,6 +112,7 @@ struct ElocParams {
     const Slot<KT> *tab;
     int32_t bits;
     uint32_t tag;            // epoch << 24 of this call's hash table entries
+    const uint32_t *bloom;   // BLOOM variant: the call's Bloom filter (global copy, staged into LDS)
     // rows to produce
     int64_t row_begin, n_rows;
     int32_t rows_per_block;
@@ -166,7 +173,7 @@ __device__ __forceinline__ double sign_sum_strided(KT key, const KT *__restrict_
     return h;
 }
 
-template <typename KT, int STAGE, int NT>
+template <typename KT, int STAGE, int NT, bool BLOOM>
 __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
     constexpr int NWAVES = NT / WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -176,9 +183,18 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
     int32_t *s_rp = reinterpret_cast<int32_t *>(s_queue + NWAVES * QUEUE_CAP);
     KT *s_xy = reinterpret_cast<KT *>(s_rp + (STAGE >= 1 ? (p.Kxy + 2) & ~1 : 0));
     KT *s_yz = s_xy + (STAGE >= 1 ? p.Kxy : 0);
+    // BLOOM: 64 KiB filter after everything else (offset rounded up to 16 bytes)
+    uint32_t *s_bloom = reinterpret_cast<uint32_t *>(
+        smem + ((reinterpret_cast<unsigned char *>(s_yz + (STAGE >= 2 ? p.K : 0)) - smem + 15) & ~15ull));
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
 
+    if (BLOOM) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.bloom);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_bloom);
+#pragma unroll 4
+        for (int e = tid; e < BLOOM_WORDS / 4; e += NT) dst[e] = src[e];
+    }
     if (STAGE >= 1) {
 #pragma unroll 4
         for (int g = tid; g < p.Kxy; g += NT) s_xy[g] = p.xy_g[g];
@@ -205,8 +221,15 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
     const Slot<KT> *__restrict__ tab = p.tab;
     const double2 *__restrict__ psi = p.psi;
 
+    // candidate worth a look-up in the L2-resident hash table: particle numbers conserved and (BLOOM) the
+    // LDS-resident Bloom filter does not rule it out
     auto physical = [&](KT j) {
-        return !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
+        bool ok = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
+        if (BLOOM && ok) {
+            const uint32_t b = bloom_bit(j);
+            ok = (s_bloom[b >> 5] >> (b & 31)) & 1u;
+        }
+        return ok;
     };
 
     // Rows of the workgroup are dealt to its waves round-robin.  (A dynamic deal through an LDS
@@ -402,6 +425,7 @@ struct naqs_ham {
     void *d_tab = nullptr;
     int64_t tab_slots = 0;
     uint32_t epoch = 0;                      // of the hash table entries (1..255; 0 = freshly zeroed)
+    uint32_t *d_bloom = nullptr;             // Bloom filter of the current call's keys (large batches only)
     int cu_count = 256;
     naqs::EventRing prof;
 };
@@ -462,6 +486,15 @@ int eloc_begin_impl(naqs_ham *h, int64_t M, hipStream_t s, naqs::ElocFeed *feed)
         HIP_TRY(hipMemsetAsync(h->d_tab, 0, (size_t)h->tab_slots * slot, s));
         h->epoch = 1;
     }
+    // Bloom filter for large batches in large spaces (most candidates absent): NAQS_BLOOM=1/0 forces it on/off
+    const int bloom_env = env_int("NAQS_BLOOM", -1);
+    const bool use_bloom = bloom_env >= 0 ? bloom_env != 0 : (M >= 20000);
+    feed->bloom = nullptr;
+    if (use_bloom) {
+        if (!h->d_bloom) HIP_TRY(hipMalloc((void **)&h->d_bloom, BLOOM_WORDS * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(h->d_bloom, 0, BLOOM_WORDS * sizeof(uint32_t), s));
+        feed->bloom = h->d_bloom;
+    }
     feed->tab = h->d_tab;
     feed->keys_narrow = h->d_keys;
     feed->psi = h->d_psi;
@@ -476,7 +509,7 @@ int launch_prep(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
                 const naqs::ElocFeed &f, hipStream_t s) {
     const int grid = (int)std::min<int64_t>((M + PREP_BLOCK - 1) / PREP_BLOCK, 16 * h->cu_count);
     hipLaunchKernelGGL(prep_kernel<KT>, dim3(grid), dim3(PREP_BLOCK), 0, s, M, keys_dev, psi_dev, psi_kind,
-                       reinterpret_cast<KT *>(h->d_keys), h->d_psi, reinterpret_cast<Slot<KT> *>(f.tab), f.bits, f.tag);
+                       reinterpret_cast<KT *>(h->d_keys), h->d_psi, reinterpret_cast<Slot<KT> *>(f.tab), f.bits, f.tag, f.bloom);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -515,30 +548,42 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
         rpb = (int)std::max<int64_t>(nwaves, (n_rows + target_blocks - 1) / target_blocks);
     }
     p.rows_per_block = rpb;
-    const int grid = (int)((n_rows + rpb - 1) / rpb);
 
+    // Bloom variant (filter built by the feed stage for this call): 1024-thread workgroups, one per CU
+    const bool bloom = f.bloom != nullptr && nt == 1024;
+    p.bloom = bloom ? f.bloom : nullptr;
+    const size_t b_bytes = bloom ? (size_t)BLOOM_WORDS * sizeof(uint32_t) + 16 : 0;
+    const size_t budget = bloom ? (size_t)LDS_BUDGET_BLOOM : (size_t)LDS_BUDGET;
+    if (bloom) {      // one workgroup per CU: give it more rows
+        const int64_t target_blocks = (int64_t)h->cu_count;
+        if (env_int("NAQS_ROWS_PER_BLOCK", 0) <= 0)
+            rpb = (int)std::max<int64_t>(nwaves, (n_rows + target_blocks - 1) / target_blocks);
+        p.rows_per_block = rpb;
+    }
+    const int grid2 = (int)((n_rows + rpb - 1) / rpb);
     const size_t q_bytes = (size_t)nwaves * QUEUE_CAP * sizeof(int2) + 16;
     const size_t g_bytes = (size_t)((h->Kxy + 2) & ~1ll) * sizeof(int32_t) + (size_t)h->Kxy * sizeof(KT);
     const size_t t_bytes = (size_t)h->K * (sizeof(double) + sizeof(KT));
     const int force = env_int("NAQS_STAGE", -1);   // tuning/testing: 0 none, 1 groups, 2 groups+terms
-    int stage = (q_bytes + g_bytes + t_bytes <= (size_t)LDS_BUDGET) ? 2 : (q_bytes + g_bytes <= (size_t)LDS_BUDGET ? 1 : 0);
+    int stage = (q_bytes + g_bytes + t_bytes + b_bytes <= budget) ? 2 : (q_bytes + g_bytes + b_bytes <= budget ? 1 : 0);
     if (force >= 0 && force < stage) stage = force;
-    const size_t lds = q_bytes + (stage >= 1 ? g_bytes : 0) + (stage >= 2 ? t_bytes : 0);
+    const size_t lds = q_bytes + (stage >= 1 ? g_bytes : 0) + (stage >= 2 ? t_bytes : 0) + b_bytes;
 
     const bool prof = h->prof.armed();
     if (prof) { int st = h->prof.begin(s); if (st != NAQS_OK) return st; }
-#define NAQS_LAUNCH(ST, NTHREADS)                                                                                   \
+#define NAQS_LAUNCH(ST, NTHREADS, BL)                                                                               \
     do {                                                                                                            \
         if (lds > 64 * 1024)  /* above the default dynamic-LDS limit */                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_kernel<KT, ST, NTHREADS>),               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);                       \
-        hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS>), dim3(grid), dim3(NTHREADS), lds, s, p);                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_kernel<KT, ST, NTHREADS, BL>),           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);                      \
+        hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS, BL>), dim3(grid2), dim3(NTHREADS), lds, s, p);            \
     } while (0)
-#define NAQS_LAUNCH_NT(ST)                                   \
-    do {                                                     \
-        if (nt == 1024) NAQS_LAUNCH(ST, 1024);               \
-        else if (nt == 512) NAQS_LAUNCH(ST, 512);            \
-        else NAQS_LAUNCH(ST, 256);                           \
+#define NAQS_LAUNCH_NT(ST)                                          \
+    do {                                                            \
+        if (bloom) NAQS_LAUNCH(ST, 1024, true);                     \
+        else if (nt == 1024) NAQS_LAUNCH(ST, 1024, false);          \
+        else if (nt == 512) NAQS_LAUNCH(ST, 512, false);            \
+        else NAQS_LAUNCH(ST, 256, false);                           \
     } while (0)
     if (stage == 2) NAQS_LAUNCH_NT(2);
     else if (stage == 1) NAQS_LAUNCH_NT(1);
@@ -684,7 +729,7 @@ NAQS_API int naqs_ham_destroy(naqs_ham_t *h) {
     DeviceGuard guard;
     (void)guard.init(h->device);
     (void)h->prof.enable(0);
-    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_col, h->d_c, h->d_keys, h->d_psi, h->d_tab};
+    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_col, h->d_c, h->d_keys, h->d_psi, h->d_tab, h->d_bloom};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return NAQS_OK;

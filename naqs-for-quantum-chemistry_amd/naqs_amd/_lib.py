@@ -91,6 +91,8 @@ def load_library():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
+            if os.environ.get("NAQS_LOADER_LAX") == "1":      # A/B runs against older builds (tools/ only)
+                continue
             raise NaqsError(f"{path} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
     if lib.naqs_abi_version() != 1:

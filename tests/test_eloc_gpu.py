@@ -370,3 +370,35 @@ def test_fused_reduction_and_epoch_wrap(env):
     # row shard + weights of the shard
     e2, s2 = ham.local_energy(ka, wa, row_begin=500, n_rows=700, weights=w[500:1200])
     assert torch.max(torch.abs(s2 - ham.reduce(w[500:1200], e2)) / s2.abs().clamp(min=1)).item() < 1e-12
+
+
+def test_bloom_filter_variant_is_bit_identical(env):
+    """Large batches take the LDS Bloom-filter variant of eloc_kernel (NAQS_BLOOM forces it on/off): it may
+    only skip look-ups that would miss, so E_loc must not change by a single bit."""
+    ham = dev_ham(env, "Li2O")
+    z = golden("eloc_Li2O_subset.npz")
+    keys = random_physical_keys(30, 7, 7, 24000, 5)
+    keys = np.unique(np.r_[keys, z["keys"]])                      # a connected cluster inside a random cloud
+    lp = synth_logpsi(len(keys), 6, sigma=1.0)
+    psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    wf = np.stack([psi.real, psi.imag], -1)
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["NAQS_BLOOM"] = flag
+        try:
+            res[flag] = run_eloc(env, ham, keys, wf, dtype=torch.float64)
+        finally:
+            del os.environ["NAQS_BLOOM"]
+    assert np.array_equal(res["0"], res["1"])
+    auto = run_eloc(env, ham, keys, wf, dtype=torch.float64)      # M >= 20000 -> Bloom variant by default
+    assert np.array_equal(auto, res["0"])
+    assert np.count_nonzero(np.abs(res["0"].imag) > 1e-12) > 500  # the cluster really couples
+    # small molecule with the filter forced on (all tables + filter in LDS)
+    z2 = golden("eloc_N2.npz")
+    ham2 = dev_ham(env, "N2")
+    os.environ["NAQS_BLOOM"] = "1"
+    try:
+        e = run_eloc(env, ham2, z2["c2_keys"], z2["c2_psi_f32"])
+    finally:
+        del os.environ["NAQS_BLOOM"]
+    assert rel_err(e, z2["c2_eloc_c128"]) < 1e-10
