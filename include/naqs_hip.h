@@ -201,6 +201,30 @@ int naqs_net_prof_enable(naqs_net_t *net, int max_records);
 int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches);
 int naqs_net_prof_stride(naqs_net_t *net, int stride);
 
+
+/* ================================================================================================
+ * Autoregressive tree sampler on the device.
+ * Replaces wavefunction.sample(n) (src/naqs/wavefunction.py:488-521) -> _forward_sample
+ * (src/naqs/network/nade.py:632-736) with multinomial_arr (:20-37): n_samples draws from |psi|^2 as the unique
+ * bit-strings with their multiplicities.  Children that violate the electron budget are dropped after the draw
+ * exactly like the reference (:695), so sum(counts) <= n_samples.  Outputs are in (prefix, outcome) order, which is
+ * ascending key order for qubit_ordering = -1 (the reference's order).
+ *   keys_dev [max_unique] uint64 (qubit order), counts_dev [max_unique] int64, probs_dev [max_unique] float32 or
+ *   NULL (product of the float32 conditional probabilities, = the reference's `probs`),
+ *   info_dev [2] int64: {number of unique samples M, overflow flag}.  overflow = 1 (and M = 0) when more than
+ *   max_unique prefixes were alive at some level — the reference's MaxBatchSizeExceededError (:710-712).
+ * Draws are a pure function of (weights, n_samples, seed): Philox4x32-10 keyed by the seed and indexed by the
+ * prefix, exact binomials (inversion / BTRS).  Parity with the reference is statistical (numpy's generator is not
+ * reproduced).  n_samples <= 2^44 (the float64 acceptance test of the binomial generator loses its margin beyond; the
+ * reference caps n_samples at 1e12).
+ * ============================================================================================== */
+int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                    int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream);
+/* Host evaluation of the sampler's generators, for known-answer and statistical tests (no device needed):
+ * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */
+int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out);
+int naqs_rng_philox_host(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@
 
 #include "naqs_common.hpp"
 #include "naqs_hash.hpp"
+#include "naqs_net.hpp"
 
 namespace {
 
@@ -38,32 +39,12 @@ using naqs::WAVE;
 using naqs::DeviceGuard;
 using naqs::ElocFeed;
 
-constexpr int MAXP = NAQS_NET_MAX_PAIRS;
-constexpr int MAXL = NAQS_NET_MAX_PHASE_LAYERS + 1;   // linear layers of the phase block
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct NetDims {
-    int32_t P;                         // orbital pairs
-    int32_t n_alpha, n_beta;           // < 0: unrestricted
-    int32_t n_alpha_down, n_beta_down;
-    int32_t min_n_set;
-    int32_t masking;                   // 0 NONE, 1 PARTIAL, 2 FULL
-    int32_t sym;                       // amplitude spin symmetry
-    int32_t Ha;                        // amplitude hidden width
-    int32_t n_out_amp;                 // 5 with symmetry, 4 without
-    uint8_t qa[MAXP], qb[MAXP];        // qubit (bit) index of the alpha / beta orbital of model pair n
-    int32_t amp_off[MAXP];             // offset (floats) of pair n's packed parameters: Ha rows of
-                                       //   [W1[j][0..nin) | b1[j] | W2[0..5)[j] | pad] (16-byte multiples), then b2 [8]
-    // phase MLP, zero-padded and tiled: layer l: W [N_pad/16][K_pad/16][64 lanes][4], bias [N_pad]
-    int32_t n_lin;
-    int32_t K_pad[MAXL], N_pad[MAXL], w_off[MAXL], b_off[MAXL];
-    int32_t ld;                        // LDS row stride (floats)
-    // the same MLP split in 3 bf16 planes for the bf16 matrix cores (phase_kernel_bf16x3):
-    // layer l: planes [3][N_pad/16][Kh_pad/32][64 lanes][8 bf16] at wh_off (in bf16 units), bias (f32) at b_off
-    int32_t Kh_pad[MAXL], wh_off[MAXL];
-    int32_t ldh;                       // LDS row stride of one activation plane (bf16 units)
-};
+using naqs::MAXP;
+using naqs::MAXL;
+using naqs::f32x4;
+using naqs::NetDims;
+using naqs::amp_partial;
+using naqs::amp_finish;
 
 // ------------------------------------------------------------------------------------------------
 // amplitude conditionals
@@ -76,76 +57,6 @@ struct NetDims {
 #endif
 constexpr int AMP_TILES = NAQS_AMP_TILES;   // 64-sample tiles per workgroup sharing one staged weight set
 constexpr int AMP_SPLIT = NAQS_AMP_SPLIT;   // waves splitting the hidden units of one tile
-
-// partial output sums of pair NB over hidden units [j0, j1): o[c] += W2[c][j] * relu(W1[j].x + b1[j])
-template <int NB>
-__device__ __forceinline__ void amp_partial(const NetDims &d, const float *__restrict__ w, uint32_t first,
-                                            uint32_t second, int j0, int j1, float (&o)[5]) {
-    constexpr int NIN = NB == 0 ? 1 : 2 * NB;
-    float x[NIN];
-    if (NB == 0) {
-        x[0] = 0.0f;
-    } else {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            x[k] = ((first >> k) & 1u) ? 1.0f : -1.0f;
-            x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
-        }
-    }
-    const int nout = d.n_out_amp;
-    constexpr int S = (NIN + 1 + 5 + 3) & ~3;          // packed row: W1[j][:], b1[j], W2[:][j], padded to 16 bytes
-    const float *rows = w;                             // this pair's rows, staged in LDS by the workgroup
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-        const float *row = rows + j * S;               // same address in every lane -> LDS broadcast reads
-        // two interleaved accumulation chains keep the FMA pipe busier than one 2n-long dependent chain
-        float h0 = row[NIN], h1 = 0.0f;
-#pragma unroll
-        for (int k = 0; k + 1 < NIN; k += 2) { h0 = fmaf(row[k], x[k], h0); h1 = fmaf(row[k + 1], x[k + 1], h1); }
-        if (NIN & 1) h0 = fmaf(row[NIN - 1], x[NIN - 1], h0);
-        const float h = fmaxf(h0 + h1, 0.0f);
-#pragma unroll
-        for (int c = 0; c < 5; ++c)
-            if (c < nout) o[c] = fmaf(row[NIN + 1 + c], h, o[c]);
-    }
-}
-
-// symmetrise, mask, 0.5*log_softmax(2x), select the realised outcome
-__device__ __forceinline__ float amp_finish(const NetDims &d, int NB, const float (&o)[5], uint32_t abits,
-                                            uint32_t bbits, int occ) {
-    const int x_order = !d.sym ? 2 : (abits > bbits ? 0 : (abits == bbits ? 1 : 2));
-    // symmetrise 5 -> 4 (nade.py:585-586): (o[0,1,1,2] + o[idx2sort[x_order]]) / 2
-    float a4[4];
-    if (d.sym) {
-        const float s1 = x_order == 0 ? o[3] : (x_order == 1 ? o[1] : o[4]);
-        const float s2 = x_order == 0 ? o[4] : (x_order == 1 ? o[1] : o[3]);
-        a4[0] = (o[0] + o[0]) * 0.5f;
-        a4[1] = (o[1] + s1) * 0.5f;
-        a4[2] = (o[1] + s2) * 0.5f;
-        a4[3] = (o[2] + o[2]) * 0.5f;
-    } else {
-        a4[0] = o[0]; a4[1] = o[1]; a4[2] = o[2]; a4[3] = o[3];
-    }
-    // electron-budget mask (nade.py:426-474), skipped on the last pair under PARTIAL (:615-617)
-    bool ok[4] = {true, true, true, true};
-    const bool mask_active = !(d.masking == 0 || (d.masking == 1 && NB == d.P - 1));
-    if (mask_active && d.n_alpha >= 0 && NB >= max(d.min_n_set, 1)) {
-        const int ua = __popc(abits), ub = __popc(bbits);
-        const bool a_up = ua < d.n_alpha, a_dn = (NB - ua) < d.n_alpha_down;
-        const bool b_up = ub < d.n_beta, b_dn = (NB - ub) < d.n_beta_down;
-        ok[0] = a_dn && b_dn; ok[1] = a_up && b_dn; ok[2] = a_dn && b_up; ok[3] = a_up && b_up;
-    }
-    // 0.5 * log_softmax(2 a) over the allowed outcomes (activations.py:40-46)
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { a4[c] *= 2.0f; if (ok[c]) m = fmaxf(m, a4[c]); }
-    float s = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) if (ok[c]) s += expf(a4[c] - m);
-    const float sel = occ == 0 ? a4[0] : (occ == 1 ? a4[1] : (occ == 2 ? a4[2] : a4[3]));
-    const bool sel_ok = occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3]));
-    return sel_ok ? 0.5f * ((sel - m) - logf(s)) : -INFINITY;
-}
 
 // workgroup = AMP_TILES x AMP_SPLIT waves for one orbital pair n (blockIdx.y): the pair's packed weights are
 // staged once, wave (t, q) runs hidden-unit slice q for the 64 samples of tile t, the AMP_SPLIT partial
@@ -657,26 +568,6 @@ __global__ __launch_bounds__(256) void pack_phase_kernel(const float *__restrict
 
 }  // namespace
 
-struct naqs_net {
-    int device = 0;
-    naqs_net_config_t cfg{};
-    NetDims dims{};
-    int64_t n_params = 0;
-    int64_t amp_params = 0;                 // floats of all amplitude blocks in the flat source
-    int64_t amp_src_off[MAXP] = {};         // per pair: offset in the flat source
-    std::vector<int64_t> phase_src_off;     // per phase linear layer: offset in the flat source
-    std::vector<int> phase_K, phase_N;
-    float *d_w = nullptr;                   // [amp params | packed phase layers]
-    unsigned short *d_wh = nullptr;         // phase layers as 3 bf16 planes (phase_kernel_bf16x3)
-    int64_t wh_elems = 0;
-    int64_t w_floats = 0;
-    float *d_scratch = nullptr;             // [P][cap_M] log-amplitude contributions
-    int64_t cap_M = 0;
-    int cu_count = 256;
-    bool have_weights = false;
-    naqs::EventRing prof;
-};
-
 NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_t **out) {
     if (!cfg || !out) return NAQS_ERR_INVALID;
     *out = nullptr;
@@ -794,6 +685,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_w) (void)hipFree(net->d_w);
     if (net->d_wh) (void)hipFree(net->d_wh);
     if (net->d_scratch) (void)hipFree(net->d_scratch);
+    if (net->d_samp) (void)hipFree(net->d_samp);
     delete net;
     return NAQS_OK;
 }

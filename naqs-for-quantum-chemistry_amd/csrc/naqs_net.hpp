@@ -1,0 +1,152 @@
+// naqs_net.hpp — the network handle and the device pieces of the amplitude conditionals shared by the
+// translation units that evaluate (naqs_logpsi.hip), sample (naqs_sample.hip) and differentiate
+// (naqs_grad.hip) the orbital NADE.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "naqs_common.hpp"
+
+namespace naqs {
+
+constexpr int MAXP = NAQS_NET_MAX_PAIRS;
+constexpr int MAXL = NAQS_NET_MAX_PHASE_LAYERS + 1;   // linear layers of the phase block
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NetDims {
+    int32_t P;                         // orbital pairs
+    int32_t n_alpha, n_beta;           // < 0: unrestricted
+    int32_t n_alpha_down, n_beta_down;
+    int32_t min_n_set;
+    int32_t masking;                   // 0 NONE, 1 PARTIAL, 2 FULL
+    int32_t sym;                       // amplitude spin symmetry
+    int32_t Ha;                        // amplitude hidden width
+    int32_t n_out_amp;                 // 5 with symmetry, 4 without
+    uint8_t qa[MAXP], qb[MAXP];        // qubit (bit) index of the alpha / beta orbital of model pair n
+    int32_t amp_off[MAXP];             // offset (floats) of pair n's packed parameters: Ha rows of
+                                       //   [W1[j][0..nin) | b1[j] | W2[0..5)[j] | pad] (16-byte multiples), then b2 [8]
+    // phase MLP, zero-padded and tiled: layer l: W [N_pad/16][K_pad/16][64 lanes][4], bias [N_pad]
+    int32_t n_lin;
+    int32_t K_pad[MAXL], N_pad[MAXL], w_off[MAXL], b_off[MAXL];
+    int32_t ld;                        // LDS row stride (floats)
+    // the same MLP split in 3 bf16 planes for the bf16 matrix cores (phase_kernel_bf16x3):
+    // layer l: planes [3][N_pad/16][Kh_pad/32][64 lanes][8 bf16] at wh_off (in bf16 units), bias (f32) at b_off
+    int32_t Kh_pad[MAXL], wh_off[MAXL];
+    int32_t ldh;                       // LDS row stride of one activation plane (bf16 units)
+};
+
+// partial output sums of pair NB over hidden units [j0, j1): o[c] += W2[c][j] * relu(W1[j].x + b1[j])
+template <int NB>
+__device__ __forceinline__ void amp_partial(const NetDims &d, const float *__restrict__ w, uint32_t first,
+                                            uint32_t second, int j0, int j1, float (&o)[5]) {
+    constexpr int NIN = NB == 0 ? 1 : 2 * NB;
+    float x[NIN];
+    if (NB == 0) {
+        x[0] = 0.0f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            x[k] = ((first >> k) & 1u) ? 1.0f : -1.0f;
+            x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
+        }
+    }
+    const int nout = d.n_out_amp;
+    constexpr int S = (NIN + 1 + 5 + 3) & ~3;          // packed row: W1[j][:], b1[j], W2[:][j], padded to 16 bytes
+    const float *rows = w;                             // this pair's rows, staged in LDS by the workgroup
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const float *row = rows + j * S;               // same address in every lane -> LDS broadcast reads
+        // two interleaved accumulation chains keep the FMA pipe busier than one 2n-long dependent chain
+        float h0 = row[NIN], h1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k + 1 < NIN; k += 2) { h0 = fmaf(row[k], x[k], h0); h1 = fmaf(row[k + 1], x[k + 1], h1); }
+        if (NIN & 1) h0 = fmaf(row[NIN - 1], x[NIN - 1], h0);
+        const float h = fmaxf(h0 + h1, 0.0f);
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (c < nout) o[c] = fmaf(row[NIN + 1 + c], h, o[c]);
+    }
+}
+
+// electron-budget mask of pair NB given the prefix (nade.py:417-474): outcome (a, b) allowed iff the alpha / beta
+// strings can still take that value; all true when unrestricted or NB < max(min_n_set, 1), like the reference
+__device__ __forceinline__ void amp_budget_mask(const NetDims &d, int NB, uint32_t abits, uint32_t bbits, bool (&ok)[4]) {
+    ok[0] = ok[1] = ok[2] = ok[3] = true;
+    if (d.n_alpha >= 0 && NB >= max(d.min_n_set, 1)) {
+        const int ua = __popc(abits), ub = __popc(bbits);
+        const bool a_up = ua < d.n_alpha, a_dn = (NB - ua) < d.n_alpha_down;
+        const bool b_up = ub < d.n_beta, b_dn = (NB - ub) < d.n_beta_down;
+        ok[0] = a_dn && b_dn; ok[1] = a_up && b_dn; ok[2] = a_dn && b_up; ok[3] = a_up && b_up;
+    }
+}
+
+// symmetrise the 5 raw outputs to the 4 outcome logits (nade.py:585-586): (o[0,1,1,2] + o[idx2sort[x_order]]) / 2
+__device__ __forceinline__ void amp_symmetrise(const NetDims &d, const float (&o)[5], uint32_t abits, uint32_t bbits,
+                                               float (&a4)[4]) {
+    if (d.sym) {
+        const int x_order = abits > bbits ? 0 : (abits == bbits ? 1 : 2);
+        const float s1 = x_order == 0 ? o[3] : (x_order == 1 ? o[1] : o[4]);
+        const float s2 = x_order == 0 ? o[4] : (x_order == 1 ? o[1] : o[3]);
+        a4[0] = (o[0] + o[0]) * 0.5f;
+        a4[1] = (o[1] + s1) * 0.5f;
+        a4[2] = (o[1] + s2) * 0.5f;
+        a4[3] = (o[2] + o[2]) * 0.5f;
+    } else {
+        a4[0] = o[0]; a4[1] = o[1]; a4[2] = o[2]; a4[3] = o[3];
+    }
+}
+
+// the conditional of pair NB: la[c] = 0.5 * log_softmax(2 a)[c] over the allowed outcomes (activations.py:40-46),
+// -inf where masked; the mask is skipped on the last pair under PARTIAL masking (nade.py:615-617)
+__device__ __forceinline__ void amp_conditional(const NetDims &d, int NB, const float (&o)[5], uint32_t abits,
+                                                uint32_t bbits, float (&la)[4], bool (&ok)[4]) {
+    float a4[4];
+    amp_symmetrise(d, o, abits, bbits, a4);
+    const bool mask_active = !(d.masking == 0 || (d.masking == 1 && NB == d.P - 1));
+    if (mask_active) amp_budget_mask(d, NB, abits, bbits, ok);
+    else ok[0] = ok[1] = ok[2] = ok[3] = true;
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { a4[c] *= 2.0f; if (ok[c]) m = fmaxf(m, a4[c]); }
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (ok[c]) s += expf(a4[c] - m);
+    const float ls = logf(s);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) la[c] = ok[c] ? 0.5f * ((a4[c] - m) - ls) : -INFINITY;
+}
+
+// log-amplitude of the realised outcome
+__device__ __forceinline__ float amp_finish(const NetDims &d, int NB, const float (&o)[5], uint32_t abits,
+                                            uint32_t bbits, int occ) {
+    float la[4];
+    bool ok[4];
+    amp_conditional(d, NB, o, abits, bbits, la, ok);
+    return occ == 0 ? la[0] : (occ == 1 ? la[1] : (occ == 2 ? la[2] : la[3]));
+}
+
+}  // namespace naqs
+
+struct naqs_net {
+    int device = 0;
+    naqs_net_config_t cfg{};
+    naqs::NetDims dims{};
+    int64_t n_params = 0;
+    int64_t amp_params = 0;                 // floats of all amplitude blocks in the flat source
+    int64_t amp_src_off[naqs::MAXP] = {};         // per pair: offset in the flat source
+    std::vector<int64_t> phase_src_off;     // per phase linear layer: offset in the flat source
+    std::vector<int> phase_K, phase_N;
+    float *d_w = nullptr;                   // [amp params | packed phase layers]
+    unsigned short *d_wh = nullptr;         // phase layers as 3 bf16 planes (phase_kernel_bf16x3)
+    int64_t wh_elems = 0;
+    int64_t w_floats = 0;
+    float *d_scratch = nullptr;             // [P][cap_M] log-amplitude contributions
+    int64_t cap_M = 0;
+    void *d_samp = nullptr;                 // tree-sampler scratch (naqs_sample.hip), sized for samp_cap unique prefixes
+    int64_t samp_cap = 0;
+    int cu_count = 256;
+    bool have_weights = false;
+    naqs::EventRing prof;
+};
+

@@ -1,0 +1,135 @@
+// naqs_rng.hpp — counter-based random numbers and an exact binomial generator for the tree sampler.
+//
+// The reference draws the children counts of a prefix with numpy's binomial on the host
+// (src/naqs/network/nade.py:20-37, conditional-binomial chain).  Here every draw is a pure function of
+// (seed, prefix bits, block, outcome, attempt): Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, so a
+// sample is reproducible whatever the launch geometry, and the same code runs on the host for the statistical
+// tests (naqs_rng_*_host in the C ABI).  Binomial(n, p), n up to 2^44: sequential inversion when n*min(p,q) < 10,
+// otherwise Hörmann's transformed rejection with squeeze (BTRS, "The generation of binomial random variates",
+// J. Stat. Comput. Simul. 46 (1993)) — exact, ~1.15 uniform pairs per variate.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define NAQS_HD __host__ __device__ __forceinline__
+#else
+#define NAQS_HD inline
+#endif
+
+namespace naqs {
+
+NAQS_HD void mulhilo32(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+    const uint64_t p = (uint64_t)a * (uint64_t)b;
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
+}
+
+NAQS_HD void philox4x32_10(const uint32_t (&ctr)[4], uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo32(0xD2511F53u, c0, hi0, lo0);
+        mulhilo32(0xCD9E8D57u, c2, hi1, lo1);
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform on the open interval (0, 1) with 53 random bits
+NAQS_HD double u01(uint32_t hi, uint32_t lo) {
+    const uint64_t bits = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);      // 27 + 26 bits
+    return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// one stream of uniform pairs: counter = (c0, c1, c2, attempt)
+struct RngStream {
+    uint32_t k0, k1, c0, c1, c2, attempt;
+    NAQS_HD void pair(double &u, double &v) {
+        const uint32_t ctr[4] = {c0, c1, c2, attempt++};
+        uint32_t r[4];
+        philox4x32_10(ctr, k0, k1, r);
+        u = u01(r[0], r[1]);
+        v = u01(r[2], r[3]);
+    }
+};
+
+// log(k!) - [ (k + 1/2) log(k + 1) - (k + 1) + log(2 pi)/2 ]  (Stirling series remainder)
+NAQS_HD double stirling_tail(double k) {
+    if (k < 10.0) {
+        switch ((int)k) {
+            case 0: return 0.08106146679532726;
+            case 1: return 0.04134069595540929;
+            case 2: return 0.02767792568499834;
+            case 3: return 0.02079067210376509;
+            case 4: return 0.01664469118982119;
+            case 5: return 0.01387612882307075;
+            case 6: return 0.01189670994589177;
+            case 7: return 0.01041126526197209;
+            case 8: return 0.009255462182712733;
+            default: return 0.008330563433362871;
+        }
+    }
+    const double k1 = k + 1.0, s = k1 * k1;
+    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / s) / s) / k1;
+}
+
+// Binomial(n, p), 0 < p <= 1/2, n p < 10: invert the CDF upwards from 0
+NAQS_HD double binomial_inversion(double n, double p, RngStream &g) {
+    const double s = p / (1.0 - p);
+    double u, v;
+    g.pair(u, v);
+    double f = exp(n * log1p(-p));          // P(0) = q^n >= e^-15 here
+    double k = 0.0;
+    for (int it = 0; it < 400 && u > f && k < n; ++it) {
+        u -= f;
+        k += 1.0;
+        f *= s * (n - k + 1.0) / k;
+    }
+    return k;
+}
+
+// Binomial(n, p), 0 < p <= 1/2, n p >= 10 (BTRS)
+NAQS_HD double binomial_btrs(double n, double p, RngStream &g) {
+    const double q = 1.0 - p, spq = sqrt(n * p * q);
+    const double b = 1.15 + 2.53 * spq;
+    const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+    const double c = n * p + 0.5;
+    const double vr = 0.92 - 4.2 / b;
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double r = p / q;
+    const double m = floor((n + 1.0) * p);
+    const double h_m = (m + 0.5) * log((m + 1.0) / (r * (n - m + 1.0))) + stirling_tail(m) + stirling_tail(n - m);
+    for (int it = 0; it < 1000; ++it) {
+        double u, v;
+        g.pair(u, v);
+        u -= 0.5;
+        const double us = 0.5 - fabs(u);
+        const double k = floor((2.0 * a / us + b) * u + c);
+        if (us >= 0.07 && v <= vr) return k;                      // inside the squeeze: accept immediately
+        if (k < 0.0 || k > n) continue;
+        const double lv = log(v * alpha / (a / (us * us) + b));
+        const double ub = h_m + (n + 1.0) * log1p((k - m) / (n - k + 1.0)) +
+                          (k + 0.5) * log(r * (n - k + 1.0) / (k + 1.0)) - stirling_tail(k) - stirling_tail(n - k);
+        if (lv <= ub) return k;
+    }
+    return m;                                                     // unreachable in practice (acceptance ~0.87 per pair)
+}
+
+NAQS_HD int64_t binomial(int64_t n, double p, RngStream &g) {
+    if (n <= 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double pp = flip ? 1.0 - p : p;
+    const double nd = (double)n;
+    const double k = nd * pp < 10.0 ? binomial_inversion(nd, pp, g) : binomial_btrs(nd, pp, g);
+    int64_t ki = (int64_t)k;
+    ki = ki < 0 ? 0 : (ki > n ? n : ki);
+    return flip ? n - ki : ki;
+}
+
+}  // namespace naqs

@@ -1,0 +1,312 @@
+// naqs_sample.hip — the autoregressive tree sampler on gfx950 (MI355X).
+//
+// Semantics: ComplexAutoregressiveMachine1D_OrbitalNade._forward_sample (src/naqs/network/nade.py:632-736) with
+// multinomial_arr (:20-37) of the reference: n_samples draws are represented as a tree of unique prefixes with
+// counts.  Per orbital pair n every live prefix evaluates its conditional (amplitude block n -> symmetrise ->
+// electron-budget mask -> 0.5 log_softmax(2x)), p = exp(.)^2 in float32 renormalised in float64 (:673-683), splits
+// its count over the four outcomes with the conditional-binomial chain, drops un-physical children (:695) and
+// the survivors become the next level.  The reference does this with ~25 host-driven array operations and a
+// host binomial per level; here a level is two launches and nothing returns to the host until the end:
+//
+//   sample_expand_kernel   one thread per prefix: block-n MLP with the weights staged in LDS (the code path of
+//                          amp_kernel), conditional, binomial chain (naqs_rng.hpp: Philox-keyed by the prefix
+//                          itself, so the draw does not depend on where the prefix sits in the arrays), children
+//                          counts -> scratch, survivors per workgroup -> wg_total.
+//   sample_scatter_kernel  stream compaction in (prefix, outcome) order: workgroup offset = sum of the preceding
+//                          totals, in-workgroup exclusive scan, children written to the other half of the
+//                          ping-pong arrays.  With qubit_ordering = -1 this order IS ascending key order, which
+//                          is how the reference's samples come out.
+//
+// The level sizes live on the device (U[n]); grids are sized for the worst case min(4^n, cap) and surplus
+// workgroups exit at once.  More than max_unique live prefixes at any level sets the overflow flag (the
+// reference raises MaxBatchSizeExceededError, nade.py:710-712) and the remaining launches fall through.
+// Statistical, not bitwise, parity with the reference (its generator is numpy's): tests/test_sampler_gpu.py.
+
+#include <algorithm>
+#include <cstdint>
+
+#include "naqs_common.hpp"
+#include "naqs_net.hpp"
+#include "naqs_rng.hpp"
+
+namespace {
+
+using naqs::MAXP;
+using naqs::NetDims;
+using naqs::WAVE;
+using naqs::DeviceGuard;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SB = 256;                     // prefixes per workgroup
+constexpr int U_SLOTS = MAXP + 2;           // U[0..P] level sizes, U[MAXP + 1] overflow flag
+
+struct SampleBufs {
+    uint32_t *ab[2];                        // prefix occupations in model order: alpha string | beta string << 16
+    int64_t *cnt[2];
+    float *prob[2];
+    int64_t *child_cnt;                     // [cap][4]
+    float *child_prob;                      // [cap][4]
+    uint32_t *wg_total;                     // survivors per workgroup of the current level
+    int64_t *U;
+};
+
+__global__ void sample_init_kernel(SampleBufs b, int64_t n_samples) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < U_SLOTS; ++i) b.U[i] = 0;
+        b.U[0] = 1;
+        b.ab[0][0] = 0u;
+        b.cnt[0][0] = n_samples;
+        b.prob[0][0] = 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, const float *__restrict__ w, const int n,
+                                                           const SampleBufs b, const int cur, const uint32_t k0,
+                                                           const uint32_t k1) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    __shared__ uint32_t s_red[SB / WAVE];
+    const int64_t U = b.U[n];
+    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * SB >= U) return;          // workgroup-uniform
+    const int nin = n == 0 ? 1 : 2 * n;
+    const int S = (nin + 1 + 5 + 3) & ~3;
+    {
+        const int total = d.Ha * S + 8;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(w + d.amp_off[n]);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(s_w);
+        for (int e = threadIdx.x; e < total / 4; e += SB) dst[e] = src[e];
+    }
+    const int64_t u = (int64_t)blockIdx.x * SB + threadIdx.x;
+    const bool active = u < U;
+    const uint32_t ab = active ? b.ab[cur][u] : 0u;
+    const uint32_t abits = ab & 0xffffu, bbits = ab >> 16;
+    const bool swap = d.sym && abits > bbits;                                  // nade.py:519-530
+    const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
+    float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    switch (n) {
+#define CASE(NB) case NB: naqs::amp_partial<NB>(d, s_w, first, second, 0, d.Ha, o); break;
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
+        CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+#undef CASE
+        default: break;
+    }
+    uint32_t survivors = 0;
+    if (active) {
+        const float *b2 = s_w + d.Ha * S;
+        float t[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + o[c];
+        float la[4];
+        bool ok[4], phys[4];
+        naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
+        naqs::amp_budget_mask(d, n, abits, bbits, phys);
+        float p[4];
+        double cs[4], acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float e = ok[c] ? expf(la[c]) : 0.0f;
+            p[c] = e * e;                                                       // float32, nade.py:673
+            acc += (double)p[c];
+            cs[c] = acc;
+        }
+        int64_t remaining = b.cnt[cur][u];
+        const float pr = b.prob[cur][u];
+        int64_t out[4] = {0, 0, 0, 0};
+        // conditional-binomial chain from the last outcome down (multinomial_arr, nade.py:31-35); the float64
+        // renormalisation of :682-683 cancels in p[j] / cumsum[j]
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {
+            double cp = cs[j] > 0.0 ? (double)p[j] / cs[j] : 0.0;
+            cp = cp < 0.0 ? 0.0 : (cp > 1.0 ? 1.0 : cp);
+            naqs::RngStream g{k0, k1, ab, (uint32_t)n | ((uint32_t)j << 8), 0u, 0u};
+            const int64_t draw = naqs::binomial(remaining, cp, g);
+            out[j] = draw;
+            remaining -= draw;
+        }
+        out[0] = acc > 0.0 ? remaining : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!phys[c]) out[c] = 0;                                           // un-physical samples are thrown away, :695
+            b.child_cnt[u * 4 + c] = out[c];
+            b.child_prob[u * 4 + c] = pr * p[c];
+            survivors += out[c] > 0 ? 1u : 0u;
+        }
+    }
+    // survivors of this workgroup
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) survivors += __shfl_down(survivors, off, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = survivors;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < SB / WAVE; ++i) tot += s_red[i];
+        b.wg_total[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(SB) void sample_scatter_kernel(const NetDims d, const int n, const SampleBufs b, const int cur,
+                                                            const int64_t cap, const int last,
+                                                            uint64_t *__restrict__ keys_out, int64_t *__restrict__ counts_out,
+                                                            float *__restrict__ probs_out) {
+    __shared__ int64_t s_off[SB / WAVE];
+    __shared__ uint32_t s_wave[SB / WAVE];
+    const int64_t U = b.U[n];
+    if (b.U[MAXP + 1] != 0) return;
+    const int64_t nwg = (U + SB - 1) / SB;
+    if ((int64_t)blockIdx.x >= nwg) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // offset of this workgroup = survivors of all preceding workgroups
+    int64_t part = 0;
+    for (int64_t wg = threadIdx.x; wg < (int64_t)blockIdx.x; wg += SB) part += b.wg_total[wg];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) s_off[wave] = part;
+    const int64_t u = (int64_t)blockIdx.x * SB + threadIdx.x;
+    const bool active = u < U;
+    int64_t cc[4] = {0, 0, 0, 0};
+    uint32_t mine = 0;
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { cc[c] = b.child_cnt[u * 4 + c]; mine += cc[c] > 0 ? 1u : 0u; }
+    }
+    // exclusive scan of `mine` over the workgroup
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int64_t base = 0;
+    for (int i = 0; i < SB / WAVE; ++i) base += s_off[i];
+    uint32_t before = 0, total = 0;
+    for (int i = 0; i < SB / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
+    int64_t pos = base + before + (incl - mine);
+    if (active && mine) {
+        const uint32_t ab = b.ab[cur][u];
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (cc[c] > 0) {
+                if (pos < cap) {
+                    const uint32_t child = ab | ((uint32_t)(c & 1) << n) | ((uint32_t)(c >> 1) << (16 + n));
+                    const float pr = b.child_prob[u * 4 + c];
+                    if (last) {
+                        uint64_t key = 0;
+                        for (int k = 0; k < d.P; ++k) {
+                            key |= (uint64_t)((child >> k) & 1u) << d.qa[k];
+                            key |= (uint64_t)((child >> (16 + k)) & 1u) << d.qb[k];
+                        }
+                        keys_out[pos] = key;
+                        counts_out[pos] = cc[c];
+                        if (probs_out) probs_out[pos] = pr;
+                    } else {
+                        b.ab[nxt][pos] = child;
+                        b.cnt[nxt][pos] = cc[c];
+                        b.prob[nxt][pos] = pr;
+                    }
+                }
+                ++pos;
+            }
+        }
+    }
+    if ((int64_t)blockIdx.x == nwg - 1 && threadIdx.x == 0) {
+        const int64_t all = base + total;
+        b.U[n + 1] = all < cap ? all : cap;
+        if (all > cap) b.U[MAXP + 1] = 1;
+    }
+}
+
+__global__ void sample_finish_kernel(SampleBufs b, int P, int64_t *__restrict__ info) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t overflow = b.U[MAXP + 1];
+        info[0] = overflow ? 0 : b.U[P];
+        info[1] = overflow;
+    }
+}
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                             int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream) {
+    if (!net || n_samples < 0 || max_unique <= 0 || !keys_dev || !counts_dev || !info_dev) return NAQS_ERR_INVALID;
+    if (!net->have_weights) return NAQS_ERR_INVALID;
+    if (n_samples > (1ll << 44) || max_unique >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    const NetDims &d = net->dims;
+    const int64_t cap = max_unique;
+    const int64_t nwg_cap = (cap + SB - 1) / SB;
+    // carve the scratch: 2 x (ab, cnt, prob), children counts / probs, workgroup totals, level sizes
+    size_t off = 0;
+    size_t o_ab[2], o_cnt[2], o_prob[2];
+    for (int i = 0; i < 2; ++i) {
+        o_ab[i] = off; off = align_up(off + (size_t)cap * sizeof(uint32_t));
+        o_cnt[i] = off; off = align_up(off + (size_t)cap * sizeof(int64_t));
+        o_prob[i] = off; off = align_up(off + (size_t)cap * sizeof(float));
+    }
+    const size_t o_cc = off; off = align_up(off + (size_t)cap * 4 * sizeof(int64_t));
+    const size_t o_cp = off; off = align_up(off + (size_t)cap * 4 * sizeof(float));
+    const size_t o_wg = off; off = align_up(off + (size_t)nwg_cap * sizeof(uint32_t));
+    const size_t o_U = off; off = align_up(off + (size_t)U_SLOTS * sizeof(int64_t));
+    if (cap > net->samp_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (net->d_samp) (void)hipFree(net->d_samp);
+        net->d_samp = nullptr; net->samp_cap = 0;
+        HIP_TRY(hipMalloc(&net->d_samp, off));
+        net->samp_cap = cap;
+    }
+    char *base = static_cast<char *>(net->d_samp);
+    SampleBufs b;
+    for (int i = 0; i < 2; ++i) {
+        b.ab[i] = reinterpret_cast<uint32_t *>(base + o_ab[i]);
+        b.cnt[i] = reinterpret_cast<int64_t *>(base + o_cnt[i]);
+        b.prob[i] = reinterpret_cast<float *>(base + o_prob[i]);
+    }
+    b.child_cnt = reinterpret_cast<int64_t *>(base + o_cc);
+    b.child_prob = reinterpret_cast<float *>(base + o_cp);
+    b.wg_total = reinterpret_cast<uint32_t *>(base + o_wg);
+    b.U = reinterpret_cast<int64_t *>(base + o_U);
+
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sample_init_kernel, dim3(1), dim3(64), 0, s, b, n_samples);
+    HIP_TRY(hipGetLastError());
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    int64_t bound = 1;                                     // worst-case prefixes entering level n: min(4^n, cap)
+    for (int n = 0; n < d.P; ++n) {
+        const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
+        const int nin = n == 0 ? 1 : 2 * n;
+        const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+        hipLaunchKernelGGL(sample_expand_kernel, dim3(grid), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, n & 1, cap, n == d.P - 1 ? 1 : 0,
+                           keys_dev, counts_dev, probs_dev);
+        HIP_TRY(hipGetLastError());
+        bound = bound > cap ? bound : bound * 4;
+    }
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, s, b, d.P, info_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out) {
+    if (reps < 0 || (reps > 0 && !out) || n < 0 || n > (1ll << 44)) return NAQS_ERR_INVALID;
+    for (int64_t i = 0; i < reps; ++i) {
+        naqs::RngStream g{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, (uint32_t)(i >> 32), 0u, 0u};
+        out[i] = naqs::binomial(n, p, g);
+    }
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_rng_philox_host(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    if (!counter || !key || !out) return NAQS_ERR_INVALID;
+    const uint32_t c[4] = {counter[0], counter[1], counter[2], counter[3]};
+    uint32_t r[4];
+    naqs::philox4x32_10(c, key[0], key[1], r);
+    for (int i = 0; i < 4; ++i) out[i] = r[i];
+    return NAQS_OK;
+}

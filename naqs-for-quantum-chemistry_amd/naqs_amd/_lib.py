@@ -45,6 +45,9 @@ SIGNATURES = {
     "naqs_logpsi_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_net_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "naqs_net_sample": (ctypes.c_int, [c_vp, c_i64, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_rng_binomial_host": (ctypes.c_int, [c_i64, ctypes.c_double, ctypes.c_uint64, c_i64, c_vp]),
+    "naqs_rng_philox_host": (ctypes.c_int, [c_vp, c_vp, c_vp]),
 }
 
 NET_MAX_PAIRS, NET_MAX_PHASE_LAYERS = 16, 8

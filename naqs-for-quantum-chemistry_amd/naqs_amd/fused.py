@@ -50,6 +50,7 @@ class FusedLogPsi:
         n = ctypes.c_int64(0)
         _lib.check(self._lib.naqs_net_param_count(self._h, ctypes.byref(n)), "naqs_net_param_count")
         self.n_params = n.value
+        self._samp = None
         assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
         self.refresh()
 
@@ -88,6 +89,27 @@ class FusedLogPsi:
                                         log_psi_out.data_ptr(), eloc_out.data_ptr(), s_ptr, _stream_ptr(self.device))
         _lib.check(st, "naqs_logpsi_eloc")
         return (log_psi_out, eloc_out, sums_out) if weights is not None else (log_psi_out, eloc_out)
+
+    def sample(self, n_samples, seed, max_unique):
+        """Draw ``n_samples`` from |psi|^2 on the device (``naqs_net_sample``): -> (keys int64 [M] in qubit order,
+        counts int64 [M], probs float32 [M]), M unique bit-strings in (prefix, outcome) order.  Raises
+        ``MaxBatchSizeExceededError`` when more than ``max_unique`` prefixes are alive at some level
+        (nade.py:710-712).  One host synchronisation (to learn M)."""
+        from .nade import MaxBatchSizeExceededError
+        cap = int(max_unique)
+        if self._samp is None or self._samp[0].shape[0] < cap:
+            self._samp = (torch.empty(cap, dtype=torch.int64, device=self.device),
+                          torch.empty(cap, dtype=torch.int64, device=self.device),
+                          torch.empty(cap, dtype=torch.float32, device=self.device),
+                          torch.empty(2, dtype=torch.int64, device=self.device))
+        keys, counts, probs, info = self._samp
+        st = self._lib.naqs_net_sample(self._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, keys.data_ptr(),
+                                       counts.data_ptr(), probs.data_ptr(), info.data_ptr(), _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_sample")
+        m, overflow = info.tolist()
+        if overflow:
+            raise MaxBatchSizeExceededError
+        return keys[:m].clone(), counts[:m].clone(), probs[:m].clone()
 
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")

@@ -76,6 +76,7 @@ class NAQSComplex_NADE_orbitals:
         self._m2s_shell = torch.as_tensor(self.model2state_permutation_shell, device=self.device)
         self.model.train()
         self.model.predict()
+        self._fused, self._fused_version = None, None
 
     # ---- mode helpers (wavefunction.py:90-100)
     def train_model(self):
@@ -143,20 +144,69 @@ class NAQSComplex_NADE_orbitals:
         return phases
 
     # ---- sampling (wavefunction.py:488-521)
+    # ---- fused HIP kernels for this network (naqs_amd.fused), kept in step with the parameters
+    def fused(self):
+        """The ``FusedLogPsi`` handle of this network (created on first use; ``None`` when the architecture is
+        outside the fused family or the network is not on a HIP device).  Its packed copy of the weights is
+        refreshed whenever a parameter has been modified in place since the last call (tensor version counters:
+        optimiser steps, ``load_state_dict``)."""
+        if self._fused is None:
+            if self.device.type != "cuda":
+                return None
+            from .fused import FusedLogPsi
+            try:
+                self._fused = FusedLogPsi(self)
+            except NotImplementedError:
+                self._fused = False
+            self._fused_version = self._param_version()
+        if self._fused is False:
+            return None
+        v = self._param_version()
+        if v != self._fused_version:
+            self._fused.refresh()
+            self._fused_version = v
+        return self._fused
+
+    def _param_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
     def sample(self, num_samples=1, ret_probs=True, ret_log_psi=True, ret_norm_reg=False, eval_mode=False,
-               max_batch_size=None, generator=None):
+               max_batch_size=None, generator=None, use_fused=None, ret_keys=False):
+        """wavefunction.py:488-521.  On a HIP device the draw is ``naqs_net_sample`` (one library call for the
+        whole tree); ``use_fused=False`` selects the PyTorch formulation of the same sampler
+        (``OrbitalNADE._forward_sample``, ``torch.binomial`` on the device), which is also what runs for
+        architectures outside the fused family.  ``ret_keys`` appends the int64 keys of the states."""
         if ret_norm_reg:
             raise NotImplementedError("ret_norm_reg")
-        was_training = self.model.training
-        self.model.eval() if eval_mode else self.model.train()
-        self.model.sample()
-        try:
-            states_m, counts, probs = self.model(num_samples, ret_output=False, max_batch_size=max_batch_size,
-                                                 generator=generator)
-        finally:
-            self.model.predict()
-            self.model.train(was_training)
-        states = states_m[:, self._m2q].to(self.hilbert.get_state_dtype("torch"))
+        fused = self.fused() if use_fused in (None, True) else None
+        if use_fused and fused is None:
+            raise NotImplementedError("fused sampler: network not on a HIP device or architecture not supported")
+        keys = None
+        if fused is not None:
+            if generator is not None:
+                seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
+            else:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            if max_batch_size is not None:
+                cap = int(max_batch_size)
+            else:       # live prefixes are bounded by the physical space unless no conditional is masked
+                bound = 4 ** (self.hilbert.N // 2)
+                if self.model.masking is not NadeMasking.NONE and self.model.use_restricted_hilbert:
+                    bound = min(bound, self.hilbert.size)
+                cap = int(min(bound, 2 ** 22))
+            keys, counts, probs = fused.sample(int(num_samples), seed, cap)
+            states = self.hilbert.idx2state(keys)
+        else:
+            was_training = self.model.training
+            self.model.eval() if eval_mode else self.model.train()
+            self.model.sample()
+            try:
+                states_m, counts, probs = self.model(num_samples, ret_output=False, max_batch_size=max_batch_size,
+                                                     generator=generator)
+            finally:
+                self.model.predict()
+                self.model.train(was_training)
+            states = states_m[:, self._m2q].to(self.hilbert.get_state_dtype("torch"))
         out = [states, counts]
         if ret_probs:
             out.append(probs)
@@ -164,6 +214,8 @@ class NAQSComplex_NADE_orbitals:
             # differentiable log psi of the unique samples: one batched teacher-forced pass
             lp = self.log_psi(states)
             out.append(lp.reshape(-1, 2))
+        if ret_keys:
+            out.append(keys if keys is not None else self.hilbert.state2idx(states).squeeze(-1).to(torch.int64))
         return out
 
     # ---- parameters (wavefunction.py:416-451)

@@ -1,0 +1,111 @@
+"""naqs_net_sample (HIP tree sampler) on the GPU.  The reference's sampler draws with numpy's generator on the
+host, so parity is statistical: the empirical distribution must be the network's |psi|^2 over the physical
+states (chi-square against exact probabilities), with the reference's structural properties (unique, physical,
+ascending keys; un-physical draws discarded -> sum(counts) <= n; probs = product of the conditionals)."""
+import numpy as np
+import pytest
+from scipy import stats
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _setup(mol, masking=None):
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.nade import NadeMasking
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda", masking=masking or NadeMasking.PARTIAL)
+    return hil, wf, FusedLogPsi(wf)
+
+
+def _exact(hil, fused):
+    """probability of every physical state under the network (not normalised over the physical space when the
+    last block is un-masked)"""
+    keys = torch.as_tensor(np.sort(hil._all_keys()), device="cuda")
+    lp = fused.log_psi(keys)
+    return keys.cpu().numpy(), np.exp(2.0 * lp[:, 0].double().cpu().numpy())
+
+
+@pytest.mark.parametrize("mol,n", [("LiH", 2_000_000), ("H2O", 5_000_000)])
+def test_distribution_matches_psi_squared(mol, n):
+    hil, wf, fused = _setup(mol)
+    keys, counts, probs = fused.sample(n, seed=20240607, max_unique=100000)
+    k = keys.cpu().numpy()
+    c = counts.cpu().numpy()
+    assert np.all(np.diff(k) > 0), "unique and ascending (the reference's order for qubit_ordering=-1)"
+    assert hil.is_physical(k).all() and (c > 0).all()
+    all_keys, p = _exact(hil, fused)
+    total = c.sum()
+    assert total <= n
+    # mass kept = probability of drawing a physical state (un-physical children are dropped, nade.py:695)
+    p_phys = p.sum()
+    assert abs(total - n * p_phys) < 6 * np.sqrt(n * p_phys * (1 - p_phys)) + 1
+    # probs = product of float32 conditionals = exp(2 log|psi|)
+    pos = np.searchsorted(all_keys, k)
+    assert np.array_equal(all_keys[pos], k)
+    assert np.allclose(probs.cpu().numpy(), p[pos], rtol=2e-4, atol=1e-12)
+    obs = np.zeros(len(all_keys))
+    obs[pos] = c
+    expect = p / p_phys * total
+    m = expect >= 5
+    chi2 = ((obs[m] - expect[m]) ** 2 / expect[m]).sum() + (obs[~m].sum() - expect[~m].sum()) ** 2 / max(expect[~m].sum(), 1e-9)
+    assert stats.chi2.sf(chi2, m.sum()) > 1e-4, (chi2, m.sum())
+
+
+def test_full_masking_keeps_every_draw():
+    from naqs_amd.nade import NadeMasking
+    hil, wf, fused = _setup("LiH", NadeMasking.FULL)
+    keys, counts, probs = fused.sample(10 ** 6, seed=3, max_unique=1000)
+    assert counts.sum().item() == 10 ** 6                       # every conditional masked -> nothing to discard
+    assert abs(probs.double().sum().item() - 1) < 0.05 or len(keys) < hil.size
+
+
+def test_deterministic_in_seed_and_matches_torch_sampler_statistically():
+    hil, wf, fused = _setup("LiH")
+    a = fused.sample(10 ** 6, seed=11, max_unique=1000)
+    b = fused.sample(10 ** 6, seed=11, max_unique=1000)
+    c = fused.sample(10 ** 6, seed=12, max_unique=1000)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[1], c[1]) if len(a[1]) == len(c[1]) else True
+    # the PyTorch sampler of the same network (torch.binomial on device): same distribution
+    g = torch.Generator(device="cuda").manual_seed(1)
+    states, counts_t, _ = wf.sample(10 ** 6, ret_log_psi=False, generator=g, use_fused=False)
+    kt = hil.state2idx(states).squeeze().cpu().numpy().astype(np.int64)
+    ka, ca = a[0].cpu().numpy(), a[1].cpu().numpy()
+    union = np.union1d(kt, ka)
+    oa, ot = np.zeros(len(union)), np.zeros(len(union))
+    oa[np.searchsorted(union, ka)] = ca
+    ot[np.searchsorted(union, kt)] = counts_t.cpu().numpy()
+    m = (oa + ot) >= 10
+    # two-sample chi-square
+    na, nt = oa.sum(), ot.sum()
+    chi2 = ((np.sqrt(nt / na) * oa[m] - np.sqrt(na / nt) * ot[m]) ** 2 / (oa[m] + ot[m])).sum()
+    assert stats.chi2.sf(chi2, m.sum() - 1) > 1e-4
+
+
+def test_overflow_raises_like_the_reference():
+    from naqs_amd.nade import MaxBatchSizeExceededError
+    hil, wf, fused = _setup("H2O")
+    with pytest.raises(MaxBatchSizeExceededError):
+        fused.sample(10 ** 7, seed=1, max_unique=50)
+    keys, counts, _ = fused.sample(10 ** 7, seed=1, max_unique=441)      # the whole space fits
+    assert len(keys) <= 441
+
+
+def test_large_sample_counts_n2():
+    hil, wf, fused = _setup("N2")
+    n = 10 ** 12
+    keys, counts, probs = fused.sample(n, seed=5, max_unique=100000)
+    k = keys.cpu().numpy()
+    assert len(k) <= 14400 and np.all(np.diff(k) > 0) and hil.is_physical(k).all()
+    total = counts.sum().item()
+    assert 0 < total <= n
+    # with 1e12 draws the relative frequencies are the probabilities to ~1e-5
+    lp = fused.log_psi(keys)
+    p = np.exp(2.0 * lp[:, 0].double().cpu().numpy())
+    f = counts.double().cpu().numpy() / n
+    big = p > 1e-6
+    assert np.max(np.abs(f[big] / p[big] - 1)) < 5e-3

@@ -1,0 +1,75 @@
+"""Wall-clock breakdown of one training step (sampler / forward / E_loc / backward / Adam) on the GPU.
+usage: python tools/step_profile.py [molecule npz] [n_samples] [steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "naqs-for-quantum-chemistry_amd")]
+import numpy as np, torch
+from naqs_amd.hilbert import Encoding, Hilbert
+from naqs_amd.nade import NadeMasking
+from naqs_amd.optimizer import PartialSamplingOptimizer, vmc_loss, keys_to_device
+from naqs_amd.system import load_molecule, set_global_seed
+from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+
+mol_f = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/ham_N2.npz")
+n_samples = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1000000
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+dev = torch.device("cuda", 0)
+set_global_seed(1)
+mol, qh = load_molecule(mol_f)
+na, nb = mol.get_n_alpha_electrons(), mol.get_n_beta_electrons()
+hil = Hilbert.get(N=mol.n_qubits, N_alpha=na, N_beta=nb, encoding=Encoding.SIGNED)
+wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, amp_hidden_size=[64],
+                               phase_hidden_size=[512, 512], use_amp_spin_sym=True, use_phase_spin_sym=False,
+                               aggregate_phase=False, n_alpha_electrons=na, n_beta_electrons=nb, device=dev)
+opt = PartialSamplingOptimizer(n_samples=n_samples, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5,
+                               wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False, n_electrons=mol.n_electrons,
+                               n_alpha_electrons=na, n_beta_electrons=nb, optimizer=torch.optim.Adam,
+                               optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'eps': 1e-15}, {'lr': 1e-2}],
+                               save_loc="/tmp/step_profile", seed=1, grad_clip_factor=None,
+                               pauli_hamiltonian_dtype=np.float64, normalise_psi=True)
+T = {}
+def tick(name, t0):
+    torch.cuda.synchronize()
+    T[name] = T.get(name, 0.0) + time.perf_counter() - t0
+    return time.perf_counter()
+
+def step(record):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    states, counts, probs = opt.get_samples()
+    if record: t = tick("sample", t)
+    weights = counts.double() / counts.sum().double()
+    keys_h = hil.state2idx(states).squeeze(-1)
+    keys = keys_to_device(keys_h, dev)
+    if record: t = tick("state2idx", t)
+    lp = wf.log_psi(states).reshape(-1, 2)
+    if record: t = tick("forward(torch)", t)
+    w = weights.to(dev, torch.float64)
+    e_loc, sums = opt.pauli_hamiltonian.local_energy(keys, lp.detach(), kind="log_psi", weights=w)
+    if record: t = tick("eloc", t)
+    e_mean = torch.stack([sums[0], sums[1]])
+    loss = vmc_loss(lp, e_loc.to(lp.dtype), w.to(lp.dtype), e_mean.to(lp.dtype))
+    opt.optimizer.zero_grad()
+    loss.backward()
+    if record: t = tick("backward", t)
+    opt.optimizer.step()
+    if record: t = tick("adam", t)
+    e = float((sums[0] / sums[3]).item())
+    if record: t = tick("item", t)
+    return len(keys), e
+
+for _ in range(5): step(False)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps): m, e = step(True)
+torch.cuda.synchronize(); tot = time.perf_counter() - t0
+print(f"{mol_f}: {m} unique samples, E={e:.6f}; {tot / steps * 1e3:.3f} ms/step (with per-phase syncs)")
+for k, v in T.items():
+    print(f"  {k:16s} {v / steps * 1e3:8.3f} ms")
+# un-instrumented: the optimizer's own loop
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps):
+    states, counts, probs = opt.get_samples()
+    weights = counts.double() / counts.sum().double()
+    keys = hil.state2idx(states).squeeze(-1)
+    opt._SGD_step(states, keys, None, sample_weights=weights)
+torch.cuda.synchronize()
+print(f"optimizer loop: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step")
