@@ -220,6 +220,26 @@ int naqs_net_prof_stride(naqs_net_t *net, int stride);
  * ============================================================================================== */
 int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
                     int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream);
+
+/* ================================================================================================
+ * Training-time amplitude network: forward and backward of log|psi| in two launches each.
+ * The reference back-propagates 2 Re sum_i w_i log psi_i (E_loc_i - <E>)^* through PyTorch autograd
+ * (src/optimizer/energy.py:329-343); the amplitude half of that graph — ~10 orbital pairs x (2 Linear + mask +
+ * log-softmax + gathers), src/naqs/network/nade.py:738-770 — is what these replace (the phase MLP is three plain
+ * Linear layers and stays with the BLAS library).  Gradients are deterministic (fixed-order reductions).
+ * ============================================================================================== */
+/* Number of amplitude-block parameters = the leading part of the flat state_dict order of naqs_net_param_count. */
+int naqs_net_amp_param_count(const naqs_net_t *net, int64_t *count);
+/* Re-pack only the amplitude blocks (flat_dev: the whole flat parameter vector or just its amplitude part).
+ * The packed phase layers become stale: naqs_net_logpsi / naqs_logpsi_eloc return NAQS_ERR_INVALID until the next
+ * naqs_net_set_weights.  Enough for naqs_net_sample, naqs_net_logamp and naqs_net_amp_backward. */
+int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream);
+/* logamp_dev [M] float32: log|psi(key_i)| (identical to column 0 of naqs_net_logpsi). */
+int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logamp_dev, void *stream);
+/* grad_dev [amp_param_count] float32 (state_dict order) = d/d theta  sum_i g_dev[i] * log|psi(key_i)|. */
+int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev,
+                          void *stream);
+
 /* Host evaluation of the sampler's generators, for known-answer and statistical tests (no device needed):
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */
 int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out);

@@ -1,0 +1,271 @@
+// naqs_grad.hip — training-time evaluation of the amplitude half of the orbital NADE on gfx950 (MI355X):
+//   naqs_net_logamp        log|psi|(key_i) = sum_n [conditional log-amplitude of the realised outcome of pair n]
+//   naqs_net_amp_backward  d/d theta  sum_i g_i log|psi|(key_i)  for every amplitude-block parameter
+// i.e. the forward and backward of the amplitude part of _forward_predict (src/naqs/network/nade.py:738-770 with the
+// helpers :417-630, activations.py:40-46) that the reference leaves to PyTorch autograd (energy.py:329-343).  The eager
+// formulation is ~10 orbital pairs x (2 Linear + mask + softmax + gathers), forward and backward; here it is two
+// kernels each way, and the gradient is deterministic (fixed-order reductions, no float atomics).
+//
+// amp_backward_kernel: workgroup = one orbital pair n (blockIdx.y) x a strided set of 256-sample tiles.  Per tile every
+// thread owns a sample: it recomputes the block's forward from the key bits (weights staged in LDS), forms
+// d log-amp / d outputs (softmax residual through the symmetrisation, nade.py:585-586) scaled by g_i and
+// back-propagates to the hidden pre-activations.  The per-sample factors go through one LDS tile [hidden][sample];
+// the threads then re-partition over the PARAMETERS (thread = hidden unit j x a subset of input columns) and walk
+// the tile's samples, accumulating dW1, db1 (from d pre) and dW2, db2 (from h) in registers across all tiles of the
+// workgroup.  Partial sums per workgroup go to scratch in state_dict order; amp_reduce_kernel adds them in order.
+
+#include <algorithm>
+#include <cstdint>
+
+#include "naqs_common.hpp"
+#include "naqs_net.hpp"
+
+namespace {
+
+using naqs::MAXP;
+using naqs::NetDims;
+using naqs::WAVE;
+using naqs::DeviceGuard;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB = 256;            // samples per tile = threads per workgroup
+constexpr int MAX_ACC_A = 16;      // (nin + 1) input columns incl. bias / (GB / Ha) per thread
+constexpr int MAX_ACC_B = 4;       // n_out / (GB / Ha) per thread
+constexpr int MAX_TILE_WGS = 64;   // workgroups per pair (each walks tiles blockIdx.x, +gridDim.x, ...)
+
+struct AmpSrc { int64_t off[MAXP]; };     // flat (state_dict) offset of pair n's parameters
+
+// out[i] = sum_n scratch[n][i] in the order of the fused log-psi epilogue
+__global__ __launch_bounds__(256) void logamp_sum_kernel(int P, int64_t M, const float *__restrict__ scratch,
+                                                         float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float s = 0.0f;
+    for (int n = 0; n < P; ++n) s += scratch[(int64_t)n * M + i];
+    out[i] = s;
+}
+
+__device__ __forceinline__ float pre_activation(const float *__restrict__ row, int nin, uint32_t xbits, bool zero_input) {
+    float pre = row[nin];
+    if (!zero_input)
+        for (int k = 0; k < nin; ++k) pre += ((xbits >> k) & 1u) ? row[k] : -row[k];
+    return pre;
+}
+
+__global__ __launch_bounds__(GB) void amp_backward_kernel(const NetDims d, const float *__restrict__ w, const int64_t M,
+                                                          const uint64_t *__restrict__ keys, const float *__restrict__ g,
+                                                          float *__restrict__ partial, const int64_t partial_stride,
+                                                          const AmpSrc src) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockIdx.y;
+    const int nin = n == 0 ? 1 : 2 * n;
+    const int S = (nin + 1 + 5 + 3) & ~3;
+    const int Ha = d.Ha, nout = d.n_out_amp;
+    const int w_floats = (Ha * S + 8 + 3) & ~3;
+    float *s_w = smem;
+    float *s_tile = s_w + w_floats;                       // [Ha][GB + 1]
+    float *s_do = s_tile + Ha * (GB + 1);                 // [5][GB]
+    uint32_t *s_x = reinterpret_cast<uint32_t *>(s_do + 5 * GB);   // [GB] input bits | bias bit
+    const int tid = threadIdx.x;
+    {
+        const f32x4 *from = reinterpret_cast<const f32x4 *>(w + d.amp_off[n]);
+        f32x4 *to = reinterpret_cast<f32x4 *>(s_w);
+        for (int e = tid; e < (Ha * S + 8) / 4; e += GB) to[e] = from[e];
+    }
+    const float *b2 = s_w + Ha * S;
+    const bool zero_input = n == 0;                       // pair 0 sees a constant-zero input (nade.py:509-511)
+    // parameter ownership of this thread (GB % Ha == 0, checked by the host)
+    const int j = tid % Ha, kbase = tid / Ha, kstep = GB / Ha;
+    float accA[MAX_ACC_A], accB[MAX_ACC_B], accC = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MAX_ACC_A; ++m) accA[m] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MAX_ACC_B; ++m) accB[m] = 0.0f;
+    __syncthreads();
+
+    for (int64_t t0 = (int64_t)blockIdx.x * GB; t0 < M; t0 += (int64_t)gridDim.x * GB) {
+        const int64_t i = t0 + tid;
+        const bool valid = i < M;
+        const uint64_t key = valid ? keys[i] : 0ull;
+        uint32_t abits = 0, bbits = 0;
+        for (int k = 0; k < n; ++k) {
+            abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+            bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+        }
+        const int occ = (int)((key >> d.qa[n]) & 1ull) + 2 * (int)((key >> d.qb[n]) & 1ull);
+        const bool swap = d.sym && abits > bbits;
+        const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
+        const uint32_t xbits = first | (second << n);
+        const float gi = valid ? g[i] : 0.0f;
+        // forward of the block
+        float o[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o[c] = c < nout ? b2[c] : 0.0f;
+        for (int jj = 0; jj < Ha; ++jj) {
+            const float *row = s_w + jj * S;
+            const float h = fmaxf(pre_activation(row, nin, xbits, zero_input), 0.0f);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                if (c < nout) o[c] = fmaf(row[nin + 1 + c], h, o[c]);
+        }
+        float la[4];
+        bool ok[4];
+        naqs::amp_conditional(d, n, o, abits, bbits, la, ok);
+        // d la[occ] / d a4[c] = [c == occ] - softmax(2 a4)[c] on the allowed outcomes
+        float da4[4];
+        const bool live = valid && (occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3])));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float sm = ok[c] ? expf(2.0f * la[c]) : 0.0f;
+            da4[c] = live && ok[c] ? gi * ((c == occ ? 1.0f : 0.0f) - sm) : 0.0f;
+        }
+        float dout[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (d.sym) {                                       // transpose of amp_symmetrise
+            const int x_order = abits > bbits ? 0 : (abits == bbits ? 1 : 2);
+            dout[0] = da4[0];
+            dout[2] = da4[3];
+            dout[1] = 0.5f * (da4[1] + da4[2]);
+            if (x_order == 1) dout[1] += 0.5f * (da4[1] + da4[2]);
+            else if (x_order == 0) { dout[3] = 0.5f * da4[1]; dout[4] = 0.5f * da4[2]; }
+            else { dout[4] = 0.5f * da4[1]; dout[3] = 0.5f * da4[2]; }
+        } else {
+            dout[0] = da4[0]; dout[1] = da4[1]; dout[2] = da4[2]; dout[3] = da4[3];
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) s_do[c * GB + tid] = dout[c];
+        s_x[tid] = xbits | (1u << nin);                    // bit nin: the bias column
+        // d pre-activations -> tile
+        for (int jj = 0; jj < Ha; ++jj) {
+            const float *row = s_w + jj * S;
+            const float pre = pre_activation(row, nin, xbits, zero_input);
+            float dh = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                if (c < nout) dh = fmaf(row[nin + 1 + c], dout[c], dh);
+            s_tile[jj * (GB + 1) + tid] = pre > 0.0f ? dh : 0.0f;
+        }
+        __syncthreads();
+        // dW1[j][k], db1[j] (k == nin): walk the tile's samples
+        {
+            const float *col = s_tile + j * (GB + 1);
+            for (int s = 0; s < GB; ++s) {
+                const float v = col[s];
+                const uint32_t xb = s_x[s];
+#pragma unroll
+                for (int m = 0; m < MAX_ACC_A; ++m) {
+                    const int k = kbase + m * kstep;
+                    accA[m] += ((xb >> (k & 31)) & 1u) ? v : -v;
+                }
+            }
+        }
+        __syncthreads();
+        // hidden activations -> tile
+        for (int jj = 0; jj < Ha; ++jj) {
+            const float *row = s_w + jj * S;
+            s_tile[jj * (GB + 1) + tid] = fmaxf(pre_activation(row, nin, xbits, zero_input), 0.0f);
+        }
+        __syncthreads();
+        {
+            const float *col = s_tile + j * (GB + 1);
+            for (int s = 0; s < GB; ++s) {
+                const float h = col[s];
+#pragma unroll
+                for (int m = 0; m < MAX_ACC_B; ++m) {
+                    const int c = kbase + m * kstep;
+                    if (c < nout) accB[m] = fmaf(s_do[c * GB + s], h, accB[m]);
+                }
+            }
+            if (tid < nout)
+                for (int s = 0; s < GB; ++s) accC += s_do[tid * GB + s];
+        }
+        __syncthreads();
+    }
+
+    // partial sums of this workgroup in state_dict order: W1 [Ha][nin], b1 [Ha], W2 [nout][Ha], b2 [nout]
+    float *out = partial + (int64_t)blockIdx.x * partial_stride + src.off[n];
+#pragma unroll
+    for (int m = 0; m < MAX_ACC_A; ++m) {
+        const int k = kbase + m * kstep;
+        if (k < nin) out[j * nin + k] = zero_input ? 0.0f : accA[m];
+        else if (k == nin) out[Ha * nin + j] = accA[m];
+    }
+#pragma unroll
+    for (int m = 0; m < MAX_ACC_B; ++m) {
+        const int c = kbase + m * kstep;
+        if (c < nout) out[Ha * nin + Ha + c * Ha + j] = accB[m];
+    }
+    if (tid < nout) out[Ha * nin + Ha + nout * Ha + tid] = accC;
+}
+
+__global__ __launch_bounds__(256) void amp_reduce_kernel(int64_t count, int n_partials, int64_t partial_stride,
+                                                         const float *__restrict__ partial, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    float s = 0.0f;
+    for (int b = 0; b < n_partials; ++b) s += partial[(int64_t)b * partial_stride + e];
+    out[e] = s;
+}
+
+// the amp kernel of naqs_logpsi.hip is reached through naqs::net_amp_forward
+}  // namespace
+
+NAQS_API int naqs_net_amp_param_count(const naqs_net_t *net, int64_t *count) {
+    if (!net || !count) return NAQS_ERR_INVALID;
+    *count = net->amp_params;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logamp_dev, void *stream) {
+    if (!net || M < 0 || (M > 0 && (!keys_dev || !logamp_dev))) return NAQS_ERR_INVALID;
+    if (!net->have_amp_weights) return NAQS_ERR_INVALID;
+    if (M == 0) return NAQS_OK;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    st = naqs::net_amp_forward(net, M, keys_dev, s);
+    if (st != NAQS_OK) return st;
+    hipLaunchKernelGGL(logamp_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch,
+                       logamp_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
+                                   float *grad_dev, void *stream) {
+    if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
+    if (!net->have_amp_weights) return NAQS_ERR_INVALID;
+    const NetDims &d = net->dims;
+    if (d.Ha > GB || GB % d.Ha != 0) return NAQS_ERR_UNSUPPORTED;
+    const int kstep = GB / d.Ha, nin_max = 2 * (d.P - 1);
+    if ((nin_max + 1 + kstep - 1) / kstep > MAX_ACC_A || (d.n_out_amp + kstep - 1) / kstep > MAX_ACC_B) return NAQS_ERR_UNSUPPORTED;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M == 0) {
+        HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)net->amp_params * sizeof(float), s));
+        return NAQS_OK;
+    }
+    const int n_wg = (int)std::min<int64_t>(MAX_TILE_WGS, (M + GB - 1) / GB);
+    const int64_t stride = (net->amp_params + 3) & ~3ll;
+    if (!net->d_gpart) {
+        HIP_TRY(hipMalloc((void **)&net->d_gpart, (size_t)MAX_TILE_WGS * stride * sizeof(float)));
+    }
+    const int S_max = (nin_max + 1 + 5 + 3) & ~3;
+    const size_t lds = ((size_t)((d.Ha * S_max + 8 + 3) & ~3) + (size_t)d.Ha * (GB + 1) + 5 * GB + GB) * sizeof(float);
+    if (lds > 160 * 1024) return NAQS_ERR_UNSUPPORTED;
+    if (!net->grad_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        net->grad_attr_set = true;
+    }
+    AmpSrc src;
+    for (int n = 0; n < MAXP; ++n) src.off[n] = net->amp_src_off[n];
+    hipLaunchKernelGGL(amp_backward_kernel, dim3((unsigned)n_wg, (unsigned)d.P), dim3(GB), lds, s, d, net->d_w, M, keys_dev, g_dev,
+                       net->d_gpart, stride, src);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(amp_reduce_kernel, dim3((unsigned)((net->amp_params + 255) / 256)), dim3(256), 0, s, net->amp_params, n_wg,
+                       stride, net->d_gpart, grad_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}

@@ -532,8 +532,15 @@ __global__ __launch_bounds__(256) void pack_phase_bf16_kernel(const float *__res
 // re-pack the flat state_dict-order parameters into the kernels' layout
 // amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]] ->
 // Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
-__global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ src, int Ha, int nin, int nout,
-                                                       float *__restrict__ dst) {
+struct AmpSrcOff { int64_t off[MAXP]; };
+
+// every amplitude block in one launch: blockIdx.y = pair n, rows [W1[j][:] | b1[j] | W2[:][j] | pad] + b2
+__global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
+                                                       float *__restrict__ w) {
+    const int n = blockIdx.y;
+    const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
+    const float *src = flat + so.off[n];
+    float *dst = w + d.amp_off[n];
     const int S = (nin + 1 + 5 + 3) & ~3, total = Ha * S + 8;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         float v = 0.0f;
@@ -686,6 +693,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_wh) (void)hipFree(net->d_wh);
     if (net->d_scratch) (void)hipFree(net->d_scratch);
     if (net->d_samp) (void)hipFree(net->d_samp);
+    if (net->d_gpart) (void)hipFree(net->d_gpart);
     delete net;
     return NAQS_OK;
 }
@@ -696,6 +704,29 @@ NAQS_API int naqs_net_param_count(const naqs_net_t *net, int64_t *count) {
     return NAQS_OK;
 }
 
+static int pack_amp_blocks(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
+    const NetDims &d = net->dims;
+    AmpSrcOff so;
+    for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
+    const int total_max = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;
+    hipLaunchKernelGGL(pack_amp_kernel, dim3((total_max + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_w);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
+    if (!net || !flat_dev || (count != net->n_params && count != net->amp_params)) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    net->have_weights = false;               // the packed phase layers no longer belong to these parameters
+    net->have_amp_weights = false;
+    st = pack_amp_blocks(net, flat_dev, reinterpret_cast<hipStream_t>(stream));
+    if (st != NAQS_OK) return st;
+    net->have_amp_weights = true;
+    return NAQS_OK;
+}
+
 NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
     if (!net || !flat_dev || count != net->n_params) return NAQS_ERR_INVALID;
     DeviceGuard guard;
@@ -703,13 +734,9 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const NetDims &d = net->dims;
-    for (int n = 0; n < d.P; ++n) {
-        const int nin = n == 0 ? 1 : 2 * n;
-        const int total = d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
-        hipLaunchKernelGGL(pack_amp_kernel, dim3((total + 255) / 256), dim3(256), 0, s, flat_dev + net->amp_src_off[n], d.Ha, nin,
-                           d.n_out_amp, net->d_w + d.amp_off[n]);
-        HIP_TRY(hipGetLastError());
-    }
+    net->have_weights = net->have_amp_weights = false;
+    st = pack_amp_blocks(net, flat_dev, s);
+    if (st != NAQS_OK) return st;
     for (int l = 0; l < d.n_lin; ++l) {
         const int total = d.N_pad[l] * d.K_pad[l] + d.N_pad[l];
         hipLaunchKernelGGL(pack_phase_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
@@ -722,7 +749,26 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
                            d.Kh_pad[l], d.N_pad[l], net->d_wh + d.wh_off[l]);
         HIP_TRY(hipGetLastError());
     }
-    net->have_weights = true;
+    net->have_weights = net->have_amp_weights = true;
+    return NAQS_OK;
+}
+
+int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed) {
+    const NetDims &d = net->dims;
+    if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
+    if (M > net->cap_M) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (net->d_scratch) (void)hipFree(net->d_scratch);
+        net->d_scratch = nullptr; net->cap_M = 0;
+        const int64_t cap = std::max<int64_t>(1024, M + M / 4);
+        HIP_TRY(hipMalloc((void **)&net->d_scratch, (size_t)cap * d.P * sizeof(float)));
+        net->cap_M = cap;
+    }
+    const ElocFeed none{};
+    const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, net->d_w, M,
+                       keys_dev, net->d_scratch, feed ? *feed : none);
+    HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
 
@@ -736,19 +782,9 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
-    if (M > net->cap_M) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (net->d_scratch) (void)hipFree(net->d_scratch);
-        net->d_scratch = nullptr; net->cap_M = 0;
-        const int64_t cap = std::max<int64_t>(1024, M + M / 4);
-        HIP_TRY(hipMalloc((void **)&net->d_scratch, (size_t)cap * d.P * sizeof(float)));
-        net->cap_M = cap;
-    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, net->d_w, M,
-                       keys_dev, net->d_scratch, feed);
-    HIP_TRY(hipGetLastError());
+    st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
+    if (st != NAQS_OK) return st;
 
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA

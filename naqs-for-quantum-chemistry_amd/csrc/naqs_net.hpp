@@ -146,7 +146,15 @@ struct naqs_net {
     void *d_samp = nullptr;                 // tree-sampler scratch (naqs_sample.hip), sized for samp_cap unique prefixes
     int64_t samp_cap = 0;
     int cu_count = 256;
-    bool have_weights = false;
+    bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
+    bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
+    float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
+    bool grad_attr_set = false;
     naqs::EventRing prof;
 };
 
+namespace naqs {
+struct ElocFeed;
+// naqs_logpsi.hip: grow the [P][M] scratch and launch amp_kernel (feed == nullptr: no E_loc hand-over)
+int net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed = nullptr);
+}  // namespace naqs

@@ -233,7 +233,7 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
                              int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream) {
     if (!net || n_samples < 0 || max_unique <= 0 || !keys_dev || !counts_dev || !info_dev) return NAQS_ERR_INVALID;
-    if (!net->have_weights) return NAQS_ERR_INVALID;
+    if (!net->have_amp_weights) return NAQS_ERR_INVALID;
     if (n_samples > (1ll << 44) || max_unique >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
     DeviceGuard guard;
     int st = guard.init(net->device);

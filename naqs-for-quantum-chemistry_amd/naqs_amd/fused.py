@@ -14,6 +14,36 @@ from . import _lib
 from .hamiltonian import _stream_ptr
 
 
+class _LogAmp(torch.autograd.Function):
+    """log|psi|(keys) with the amplitude blocks' forward and backward as HIP kernels
+    (``naqs_net_logamp`` / ``naqs_net_amp_backward``)."""
+
+    @staticmethod
+    def forward(ctx, fused, keys, *amp_params):
+        M = keys.shape[0]
+        out = torch.empty(M, dtype=torch.float32, device=keys.device)
+        st = fused._lib.naqs_net_logamp(fused._h, M, keys.data_ptr(), out.data_ptr(), _stream_ptr(fused.device))
+        _lib.check(st, "naqs_net_logamp")
+        ctx.fused, ctx.keys = fused, keys
+        ctx.shapes = [p.shape for p in amp_params]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fused, keys = ctx.fused, ctx.keys
+        g = g.to(torch.float32).contiguous()
+        flat = torch.empty(fused.n_amp_params, dtype=torch.float32, device=keys.device)
+        st = fused._lib.naqs_net_amp_backward(fused._h, keys.shape[0], keys.data_ptr(), g.data_ptr(), flat.data_ptr(),
+                                              _stream_ptr(fused.device))
+        _lib.check(st, "naqs_net_amp_backward")
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = shp.numel()
+            grads.append(flat[off:off + n].view(shp))
+            off += n
+        return (None, None, *grads)
+
+
 class FusedLogPsi:
     def __init__(self, wavefunction):
         wf, m = wavefunction, wavefunction.model
@@ -52,14 +82,40 @@ class FusedLogPsi:
         self.n_params = n.value
         self._samp = None
         assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
+        _lib.check(self._lib.naqs_net_amp_param_count(self._h, ctypes.byref(n)), "naqs_net_amp_param_count")
+        self.n_amp_params = n.value
+        self._amp_params = [p for blk in m.amp_layers for p in blk.parameters()]
+        assert self.n_amp_params == sum(p.numel() for p in self._amp_params), "amplitude parameter layout mismatch"
+        # key bits feeding the phase block (alpha then beta occupations of model pairs 0..P-2) and the last pair's outcome
+        q2m = [int(q) for q in wf.qubit2model_permutation]
+        P = m.P
+        self._phase_shifts = torch.tensor([q2m[2 * k] for k in range(P - 1)] + [q2m[2 * k + 1] for k in range(P - 1)],
+                                          dtype=torch.int64, device=self.device)
+        self._last_a, self._last_b = q2m[2 * (P - 1)], q2m[2 * (P - 1) + 1]
         self.refresh()
 
-    def refresh(self):
-        """Re-pack the current network parameters (call after every optimiser step)."""
-        flat = torch.cat([p.detach().reshape(-1) for p in self.wf.model.parameters()]).to(torch.float32).contiguous()
-        st = self._lib.naqs_net_set_weights(self._h, flat.data_ptr(), flat.numel(), _stream_ptr(self.device))
-        _lib.check(st, "naqs_net_set_weights")
+    def refresh(self, amp_only=False):
+        """Re-pack the current network parameters (after every optimiser step).  ``amp_only`` packs just the
+        amplitude blocks — all that sampling and the training forward/backward need; the phase layers are then
+        stale for ``log_psi`` / ``log_psi_and_local_energy`` until a full refresh."""
+        params = self._amp_params if amp_only else list(self.wf.model.parameters())
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
+        fn = self._lib.naqs_net_set_amp_weights if amp_only else self._lib.naqs_net_set_weights
+        _lib.check(fn(self._h, flat.data_ptr(), flat.numel(), _stream_ptr(self.device)), "naqs_net_set_weights")
         self._flat = flat          # keep alive until the async copy has been consumed
+
+    def log_psi_train(self, keys):
+        """Differentiable log psi [M, 2] of int64 device keys: amplitude blocks through the HIP forward/backward
+        pair, the phase MLP (three Linear layers) through PyTorch/rocBLAS.  Same function of the parameters as
+        ``wavefunction.log_psi(states)``."""
+        m = self.wf.model
+        keys = keys.contiguous()
+        log_amp = _LogAmp.apply(self, keys, *self._amp_params)
+        x = ((keys.unsqueeze(-1) >> self._phase_shifts) & 1).to(torch.float32).mul_(2.0).sub_(1.0)
+        out = m.phase_layers[0](x)                                                   # nade.py:563-569
+        occ = ((keys >> self._last_a) & 1) + 2 * ((keys >> self._last_b) & 1)
+        phase = out.gather(1, occ.unsqueeze(1)).squeeze(1)
+        return torch.stack([log_amp, phase], -1)
 
     def log_psi(self, keys, out=None):
         """keys: int64 device tensor [M] (uint64 bit patterns, qubit order) -> float32 [M, 2]."""

@@ -95,6 +95,7 @@ class OptimizerBase:
             self.generator.manual_seed(torch.initial_seed() % (2 ** 63))
         self.sampled_idxs = Counter()
         self.track_sampled_idxs = True
+        self.use_fused = True                # HIP sampler / amplitude forward-backward when the network supports them
         self.reset_log()
         self.reset_optimizer()
 
@@ -172,9 +173,15 @@ class OptimizerBase:
         else:
             # gradients only for the owned rows; the table needed for the psi look-ups is evaluated
             # without autograd (the rows of other ranks are theirs to differentiate)
-            lp_mine = self.wavefunction.log_psi(states[b:e_]).reshape(-1, 2)
+            fused = self.wavefunction.fused(need_phase=world > 1) if self.use_fused else None
+            if fused is not None:           # HIP forward/backward of the amplitude blocks, keys in, no state tensors
+                lp_mine = fused.log_psi_train(keys[b:e_])
+            else:
+                lp_mine = self.wavefunction.log_psi(states[b:e_]).reshape(-1, 2)
             if world == 1:
                 lp_all = lp_mine
+            elif fused is not None:
+                lp_all = fused.log_psi(keys)
             else:
                 with torch.no_grad():
                     lp_all = self.wavefunction.log_psi(states).reshape(-1, 2)

@@ -76,7 +76,7 @@ class NAQSComplex_NADE_orbitals:
         self._m2s_shell = torch.as_tensor(self.model2state_permutation_shell, device=self.device)
         self.model.train()
         self.model.predict()
-        self._fused, self._fused_version = None, None
+        self._fused, self._fused_version, self._fused_amp_version = None, None, None
 
     # ---- mode helpers (wavefunction.py:90-100)
     def train_model(self):
@@ -145,11 +145,12 @@ class NAQSComplex_NADE_orbitals:
 
     # ---- sampling (wavefunction.py:488-521)
     # ---- fused HIP kernels for this network (naqs_amd.fused), kept in step with the parameters
-    def fused(self):
+    def fused(self, need_phase=True):
         """The ``FusedLogPsi`` handle of this network (created on first use; ``None`` when the architecture is
         outside the fused family or the network is not on a HIP device).  Its packed copy of the weights is
         refreshed whenever a parameter has been modified in place since the last call (tensor version counters:
-        optimiser steps, ``load_state_dict``)."""
+        optimiser steps, ``load_state_dict``); ``need_phase=False`` (sampling, training forward/backward) re-packs
+        only the amplitude blocks."""
         if self._fused is None:
             if self.device.type != "cuda":
                 return None
@@ -158,13 +159,17 @@ class NAQSComplex_NADE_orbitals:
                 self._fused = FusedLogPsi(self)
             except NotImplementedError:
                 self._fused = False
-            self._fused_version = self._param_version()
+            self._fused_version = self._fused_amp_version = self._param_version()
         if self._fused is False:
             return None
         v = self._param_version()
-        if v != self._fused_version:
+        if need_phase and v != self._fused_version:
             self._fused.refresh()
-            self._fused_version = v
+            self._fused_version = self._fused_amp_version = v
+        elif not need_phase and v != self._fused_amp_version:
+            self._fused.refresh(amp_only=True)
+            self._fused_amp_version = v
+            self._fused_version = None
         return self._fused
 
     def _param_version(self):
@@ -178,7 +183,7 @@ class NAQSComplex_NADE_orbitals:
         architectures outside the fused family.  ``ret_keys`` appends the int64 keys of the states."""
         if ret_norm_reg:
             raise NotImplementedError("ret_norm_reg")
-        fused = self.fused() if use_fused in (None, True) else None
+        fused = self.fused(need_phase=False) if use_fused in (None, True) else None
         if use_fused and fused is None:
             raise NotImplementedError("fused sampler: network not on a HIP device or architecture not supported")
         keys = None

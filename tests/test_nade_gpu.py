@@ -185,3 +185,36 @@ def test_fused_logpsi_eloc_equals_separate_calls(mol):
     want = z["sgd_eloc_c128"]
     got = e.cpu().numpy()
     assert np.max(np.abs(got[:, 0] + 1j * got[:, 1] - want) / np.maximum(1, np.abs(want))) < 2e-5
+
+
+@pytest.mark.parametrize("mol", ["LiH", "H2O", "N2"])
+def test_fused_training_forward_backward_matches_autograd(mol):
+    """naqs_net_logamp / naqs_net_amp_backward (+ the phase MLP through torch) against PyTorch autograd of the
+    module formulation on the same weights: values 5e-5, every parameter gradient to 2e-4 of its scale."""
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    fused = FusedLogPsi(wf)
+    states = torch.tensor(z["eval_states"], device="cuda")
+    keys = keys_to_device(z["eval_keys"].astype(np.int64), "cuda")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g = torch.randn((len(keys), 2), device="cuda", generator=gen) / len(keys)
+    params = list(wf.model.parameters())
+
+    lp_ref = wf.log_psi(states).reshape(-1, 2)
+    grads_ref = torch.autograd.grad((lp_ref * g).sum(), params, allow_unused=True)
+    lp = fused.log_psi_train(keys)
+    grads = torch.autograd.grad((lp * g).sum(), params, allow_unused=True)
+    assert torch.max(torch.abs(lp - lp_ref)).item() < 5e-5
+    assert torch.equal(lp[:, 0], fused.log_psi(keys)[:, 0])              # same kernel as the inference path
+    for (name, _), a, b in zip(wf.model.named_parameters(), grads, grads_ref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, name
+            continue
+        scale = float(b.abs().max()) + 1e-12
+        assert a is not None and float((a - b).abs().max()) < 2e-4 * scale + 1e-9, (name, float((a - b).abs().max()), scale)
+    # determinism of the HIP backward
+    grads2 = torch.autograd.grad((fused.log_psi_train(keys) * g).sum(), params, allow_unused=True)
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads2) if a is not None)

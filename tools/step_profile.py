@@ -41,8 +41,10 @@ def step(record):
     keys_h = hil.state2idx(states).squeeze(-1)
     keys = keys_to_device(keys_h, dev)
     if record: t = tick("state2idx", t)
-    lp = wf.log_psi(states).reshape(-1, 2)
-    if record: t = tick("forward(torch)", t)
+    fused = wf.fused(need_phase=False)
+    if record: t = tick("repack", t)
+    lp = fused.log_psi_train(keys) if fused is not None else wf.log_psi(states).reshape(-1, 2)
+    if record: t = tick("forward", t)
     w = weights.to(dev, torch.float64)
     e_loc, sums = opt.pauli_hamiltonian.local_energy(keys, lp.detach(), kind="log_psi", weights=w)
     if record: t = tick("eloc", t)
