@@ -28,9 +28,8 @@ using naqs::WAVE;
 using naqs::DeviceGuard;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GB = 256;            // samples per tile = threads per workgroup
-constexpr int MAX_ACC_A = 16;      // (nin + 1) input columns incl. bias / (GB / Ha) per thread
-constexpr int MAX_ACC_B = 4;       // n_out / (GB / Ha) per thread
+constexpr int KSTEP = 4;           // threads per hidden unit: workgroup = tile = KSTEP * Ha samples (Ha = 64 -> 256)
+constexpr int GB_MAX = 256;
 constexpr int MAX_TILE_WGS = 64;   // workgroups per pair (each walks tiles blockIdx.x, +gridDim.x, ...)
 
 struct AmpSrc { int64_t off[MAXP]; };     // flat (state_dict) offset of pair n's parameters
@@ -45,42 +44,46 @@ __global__ __launch_bounds__(256) void logamp_sum_kernel(int P, int64_t M, const
     out[i] = s;
 }
 
-__device__ __forceinline__ float pre_activation(const float *__restrict__ row, int nin, uint32_t xbits, bool zero_input) {
-    float pre = row[nin];
-    if (!zero_input)
-        for (int k = 0; k < nin; ++k) pre += ((xbits >> k) & 1u) ? row[k] : -row[k];
-    return pre;
+// pre-activation of hidden unit `row` for the inputs x (compile-time width: fully unrolled, two FMA chains)
+template <int NIN>
+__device__ __forceinline__ float pre_activation(const float *__restrict__ row, const float (&x)[NIN]) {
+    float h0 = row[NIN], h1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k + 1 < NIN; k += 2) { h0 = fmaf(row[k], x[k], h0); h1 = fmaf(row[k + 1], x[k + 1], h1); }
+    if (NIN & 1) h0 = fmaf(row[NIN - 1], x[NIN - 1], h0);
+    return h0 + h1;
 }
 
-__global__ __launch_bounds__(GB) void amp_backward_kernel(const NetDims d, const float *__restrict__ w, const int64_t M,
-                                                          const uint64_t *__restrict__ keys, const float *__restrict__ g,
-                                                          float *__restrict__ partial, const int64_t partial_stride,
-                                                          const AmpSrc src) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = blockIdx.y;
-    const int nin = n == 0 ? 1 : 2 * n;
-    const int S = (nin + 1 + 5 + 3) & ~3;
-    const int Ha = d.Ha, nout = d.n_out_amp;
+// one orbital pair NB: all tiles of this workgroup.  smem: weights | d-pre tile [Ha][GB+1] | h tile [Ha][GB+1] |
+// d-out [5][GB] | input bits [GB]
+template <int NB>
+__device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float *__restrict__ w, const int64_t M,
+                                                  const uint64_t *__restrict__ keys, const float *__restrict__ g,
+                                                  float *__restrict__ out, float *smem) {
+    constexpr int NIN = NB == 0 ? 1 : 2 * NB;
+    constexpr int S = (NIN + 1 + 5 + 3) & ~3;
+    constexpr int NA = (NIN + 1 + KSTEP - 1) / KSTEP;     // input columns (incl. the bias column NIN) per thread
+    constexpr int NBACC = (5 + KSTEP - 1) / KSTEP;
+    const int Ha = d.Ha, nout = d.n_out_amp, GB = blockDim.x, LD = GB + 1;
     const int w_floats = (Ha * S + 8 + 3) & ~3;
     float *s_w = smem;
-    float *s_tile = s_w + w_floats;                       // [Ha][GB + 1]
-    float *s_do = s_tile + Ha * (GB + 1);                 // [5][GB]
-    uint32_t *s_x = reinterpret_cast<uint32_t *>(s_do + 5 * GB);   // [GB] input bits | bias bit
+    float *s_dpre = s_w + w_floats;
+    float *s_h = s_dpre + Ha * LD;
+    float *s_do = s_h + Ha * LD;
+    uint32_t *s_x = reinterpret_cast<uint32_t *>(s_do + 5 * GB);
     const int tid = threadIdx.x;
     {
-        const f32x4 *from = reinterpret_cast<const f32x4 *>(w + d.amp_off[n]);
+        const f32x4 *from = reinterpret_cast<const f32x4 *>(w + d.amp_off[NB]);
         f32x4 *to = reinterpret_cast<f32x4 *>(s_w);
         for (int e = tid; e < (Ha * S + 8) / 4; e += GB) to[e] = from[e];
     }
     const float *b2 = s_w + Ha * S;
-    const bool zero_input = n == 0;                       // pair 0 sees a constant-zero input (nade.py:509-511)
-    // parameter ownership of this thread (GB % Ha == 0, checked by the host)
-    const int j = tid % Ha, kbase = tid / Ha, kstep = GB / Ha;
-    float accA[MAX_ACC_A], accB[MAX_ACC_B], accC = 0.0f;
+    const int j = tid % Ha, kbase = tid / Ha;             // parameter ownership: hidden unit j, columns kbase + KSTEP m
+    float accA[NA], accB[NBACC], accC = 0.0f;
 #pragma unroll
-    for (int m = 0; m < MAX_ACC_A; ++m) accA[m] = 0.0f;
+    for (int m = 0; m < NA; ++m) accA[m] = 0.0f;
 #pragma unroll
-    for (int m = 0; m < MAX_ACC_B; ++m) accB[m] = 0.0f;
+    for (int m = 0; m < NBACC; ++m) accB[m] = 0.0f;
     __syncthreads();
 
     for (int64_t t0 = (int64_t)blockIdx.x * GB; t0 < M; t0 += (int64_t)gridDim.x * GB) {
@@ -88,29 +91,41 @@ __global__ __launch_bounds__(GB) void amp_backward_kernel(const NetDims d, const
         const bool valid = i < M;
         const uint64_t key = valid ? keys[i] : 0ull;
         uint32_t abits = 0, bbits = 0;
-        for (int k = 0; k < n; ++k) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
             abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
             bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
         }
-        const int occ = (int)((key >> d.qa[n]) & 1ull) + 2 * (int)((key >> d.qb[n]) & 1ull);
+        const int occ = (int)((key >> d.qa[NB]) & 1ull) + 2 * (int)((key >> d.qb[NB]) & 1ull);
         const bool swap = d.sym && abits > bbits;
         const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
-        const uint32_t xbits = first | (second << n);
+        float x[NIN];
+        if (NB == 0) {
+            x[0] = 0.0f;                                   // pair 0 sees a constant-zero input (nade.py:509-511)
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                x[k] = ((first >> k) & 1u) ? 1.0f : -1.0f;
+                x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
+            }
+        }
         const float gi = valid ? g[i] : 0.0f;
-        // forward of the block
+        // forward of the block; the hidden activations go to their tile
         float o[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) o[c] = c < nout ? b2[c] : 0.0f;
+#pragma unroll 2
         for (int jj = 0; jj < Ha; ++jj) {
             const float *row = s_w + jj * S;
-            const float h = fmaxf(pre_activation(row, nin, xbits, zero_input), 0.0f);
+            const float h = fmaxf(pre_activation<NIN>(row, x), 0.0f);
+            s_h[jj * LD + tid] = h;
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                if (c < nout) o[c] = fmaf(row[nin + 1 + c], h, o[c]);
+                if (c < nout) o[c] = fmaf(row[NIN + 1 + c], h, o[c]);
         }
         float la[4];
         bool ok[4];
-        naqs::amp_conditional(d, n, o, abits, bbits, la, ok);
+        naqs::amp_conditional(d, NB, o, abits, bbits, la, ok);
         // d la[occ] / d a4[c] = [c == occ] - softmax(2 a4)[c] on the allowed outcomes
         float da4[4];
         const bool live = valid && (occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3])));
@@ -133,45 +148,30 @@ __global__ __launch_bounds__(GB) void amp_backward_kernel(const NetDims d, const
         }
 #pragma unroll
         for (int c = 0; c < 5; ++c) s_do[c * GB + tid] = dout[c];
-        s_x[tid] = xbits | (1u << nin);                    // bit nin: the bias column
-        // d pre-activations -> tile
+        s_x[tid] = (NB == 0 ? 0u : (first | (second << NB))) | (1u << NIN);      // bit NIN: the bias column
+        // d pre-activations -> tile (h > 0 <=> pre > 0)
+#pragma unroll 4
         for (int jj = 0; jj < Ha; ++jj) {
             const float *row = s_w + jj * S;
-            const float pre = pre_activation(row, nin, xbits, zero_input);
             float dh = 0.0f;
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                if (c < nout) dh = fmaf(row[nin + 1 + c], dout[c], dh);
-            s_tile[jj * (GB + 1) + tid] = pre > 0.0f ? dh : 0.0f;
+                if (c < nout) dh = fmaf(row[NIN + 1 + c], dout[c], dh);
+            s_dpre[jj * LD + tid] = s_h[jj * LD + tid] > 0.0f ? dh : 0.0f;
         }
         __syncthreads();
-        // dW1[j][k], db1[j] (k == nin): walk the tile's samples
+        // walk the tile's samples: dW1[j][k] and db1[j] (k == NIN) from d-pre, dW2[c][j] from h, db2[c] from d-out
         {
-            const float *col = s_tile + j * (GB + 1);
+            const float *cp = s_dpre + j * LD, *ch = s_h + j * LD;
+#pragma unroll 4
             for (int s = 0; s < GB; ++s) {
-                const float v = col[s];
+                const float v = cp[s], h = ch[s];
                 const uint32_t xb = s_x[s];
 #pragma unroll
-                for (int m = 0; m < MAX_ACC_A; ++m) {
-                    const int k = kbase + m * kstep;
-                    accA[m] += ((xb >> (k & 31)) & 1u) ? v : -v;
-                }
-            }
-        }
-        __syncthreads();
-        // hidden activations -> tile
-        for (int jj = 0; jj < Ha; ++jj) {
-            const float *row = s_w + jj * S;
-            s_tile[jj * (GB + 1) + tid] = fmaxf(pre_activation(row, nin, xbits, zero_input), 0.0f);
-        }
-        __syncthreads();
-        {
-            const float *col = s_tile + j * (GB + 1);
-            for (int s = 0; s < GB; ++s) {
-                const float h = col[s];
+                for (int m = 0; m < NA; ++m) accA[m] += ((xb >> (kbase + m * KSTEP)) & 1u) ? v : -v;
 #pragma unroll
-                for (int m = 0; m < MAX_ACC_B; ++m) {
-                    const int c = kbase + m * kstep;
+                for (int m = 0; m < NBACC; ++m) {
+                    const int c = kbase + m * KSTEP;
                     if (c < nout) accB[m] = fmaf(s_do[c * GB + s], h, accB[m]);
                 }
             }
@@ -181,20 +181,35 @@ __global__ __launch_bounds__(GB) void amp_backward_kernel(const NetDims d, const
         __syncthreads();
     }
 
-    // partial sums of this workgroup in state_dict order: W1 [Ha][nin], b1 [Ha], W2 [nout][Ha], b2 [nout]
+    // partial sums of this workgroup in state_dict order: W1 [Ha][NIN], b1 [Ha], W2 [nout][Ha], b2 [nout]
+#pragma unroll
+    for (int m = 0; m < NA; ++m) {
+        const int k = kbase + m * KSTEP;
+        if (k < NIN) out[j * NIN + k] = NB == 0 ? 0.0f : accA[m];
+        else if (k == NIN) out[Ha * NIN + j] = accA[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NBACC; ++m) {
+        const int c = kbase + m * KSTEP;
+        if (c < nout) out[Ha * NIN + Ha + c * Ha + j] = accB[m];
+    }
+    if (tid < nout) out[Ha * NIN + Ha + nout * Ha + tid] = accC;
+}
+
+__global__ __launch_bounds__(GB_MAX) void amp_backward_kernel(const NetDims d, const float *__restrict__ w, const int64_t M,
+                                                              const uint64_t *__restrict__ keys, const float *__restrict__ g,
+                                                              float *__restrict__ partial, const int64_t partial_stride,
+                                                              const AmpSrc src) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockIdx.y;
     float *out = partial + (int64_t)blockIdx.x * partial_stride + src.off[n];
-#pragma unroll
-    for (int m = 0; m < MAX_ACC_A; ++m) {
-        const int k = kbase + m * kstep;
-        if (k < nin) out[j * nin + k] = zero_input ? 0.0f : accA[m];
-        else if (k == nin) out[Ha * nin + j] = accA[m];
+    switch (n) {
+#define CASE(NB) case NB: amp_backward_pair<NB>(d, w, M, keys, g, out, smem); break;
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
+        CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+#undef CASE
+        default: break;
     }
-#pragma unroll
-    for (int m = 0; m < MAX_ACC_B; ++m) {
-        const int c = kbase + m * kstep;
-        if (c < nout) out[Ha * nin + Ha + c * Ha + j] = accB[m];
-    }
-    if (tid < nout) out[Ha * nin + Ha + nout * Ha + tid] = accC;
 }
 
 __global__ __launch_bounds__(256) void amp_reduce_kernel(int64_t count, int n_partials, int64_t partial_stride,
@@ -236,9 +251,8 @@ NAQS_API int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *k
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
     if (!net->have_amp_weights) return NAQS_ERR_INVALID;
     const NetDims &d = net->dims;
-    if (d.Ha > GB || GB % d.Ha != 0) return NAQS_ERR_UNSUPPORTED;
-    const int kstep = GB / d.Ha, nin_max = 2 * (d.P - 1);
-    if ((nin_max + 1 + kstep - 1) / kstep > MAX_ACC_A || (d.n_out_amp + kstep - 1) / kstep > MAX_ACC_B) return NAQS_ERR_UNSUPPORTED;
+    const int GB = KSTEP * d.Ha;                           // one workgroup = one tile of KSTEP * Ha samples
+    if (GB > GB_MAX || GB < 64 || (GB & 63)) return NAQS_ERR_UNSUPPORTED;       // Ha in {16, 32, 48, 64}
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
@@ -252,8 +266,9 @@ NAQS_API int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *k
     if (!net->d_gpart) {
         HIP_TRY(hipMalloc((void **)&net->d_gpart, (size_t)MAX_TILE_WGS * stride * sizeof(float)));
     }
+    const int nin_max = 2 * (d.P - 1);
     const int S_max = (nin_max + 1 + 5 + 3) & ~3;
-    const size_t lds = ((size_t)((d.Ha * S_max + 8 + 3) & ~3) + (size_t)d.Ha * (GB + 1) + 5 * GB + GB) * sizeof(float);
+    const size_t lds = ((size_t)((d.Ha * S_max + 8 + 3) & ~3) + 2 * (size_t)d.Ha * (GB + 1) + 5 * GB + GB) * sizeof(float);
     if (lds > 160 * 1024) return NAQS_ERR_UNSUPPORTED;
     if (!net->grad_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -44,6 +44,13 @@ class _LogAmp(torch.autograd.Function):
         return (None, None, *grads)
 
 
+def _accumulate(p, grad):
+    if p.grad is None:
+        p.grad = grad
+    else:
+        p.grad.add_(grad)
+
+
 class FusedLogPsi:
     def __init__(self, wavefunction):
         wf, m = wavefunction, wavefunction.model
@@ -116,6 +123,53 @@ class FusedLogPsi:
         occ = ((keys >> self._last_a) & 1) + 2 * ((keys >> self._last_b) & 1)
         phase = out.gather(1, occ.unsqueeze(1)).squeeze(1)
         return torch.stack([log_amp, phase], -1)
+
+    # ---- training step without the autograd engine --------------------------------------------------------
+    @torch.no_grad()
+    def forward_saved(self, keys):
+        """log psi [M, 2] of int64 device keys plus what ``backward_saved`` needs (phase activations), evaluated
+        without recording an autograd graph: HIP amplitude kernels + one addmm/relu per phase layer."""
+        m = self.wf.model
+        keys = keys.contiguous()
+        M = keys.shape[0]
+        log_amp = torch.empty(M, dtype=torch.float32, device=self.device)
+        st = self._lib.naqs_net_logamp(self._h, M, keys.data_ptr(), log_amp.data_ptr(), _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_logamp")
+        lin = m.phase_layers[0].linears()
+        acts = [((keys.unsqueeze(-1) >> self._phase_shifts) & 1).to(torch.float32).mul_(2.0).sub_(1.0)]
+        for layer in lin[:-1]:
+            acts.append(torch.addmm(layer.bias, acts[-1], layer.weight.t()).relu_())
+        out = torch.addmm(lin[-1].bias, acts[-1], lin[-1].weight.t())
+        occ = (((keys >> self._last_a) & 1) + 2 * ((keys >> self._last_b) & 1)).unsqueeze(1)
+        log_psi = torch.stack([log_amp, out.gather(1, occ).squeeze(1)], -1)
+        return log_psi, (keys, acts, occ)
+
+    @torch.no_grad()
+    def backward_saved(self, saved, g):
+        """Accumulate d/d theta sum_i (g[i, 0] log|psi_i| + g[i, 1] phase_i) into the ``.grad`` of every network
+        parameter: ``naqs_net_amp_backward`` for the amplitude blocks, the phase MLP's chain rule as plain GEMMs
+        (what autograd would run for three Linear layers, without building or walking a graph)."""
+        keys, acts, occ = saved
+        m = self.wf.model
+        g = g.to(torch.float32)
+        flat = torch.empty(self.n_amp_params, dtype=torch.float32, device=self.device)
+        ga = g[:, 0].contiguous()
+        st = self._lib.naqs_net_amp_backward(self._h, keys.shape[0], keys.data_ptr(), ga.data_ptr(), flat.data_ptr(),
+                                              _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_amp_backward")
+        off = 0
+        for p in self._amp_params:
+            n = p.numel()
+            _accumulate(p, flat[off:off + n].view(p.shape))
+            off += n
+        lin = m.phase_layers[0].linears()
+        delta = torch.zeros((keys.shape[0], lin[-1].out_features), dtype=torch.float32, device=self.device)
+        delta.scatter_(1, occ, g[:, 1:2])
+        for l in range(len(lin) - 1, -1, -1):
+            _accumulate(lin[l].weight, delta.t() @ acts[l])
+            _accumulate(lin[l].bias, delta.sum(0))
+            if l > 0:
+                delta = (delta @ lin[l].weight).mul_(acts[l] > 0)
 
     def log_psi(self, keys, out=None):
         """keys: int64 device tensor [M] (uint64 bit patterns, qubit order) -> float32 [M, 2]."""

@@ -115,7 +115,10 @@ class OptimizerBase:
                 a = dict(a)
                 a['params'] = self.wavefunction.parameters(idx)
                 groups.append(a)
-            self.optimizer = self.optimizer_callable(groups)
+            extra = {}
+            if self.optimizer_callable is torch.optim.Adam and self.device.type == "cuda" and any(len(g['params']) for g in groups):
+                extra['fused'] = True         # one multi-tensor kernel per step instead of ~10 foreach launches
+            self.optimizer = self.optimizer_callable(groups, **extra)
         self.scheduler = (self.scheduler_callable(self.optimizer, **self.scheduler_args)
                           if self.scheduler_callable is not None else None)
 
@@ -167,6 +170,7 @@ class OptimizerBase:
             self.sampled_idxs.update(keys.cpu().numpy().tolist())
         # shard of rows this rank owns (the whole table when single-process)
         b, e_ = shard_bounds(M, rank, world)
+        saved = None
         if log_psi is not None:
             # reference-style call: log psi of the whole table, carrying gradients
             lp_all, lp_mine = log_psi.reshape(-1, 2), log_psi.reshape(-1, 2)[b:e_]
@@ -174,7 +178,10 @@ class OptimizerBase:
             # gradients only for the owned rows; the table needed for the psi look-ups is evaluated
             # without autograd (the rows of other ranks are theirs to differentiate)
             fused = self.wavefunction.fused(need_phase=world > 1) if self.use_fused else None
-            if fused is not None:           # HIP forward/backward of the amplitude blocks, keys in, no state tensors
+            if fused is not None and regularisation_loss is None and not self.normalize_grads:
+                # HIP amplitude forward/backward + explicit chain rule of the phase MLP: no autograd graph at all
+                lp_mine, saved = fused.forward_saved(keys[b:e_])
+            elif fused is not None:         # same kernels behind a torch.autograd.Function
                 lp_mine = fused.log_psi_train(keys[b:e_])
             else:
                 lp_mine = self.wavefunction.log_psi(states[b:e_]).reshape(-1, 2)
@@ -200,14 +207,22 @@ class OptimizerBase:
             dist.all_reduce(sums)
         e_mean = torch.stack([sums[0], sums[1]])                        # (sum w E_loc), like energy.py:328 (w not renormalised)
 
-        loss = vmc_loss(lp_mine, e_loc.to(lp_mine.dtype), w[b:e_].to(lp_mine.dtype), e_mean.to(lp_mine.dtype))
         self.optimizer.zero_grad()
-        if self.normalize_grads:
-            loss = loss / loss.detach().abs()
-        if regularisation_loss is not None:
-            loss = loss + regularisation_loss
-        loss.backward()
-        self.last_loss = loss.detach()
+        if saved is not None:
+            # d loss / d log psi of vmc_loss, written out: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>))
+            ec = e_loc.to(torch.float32) - e_mean.to(torch.float32)
+            g = ec.mul_(2.0 * w[b:e_].to(torch.float32).unsqueeze(1))
+            g[:, 1].neg_()
+            self.last_loss = (g * lp_mine).sum()
+            fused.backward_saved(saved, g)
+        else:
+            loss = vmc_loss(lp_mine, e_loc.to(lp_mine.dtype), w[b:e_].to(lp_mine.dtype), e_mean.to(lp_mine.dtype))
+            if self.normalize_grads:
+                loss = loss / loss.detach().abs()
+            if regularisation_loss is not None:
+                loss = loss + regularisation_loss
+            loss.backward()
+            self.last_loss = loss.detach()
         if dist:
             params = [p for g in self.optimizer.param_groups for p in g['params'] if p.grad is not None]
             flat = torch.cat([p.grad.reshape(-1) for p in params])
@@ -217,6 +232,7 @@ class OptimizerBase:
                 p.grad.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
         self.optimizer.step()
+        self.wavefunction.parameters_changed()
         self.optimizer.zero_grad()
         if self.scheduler is not None:
             self.scheduler.step()

@@ -77,6 +77,7 @@ class NAQSComplex_NADE_orbitals:
         self.model.train()
         self.model.predict()
         self._fused, self._fused_version, self._fused_amp_version = None, None, None
+        self._param_epoch = 0
 
     # ---- mode helpers (wavefunction.py:90-100)
     def train_model(self):
@@ -173,7 +174,12 @@ class NAQSComplex_NADE_orbitals:
         return self._fused
 
     def _param_version(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        return (self._param_epoch,) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def parameters_changed(self):
+        """Tell the fused kernels that the parameters were modified by something that does not bump the tensors'
+        version counters (the multi-tensor fused optimisers write through raw pointers)."""
+        self._param_epoch += 1
 
     def sample(self, num_samples=1, ret_probs=True, ret_log_psi=True, ret_norm_reg=False, eval_mode=False,
                max_batch_size=None, generator=None, use_fused=None, ret_keys=False):

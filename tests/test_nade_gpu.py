@@ -218,3 +218,32 @@ def test_fused_training_forward_backward_matches_autograd(mol):
     # determinism of the HIP backward
     grads2 = torch.autograd.grad((fused.log_psi_train(keys) * g).sum(), params, allow_unused=True)
     assert all(torch.equal(a, b) for a, b in zip(grads, grads2) if a is not None)
+
+
+@pytest.mark.parametrize("mol", ["LiH", "N2"])
+def test_graph_free_training_step_matches_autograd(mol):
+    """forward_saved / backward_saved (no autograd engine) give the same values and .grad as the Function path."""
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    fused = FusedLogPsi(wf)
+    keys = keys_to_device(z["eval_keys"].astype(np.int64), "cuda")
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    g = torch.randn((len(keys), 2), device="cuda", generator=gen) / len(keys)
+    params = list(wf.model.parameters())
+    lp_ref = fused.log_psi_train(keys)
+    grads_ref = torch.autograd.grad((lp_ref * g).sum(), params, allow_unused=True)
+    for p in params:
+        p.grad = None
+    lp, saved = fused.forward_saved(keys)
+    assert not lp.requires_grad and torch.allclose(lp, lp_ref.detach(), rtol=0, atol=1e-6)
+    fused.backward_saved(saved, g)
+    for (name, p), b in zip(wf.model.named_parameters(), grads_ref):
+        assert p.grad is not None, name
+        ref = torch.zeros_like(p) if b is None else b
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((p.grad - ref).abs().max()) < 1e-5 * scale + 1e-10, (name, float((p.grad - ref).abs().max()), scale)
+    fused.backward_saved(saved, g)                               # accumulates like autograd does
+    assert torch.allclose(params[-1].grad, 2 * grads_ref[-1], rtol=1e-5, atol=1e-10)

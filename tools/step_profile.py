@@ -43,17 +43,21 @@ def step(record):
     if record: t = tick("state2idx", t)
     fused = wf.fused(need_phase=False)
     if record: t = tick("repack", t)
-    lp = fused.log_psi_train(keys) if fused is not None else wf.log_psi(states).reshape(-1, 2)
+    lp, saved = fused.forward_saved(keys)
     if record: t = tick("forward", t)
     w = weights.to(dev, torch.float64)
-    e_loc, sums = opt.pauli_hamiltonian.local_energy(keys, lp.detach(), kind="log_psi", weights=w)
+    e_loc, sums = opt.pauli_hamiltonian.local_energy(keys, lp, kind="log_psi", weights=w)
     if record: t = tick("eloc", t)
     e_mean = torch.stack([sums[0], sums[1]])
-    loss = vmc_loss(lp, e_loc.to(lp.dtype), w.to(lp.dtype), e_mean.to(lp.dtype))
     opt.optimizer.zero_grad()
-    loss.backward()
+    ec = e_loc.to(torch.float32) - e_mean.to(torch.float32)
+    g = ec.mul_(2.0 * w.to(torch.float32).unsqueeze(1))
+    g[:, 1].neg_()
+    if record: t = tick("loss-grad", t)
+    fused.backward_saved(saved, g)
     if record: t = tick("backward", t)
     opt.optimizer.step()
+    wf.parameters_changed()
     if record: t = tick("adam", t)
     e = float((sums[0] / sums[3]).item())
     if record: t = tick("item", t)
