@@ -240,6 +240,26 @@ int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float 
 int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev,
                           void *stream);
 
+/* The whole network, forward and backward, for one batch of keys (no autograd graph):
+ *   naqs_net_train_forward   = naqs_net_logpsi, and the phase MLP's inputs / hidden activations stay in the handle;
+ *   naqs_net_train_backward  g_dev [M][2] float32 = d loss / d (log|psi_i|, phase_i)  ->  grad_dev [naqs_net_param_count]
+ *                            float32 = d loss / d theta in state_dict order (amplitude blocks via naqs_net_amp_backward,
+ *                            the phase Linear/ReLU stack as f32-MFMA GEMMs).  Must follow naqs_net_train_forward of the
+ *                            SAME keys with no naqs_net_set_weights in between.  Deterministic. */
+int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream);
+int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev,
+                            void *stream);
+/* Inputs of the phase block from key bits: x_dev [M][2 (n_qubits/2 - 1)] float32 (+-1 occupations: alpha strings of
+ * model pairs 0..P-2, then beta), occ_dev [M] int64 = realised outcome (alpha + 2 beta) of the last pair, which selects
+ * the phase output (nade.py:563-569). */
+int naqs_net_phase_inputs(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *x_dev, int64_t *occ_dev,
+                          void *stream);
+/* g_dev [M][2] float32 = d loss / d (log|psi_i|, phase_i) of the VMC loss 2 Re sum_i w_i log psi_i (E_loc_i - <E>)^*
+ * (energy.py:328-329), <E> = (sums_dev[0], sums_dev[1]) as produced by naqs_eloc_reduce, evaluated in float32 like
+ * the reference: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>)).  eloc_dev [M][2] float64, w_dev [M] float64. */
+int naqs_vmc_loss_grad(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
+                       void *stream);
+
 /* Host evaluation of the sampler's generators, for known-answer and statistical tests (no device needed):
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */
 int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out);

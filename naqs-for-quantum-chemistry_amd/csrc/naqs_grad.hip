@@ -221,8 +221,60 @@ __global__ __launch_bounds__(256) void amp_reduce_kernel(int64_t count, int n_pa
     out[e] = s;
 }
 
+// inputs of the phase block from key bits: x[i][c] = +-1 occupation of (alpha of model pairs 0..P-2 | beta of the same),
+// occ[i] = realised outcome of the last pair (selects the phase output, nade.py:563-569)
+__global__ __launch_bounds__(256) void phase_inputs_kernel(const NetDims d, const int64_t M, const uint64_t *__restrict__ keys,
+                                                           float *__restrict__ x, int64_t *__restrict__ occ) {
+    const int W = 2 * (d.P - 1);
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * W) return;
+    const int64_t i = e / W;
+    const int c = (int)(e - i * W);
+    const uint64_t key = keys[i];
+    const int bit = c < d.P - 1 ? d.qa[c] : d.qb[c - (d.P - 1)];
+    x[e] = ((key >> bit) & 1ull) ? 1.0f : -1.0f;
+    if (c == 0) occ[i] = (int64_t)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int64_t)((key >> d.qb[d.P - 1]) & 1ull);
+}
+
+// d loss / d (log|psi|, phase) of the VMC loss 2 Re sum_i w_i log psi_i (E_loc_i - <E>)^* in the reference's float32
+// arithmetic (energy.py:328-329 with complex.py:49-58): g = (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>))
+__global__ __launch_bounds__(256) void vmc_grad_kernel(const int64_t M, const double2 *__restrict__ eloc,
+                                                       const double *__restrict__ w, const double *__restrict__ sums,
+                                                       float2 *__restrict__ g) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float m_re = (float)sums[0], m_im = (float)sums[1];
+    const double2 e = eloc[i];
+    const float two_w = 2.0f * (float)w[i];
+    g[i] = make_float2(((float)e.x - m_re) * two_w, -(((float)e.y - m_im) * two_w));
+}
+
 // the amp kernel of naqs_logpsi.hip is reached through naqs::net_amp_forward
 }  // namespace
+
+NAQS_API int naqs_net_phase_inputs(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *x_dev, int64_t *occ_dev,
+                                   void *stream) {
+    if (!net || M < 0 || (M > 0 && (!keys_dev || !x_dev || !occ_dev))) return NAQS_ERR_INVALID;
+    if (M == 0) return NAQS_OK;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    const int64_t total = M * 2 * (net->dims.P - 1);
+    hipLaunchKernelGGL(phase_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       net->dims, M, keys_dev, x_dev, occ_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_vmc_loss_grad(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
+                                void *stream) {
+    if (M < 0 || (M > 0 && (!eloc_dev || !w_dev || !sums_dev || !g_dev))) return NAQS_ERR_INVALID;
+    if (M == 0) return NAQS_OK;
+    hipLaunchKernelGGL(vmc_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M,
+                       reinterpret_cast<const double2 *>(eloc_dev), w_dev, sums_dev, reinterpret_cast<float2 *>(g_dev));
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
 
 NAQS_API int naqs_net_amp_param_count(const naqs_net_t *net, int64_t *count) {
     if (!net || !count) return NAQS_ERR_INVALID;

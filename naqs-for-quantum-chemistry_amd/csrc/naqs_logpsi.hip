@@ -380,7 +380,10 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
 template <int RB>
 __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int ldh, int Kh_pad, int N_pad,
                                             const ushort_t *__restrict__ W, const float *__restrict__ bias, bool last,
-                                            int wave, int lane) {
+                                            int wave, int lane, float *__restrict__ save = nullptr, int save_ld = 0,
+                                            int64_t row0 = 0, int64_t M = 0) {
+    // save != nullptr (training forward): the post-ReLU activations of this hidden layer also go to HBM
+    // ([M][save_ld] float32) for the backward pass
     constexpr int BM = RB * 16;
     const int m = lane & 15, kg = lane >> 4;
     const int ncb = N_pad >> 4;
@@ -427,9 +430,11 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
                 if (last) part[t] = v[u];                          // f32 [BM][16]
                 else {
                     ushort_t h1, h2, h3;
-                    split3(fmaxf(v[u], 0.0f), h1, h2, h3);
+                    const float hv = fmaxf(v[u], 0.0f);
+                    split3(hv, h1, h2, h3);
                     const int o = (t >> 4) * ldh + (t & 15);
                     planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
+                    if (save != nullptr && row0 + (t >> 4) < M) save[(row0 + (t >> 4)) * save_ld + (t & 15)] = hv;
                 }
             }
         }
@@ -456,9 +461,12 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ushort_t h1, h2, h3;
-                    split3(fmaxf(acc[rb][c][r] + bv, 0.0f), h1, h2, h3);
-                    const int o = (rb * 16 + kg * 4 + r) * ldh + col;
+                    const float hv = fmaxf(acc[rb][c][r] + bv, 0.0f);
+                    split3(hv, h1, h2, h3);
+                    const int row = rb * 16 + kg * 4 + r;
+                    const int o = row * ldh + col;
                     planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
+                    if (save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = hv;
                 }
         }
     }
@@ -470,7 +478,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
                                                                   const ushort_t *__restrict__ wh, int64_t M,
                                                                   const uint64_t *__restrict__ keys,
                                                                   const float *__restrict__ scratch,
-                                                                  float2 *__restrict__ out, const ElocFeed feed) {
+                                                                  float2 *__restrict__ out, const ElocFeed feed,
+                                                                  const naqs::PhaseSave save) {
     extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
     constexpr int BM = RB * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
             const uint64_t key = keys[i];
             const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
             v = ((key >> q) & 1ull) ? (ushort_t)0x3F80 : (ushort_t)0xBF80;      // +1.0 / -1.0
+            if (save.x != nullptr) save.x[i * save.x_ld + k] = ((key >> q) & 1ull) ? 1.0f : -1.0f;
         }
         planes[r * ldh + k] = v;
         planes[BM * ldh + r * ldh + k] = 0;
@@ -499,7 +509,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     __syncthreads();
 
     for (int l = 0; l < d.n_lin; ++l)
-        mlp_layer_h<RB>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane);
+        mlp_layer_h<RB>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
+                        l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M);
 
     if (tid < BM) {
         const int64_t i = row0 + tid;
@@ -694,6 +705,8 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_scratch) (void)hipFree(net->d_scratch);
     if (net->d_samp) (void)hipFree(net->d_samp);
     if (net->d_gpart) (void)hipFree(net->d_gpart);
+    if (net->d_train) (void)hipFree(net->d_train);
+    if (net->d_wb) (void)hipFree(net->d_wb);
     delete net;
     return NAQS_OK;
 }
@@ -719,7 +732,7 @@ NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, in
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
-    net->have_weights = false;               // the packed phase layers no longer belong to these parameters
+    net->have_weights = net->have_wb = false;   // the packed phase layers no longer belong to these parameters
     net->have_amp_weights = false;
     st = pack_amp_blocks(net, flat_dev, reinterpret_cast<hipStream_t>(stream));
     if (st != NAQS_OK) return st;
@@ -734,7 +747,7 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const NetDims &d = net->dims;
-    net->have_weights = net->have_amp_weights = false;
+    net->have_weights = net->have_amp_weights = net->have_wb = false;
     st = pack_amp_blocks(net, flat_dev, s);
     if (st != NAQS_OK) return st;
     for (int l = 0; l < d.n_lin; ++l) {
@@ -749,6 +762,8 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
                            d.Kh_pad[l], d.N_pad[l], net->d_wh + d.wh_off[l]);
         HIP_TRY(hipGetLastError());
     }
+    st = naqs::net_pack_backward_weights(net, flat_dev, s);
+    if (st != NAQS_OK) return st;
     net->have_weights = net->have_amp_weights = true;
     return NAQS_OK;
 }
@@ -772,8 +787,8 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
     return NAQS_OK;
 }
 
-static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
-                           const ElocFeed &feed) {
+int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
+                          const ElocFeed &feed, const PhaseSave &save) {
     if (!net || M < 0 || (M > 0 && (!keys_dev || !logpsi_dev))) return NAQS_ERR_INVALID;
     if (!net->have_weights) return NAQS_ERR_INVALID;
     if (M == 0) return NAQS_OK;
@@ -790,6 +805,7 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
     const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA
     const size_t lds_h16 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
     const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;
+    if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the bf16x3 kernel only
     const int rb_max = use_h ? 3 : 4;
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
     if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
@@ -801,9 +817,9 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
     if (use_h) {
         const size_t lds = rb * lds_h16;
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
-            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
-            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed); break;
+            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save); break;
+            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save); break;
+            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save); break;
         }
     } else {
         const size_t lds = (size_t)bm * d.ld * sizeof(float);
@@ -821,7 +837,7 @@ static int net_logpsi_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev,
 
 NAQS_API int naqs_net_logpsi(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream) {
     ElocFeed none{};
-    return net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, none);
+    return naqs::net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, none, naqs::PhaseSave{});
 }
 
 NAQS_API int naqs_logpsi_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev,
@@ -841,7 +857,7 @@ NAQS_API int naqs_logpsi_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const
     ElocFeed feed{};
     st = naqs::eloc_begin(ham, M, s, &feed);
     if (st != NAQS_OK) return st;
-    st = net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, feed);      // amp kernel feeds keys, phase kernel feeds psi
+    st = naqs::net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, feed, naqs::PhaseSave{});      // amp kernel feeds keys, phase kernel feeds psi
     if (st != NAQS_OK) return st;
     return naqs::eloc_main(ham, M, feed, eloc_dev, w_dev, out4_dev, s);
 }

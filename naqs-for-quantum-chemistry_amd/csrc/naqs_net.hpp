@@ -149,12 +149,28 @@ struct naqs_net {
     bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
+    void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)
+    int64_t train_cap = 0;                  // rows the training scratch holds
+    float *d_wb = nullptr;                  // phase weights row-major [N_pad64][K_pad64] per layer (backward GEMMs)
+    bool have_wb = false;
     bool grad_attr_set = false;
     naqs::EventRing prof;
 };
 
 namespace naqs {
 struct ElocFeed;
+// where the training forward leaves what the backward pass needs (all nullptr: inference)
+struct PhaseSave {
+    float *x = nullptr;                     // [M][x_ld] +-1 inputs of the phase block (columns >= 2(P-1) stay zero)
+    int x_ld = 0;
+    float *act[MAXL] = {};                  // post-ReLU activations of hidden layer l: [M][act_ld[l]]
+    int act_ld[MAXL] = {};
+};
+// naqs_logpsi.hip: amp_kernel + phase kernel -> (log|psi|, phase)
+int net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
+                    const ElocFeed &feed, const PhaseSave &save);
+// naqs_phase_grad.hip: row-major padded copies of the phase weights for the backward GEMMs
+int net_pack_backward_weights(naqs_net *net, const float *flat_dev, hipStream_t s);
 // naqs_logpsi.hip: grow the [P][M] scratch and launch amp_kernel (feed == nullptr: no E_loc hand-over)
 int net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed = nullptr);
 }  // namespace naqs

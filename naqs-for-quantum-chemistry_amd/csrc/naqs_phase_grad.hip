@@ -1,0 +1,373 @@
+// naqs_phase_grad.hip — training forward/backward of the whole orbital NADE in one library call each, gfx950.
+//
+//   naqs_net_train_forward   keys -> (log|psi|, phase) like naqs_net_logpsi, and the phase MLP's inputs and hidden
+//                            activations are left in HBM for the backward pass
+//   naqs_net_train_backward  g = d loss / d (log|psi|, phase) per sample -> d loss / d theta for every parameter, flat
+//                            in state_dict order
+//
+// This is the graph torch.autograd builds for the reference's loss.backward() (src/optimizer/energy.py:329-343 through
+// src/naqs/network/nade.py:738-770).  The amplitude blocks are naqs_grad.hip; the phase block (Linear/ReLU stack, e.g.
+// 18 -> 512 -> 512 -> 4) is two GEMM-shaped kernels per layer on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact
+// f32, the precision autograd would use):
+//
+//   grad_w_kernel    dW_l[n][k] = sum_i delta_l[i][n] * in_l[i][k]  (+ db_l[n] = sum_i delta_l[i][n]): 64 x 64 output
+//                    block per workgroup, the sample axis split into slices (one per blockIdx.z) whose partial
+//                    blocks are added in fixed order by grad_w_reduce_kernel -> deterministic, no float atomics.
+//   grad_in_kernel   delta_{l-1}[i][k] = [in_l[i][k] > 0] * sum_n delta_l[i][n] * W_l[n][k]: 64 samples x 64 columns per
+//                    workgroup, ReLU mask fused into the write-back.
+//
+// Both stage 32-deep operand chunks in LDS (row strides chosen so that the 64 MFMA operand reads of a wave hit
+// 32 distinct banks per half-wave) and give each of the 4 waves a 32 x 32 sub-block (2 x 2 MFMA tiles).  All
+// matrices live in zero-padded buffers whose leading dimensions are multiples of 64, so there is no edge code.
+
+#include <algorithm>
+#include <cstdint>
+
+#include "naqs_common.hpp"
+#include "naqs_hash.hpp"
+#include "naqs_net.hpp"
+
+namespace {
+
+using naqs::MAXL;
+using naqs::NetDims;
+using naqs::DeviceGuard;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TB = 64;       // output block edge
+constexpr int CH = 32;       // reduction chunk staged in LDS
+constexpr int LDT = 80;      // row stride of a [CH][64] tile: 80 = 16 mod 32 -> lanes (k, k+1) x 16 columns cover 32 banks
+constexpr int LDD = 34;      // row stride of a [64][CH] tile: bank = 2 row + k -> conflict-free for 16 rows x 2 k
+
+inline int pad64(int x) { return (x + 63) & ~63; }
+
+// delta of the output layer: only the realised outcome of the last pair carries the phase gradient
+__global__ __launch_bounds__(256) void top_delta_kernel(const NetDims d, const int64_t M, const uint64_t *__restrict__ keys,
+                                                        const float2 *__restrict__ g, float *__restrict__ delta, const int ld) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * ld) return;
+    const int64_t i = e / ld;
+    const int c = (int)(e - i * ld);
+    const uint64_t key = keys[i];
+    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    delta[e] = c == occ ? g[i].y : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void split_g_kernel(const int64_t M, const float2 *__restrict__ g, float *__restrict__ g_amp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < M) g_amp[i] = g[i].x;
+}
+
+// Cpart[z][n][k] = sum_{i in slice z} P[i][n] Q[i][k];  Bpart[z][n] = sum_{i in slice z} P[i][n]
+__global__ __launch_bounds__(256) void grad_w_kernel(const float *__restrict__ P, const int ldp, const float *__restrict__ Q,
+                                                     const int ldq, const int64_t M, const int64_t rows_per_slice,
+                                                     float *__restrict__ Cpart, const int Np, const int Kp,
+                                                     float *__restrict__ Bpart) {
+    __shared__ __attribute__((aligned(16))) float Ps[CH * LDT];
+    __shared__ __attribute__((aligned(16))) float Qs[CH * LDT];
+    const int n0 = blockIdx.x * TB, k0 = blockIdx.y * TB, z = blockIdx.z;
+    const int64_t i_beg = (int64_t)z * rows_per_slice, i_end = min(M, i_beg + rows_per_slice);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1, lm = lane & 15, lq = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+    for (int64_t i0 = i_beg; i0 < i_end; i0 += CH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u, r = e >> 4, c4 = e & 15;
+            const int64_t i = i0 + r;
+            f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f}, vq = vp;
+            if (i < i_end) {
+                vp = *reinterpret_cast<const f32x4 *>(P + i * ldp + n0 + 4 * c4);
+                vq = *reinterpret_cast<const f32x4 *>(Q + i * ldq + k0 + 4 * c4);
+            }
+            *reinterpret_cast<f32x4 *>(Ps + r * LDT + 4 * c4) = vp;
+            *reinterpret_cast<f32x4 *>(Qs + r * LDT + 4 * c4) = vq;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < CH / 4; ++ks) {
+            const int kk = ks * 4 + lq;
+            const float a0 = Ps[kk * LDT + wn * 32 + lm], a1 = Ps[kk * LDT + wn * 32 + 16 + lm];
+            const float b0 = Qs[kk * LDT + wk * 32 + lm], b1 = Qs[kk * LDT + wk * 32 + 16 + lm];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            bsum[0] += a0;
+            bsum[1] += a1;
+        }
+        __syncthreads();
+    }
+    // C/D layout: column = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + tn * 16 + 4 * lq + r, k = k0 + wk * 32 + tk * 16 + lm;
+                Cpart[((int64_t)z * Np + n) * Kp + k] = acc[tn][tk][r];
+            }
+    if (blockIdx.y == 0 && wk == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = bsum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) Bpart[(int64_t)z * Np + n0 + wn * 32 + t * 16 + lane] = v;
+        }
+    }
+}
+
+// slices -> dW [N][K] and db [N] (unpadded, state_dict layout)
+__global__ __launch_bounds__(256) void grad_w_reduce_kernel(const float *__restrict__ Cpart, const float *__restrict__ Bpart,
+                                                            const int slices, const int Np, const int Kp, const int N, const int K,
+                                                            float *__restrict__ dW, float *__restrict__ db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < N * K) {
+        const int n = e / K, k = e - n * K;
+        float s = 0.0f;
+        for (int z = 0; z < slices; ++z) s += Cpart[((int64_t)z * Np + n) * Kp + k];
+        dW[e] = s;
+    } else if (e < N * K + N) {
+        const int n = e - N * K;
+        float s = 0.0f;
+        for (int z = 0; z < slices; ++z) s += Bpart[(int64_t)z * Np + n];
+        db[n] = s;
+    }
+}
+
+// Dout[i][k] = [In[i][k] > 0] * sum_n D[i][n] W[n][k]
+__global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ D, const float *__restrict__ W,
+                                                      const float *__restrict__ In, const int64_t M, const int Np, const int Kp,
+                                                      float *__restrict__ Dout) {
+    __shared__ __attribute__((aligned(16))) float Ds[TB * LDD];
+    __shared__ __attribute__((aligned(16))) float Ws[CH * LDT];
+    const int64_t i0 = (int64_t)blockIdx.x * TB;
+    const int k0 = blockIdx.y * TB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wk = wave & 1, lm = lane & 15, lq = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nn0 = 0; nn0 < Np; nn0 += CH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            {   // delta tile: 64 samples x 32 n
+                const int r = e >> 3, c4 = e & 7;
+                const int64_t i = i0 + r;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < M) v = *reinterpret_cast<const f32x4 *>(D + i * Np + nn0 + 4 * c4);
+                float2 *dst = reinterpret_cast<float2 *>(Ds + r * LDD + 4 * c4);     // LDD even: 8-byte aligned
+                dst[0] = make_float2(v[0], v[1]);
+                dst[1] = make_float2(v[2], v[3]);
+            }
+            {   // weight tile: 32 n x 64 k
+                const int r = e >> 4, c4 = e & 15;
+                *reinterpret_cast<f32x4 *>(Ws + r * LDT + 4 * c4) =
+                    *reinterpret_cast<const f32x4 *>(W + (int64_t)(nn0 + r) * Kp + k0 + 4 * c4);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < CH / 4; ++ks) {
+            const int kk = ks * 4 + lq;
+            const float a0 = Ds[(wi * 32 + lm) * LDD + kk], a1 = Ds[(wi * 32 + 16 + lm) * LDD + kk];
+            const float b0 = Ws[kk * LDT + wk * 32 + lm], b1 = Ws[kk * LDT + wk * 32 + 16 + lm];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + wi * 32 + ti * 16 + 4 * lq + r;
+                const int k = k0 + wk * 32 + tk * 16 + lm;
+                if (i < M) Dout[i * Kp + k] = In[i * Kp + k] > 0.0f ? acc[ti][tk][r] : 0.0f;
+            }
+}
+
+// phase weights, row-major and zero-padded to multiples of 64 in both dimensions: Wb_l [Np][Kp]
+__global__ __launch_bounds__(256) void pack_wb_kernel(const float *__restrict__ src, const int N, const int K, const int Np,
+                                                      const int Kp, float *__restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Np * Kp) return;
+    const int n = e / Kp, k = e - n * Kp;
+    dst[e] = (n < N && k < K) ? src[n * K + k] : 0.0f;
+}
+
+struct TrainLayout {            // carve-up of net->d_train for `cap` rows
+    size_t x, act[MAXL], delta[2], top, g_amp, cpart, bpart, total;
+    int x_ld, act_ld[MAXL], top_ld, max_ld;
+    int64_t cpart_floats;
+};
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+TrainLayout train_layout(const naqs_net *net, int64_t cap) {
+    const NetDims &d = net->dims;
+    TrainLayout L{};
+    size_t off = 0;
+    const int H = d.n_lin - 1;
+    L.x_ld = pad64(net->phase_K[0]);
+    L.x = off; off = up256(off + (size_t)cap * L.x_ld * sizeof(float));
+    L.max_ld = L.x_ld;
+    for (int l = 0; l < H; ++l) {
+        L.act_ld[l] = pad64(net->phase_N[(size_t)l]);
+        L.max_ld = std::max(L.max_ld, L.act_ld[l]);
+        L.act[l] = off; off = up256(off + (size_t)cap * L.act_ld[l] * sizeof(float));
+    }
+    for (int b = 0; b < 2; ++b) { L.delta[b] = off; off = up256(off + (size_t)cap * L.max_ld * sizeof(float)); }
+    L.top_ld = pad64(net->phase_N[(size_t)H]);
+    L.top = off; off = up256(off + (size_t)cap * L.top_ld * sizeof(float));
+    L.g_amp = off; off = up256(off + (size_t)cap * sizeof(float));
+    // GEMM partials: at most ~2 x CU-count workgroups per launch -> slices * blocks <= 512 (+ one slice minimum)
+    int64_t worst = 0;
+    for (int l = 0; l <= H; ++l) {
+        const int64_t Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
+        const int64_t blocks = (Np / TB) * (Kp / TB);
+        const int64_t slices = std::max<int64_t>(1, 512 / blocks);
+        worst = std::max(worst, slices * Np * Kp);
+    }
+    L.cpart_floats = worst;
+    L.cpart = off; off = up256(off + (size_t)worst * sizeof(float));
+    L.bpart = off; off = up256(off + (size_t)512 * 64 * sizeof(float) * 8);
+    L.total = off;
+    return L;
+}
+
+int ensure_train_scratch(naqs_net *net, int64_t M) {
+    if (M <= net->train_cap && net->d_train) return NAQS_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (net->d_train) (void)hipFree(net->d_train);
+    net->d_train = nullptr; net->train_cap = 0;
+    const int64_t cap = std::max<int64_t>(1024, M + M / 4);
+    const TrainLayout L = train_layout(net, cap);
+    HIP_TRY(hipMalloc(&net->d_train, L.total));
+    HIP_TRY(hipMemset(net->d_train, 0, L.total));          // padding columns of x stay zero for good
+    net->train_cap = cap;
+    return NAQS_OK;
+}
+
+size_t wb_offset(const naqs_net *net, int l) {
+    size_t off = 0;
+    for (int q = 0; q < l; ++q) off += (size_t)pad64(net->phase_N[(size_t)q]) * pad64(net->phase_K[(size_t)q]);
+    return off;
+}
+
+}  // namespace
+
+// called by naqs_net_set_weights (naqs_logpsi.hip): row-major padded copies of the phase weights for grad_in_kernel
+int naqs::net_pack_backward_weights(naqs_net *net, const float *flat_dev, hipStream_t s) {
+    const NetDims &d = net->dims;
+    if (!net->d_wb) {
+        HIP_TRY(hipMalloc((void **)&net->d_wb, wb_offset(net, d.n_lin) * sizeof(float)));
+    }
+    for (int l = 1; l < d.n_lin; ++l) {                     // layer 0 has no delta to propagate
+        const int N = net->phase_N[(size_t)l], K = net->phase_K[(size_t)l], Np = pad64(N), Kp = pad64(K);
+        hipLaunchKernelGGL(pack_wb_kernel, dim3((Np * Kp + 255) / 256), dim3(256), 0, s, flat_dev + net->phase_src_off[(size_t)l], N, K,
+                           Np, Kp, net->d_wb + wb_offset(net, l));
+        HIP_TRY(hipGetLastError());
+    }
+    net->have_wb = true;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream) {
+    if (!net || M < 0 || (M > 0 && (!keys_dev || !logpsi_dev))) return NAQS_ERR_INVALID;
+    if (!net->have_weights) return NAQS_ERR_INVALID;
+    if (M == 0) return NAQS_OK;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    st = ensure_train_scratch(net, M);
+    if (st != NAQS_OK) return st;
+    const TrainLayout L = train_layout(net, net->train_cap);
+    char *base = static_cast<char *>(net->d_train);
+    naqs::PhaseSave save;
+    save.x = reinterpret_cast<float *>(base + L.x);
+    save.x_ld = L.x_ld;
+    for (int l = 0; l + 1 < net->dims.n_lin; ++l) {
+        save.act[l] = reinterpret_cast<float *>(base + L.act[l]);
+        save.act_ld[l] = L.act_ld[l];
+    }
+    naqs::ElocFeed none{};
+    return naqs::net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, none, save);
+}
+
+NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
+                                     float *grad_dev, void *stream) {
+    if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
+    if (!net->have_weights || !net->have_wb) return NAQS_ERR_INVALID;
+    if (M > net->train_cap || !net->d_train) return NAQS_ERR_INVALID;        // naqs_net_train_forward of the same batch comes first
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M == 0) {
+        HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)net->n_params * sizeof(float), s));
+        return NAQS_OK;
+    }
+    const NetDims &d = net->dims;
+    const TrainLayout L = train_layout(net, net->train_cap);
+    char *base = static_cast<char *>(net->d_train);
+    float *x = reinterpret_cast<float *>(base + L.x);
+    float *delta[2] = {reinterpret_cast<float *>(base + L.delta[0]), reinterpret_cast<float *>(base + L.delta[1])};
+    float *top = reinterpret_cast<float *>(base + L.top);
+    float *g_amp = reinterpret_cast<float *>(base + L.g_amp);
+    float *cpart = reinterpret_cast<float *>(base + L.cpart), *bpart = reinterpret_cast<float *>(base + L.bpart);
+    const float2 *g2 = reinterpret_cast<const float2 *>(g_dev);
+
+    // amplitude blocks
+    hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, g2, g_amp);
+    HIP_TRY(hipGetLastError());
+    st = naqs_net_amp_backward(net, M, keys_dev, g_amp, grad_dev, stream);
+    if (st != NAQS_OK) return st;
+
+    // phase block, output layer first
+    const int H = d.n_lin - 1;
+    hipLaunchKernelGGL(top_delta_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, g2, top, L.top_ld);
+    HIP_TRY(hipGetLastError());
+    const float *dcur = top;
+    int flip = 0;
+    for (int l = H; l >= 0; --l) {
+        const int N = net->phase_N[(size_t)l], K = net->phase_K[(size_t)l], Np = pad64(N), Kp = pad64(K);
+        const float *in = l == 0 ? x : reinterpret_cast<const float *>(base + L.act[l - 1]);
+        const int ld_in = l == 0 ? L.x_ld : L.act_ld[l - 1];          // == Kp
+        const int blocks = (Np / TB) * (Kp / TB);
+        int slices = (int)std::min<int64_t>(std::max(1, 512 / blocks), (M + 127) / 128);
+        slices = std::max(1, slices);
+        const int64_t rows = ((M + slices - 1) / slices + CH - 1) / CH * CH;
+        slices = (int)((M + rows - 1) / rows);
+        hipLaunchKernelGGL(grad_w_kernel, dim3(Np / TB, Kp / TB, slices), dim3(256), 0, s, dcur, Np, in, ld_in, M, rows, cpart, Np, Kp,
+                           bpart);
+        HIP_TRY(hipGetLastError());
+        float *dW = grad_dev + net->phase_src_off[(size_t)l];
+        hipLaunchKernelGGL(grad_w_reduce_kernel, dim3((N * K + N + 255) / 256), dim3(256), 0, s, cpart, bpart, slices, Np, Kp, N, K, dW,
+                           dW + (int64_t)N * K);
+        HIP_TRY(hipGetLastError());
+        if (l > 0) {
+            float *dnext = delta[flip];
+            flip ^= 1;
+            hipLaunchKernelGGL(grad_in_kernel, dim3((unsigned)((M + TB - 1) / TB), Kp / TB), dim3(256), 0, s, dcur,
+                               net->d_wb + wb_offset(net, l), in, M, Np, Kp, dnext);
+            HIP_TRY(hipGetLastError());
+            dcur = dnext;
+        }
+    }
+    return NAQS_OK;
+}

@@ -37,7 +37,8 @@ using naqs::WAVE;
 using naqs::DeviceGuard;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SB = 256;                     // prefixes per workgroup
+constexpr int SB = 256;                     // threads per workgroup; prefixes per workgroup of the scatter kernel
+constexpr int EXP_PARENTS = SB / 4;         // prefixes per workgroup of the expand kernel (a quad of lanes each)
 constexpr int U_SLOTS = MAXP + 2;           // U[0..P] level sizes, U[MAXP + 1] overflow flag
 
 struct SampleBufs {
@@ -60,13 +61,20 @@ __global__ void sample_init_kernel(SampleBufs b, int64_t n_samples) {
     }
 }
 
+// quad (4 consecutive lanes) sum: every lane of the quad gets the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, const float *__restrict__ w, const int n,
                                                            const SampleBufs b, const int cur, const uint32_t k0,
                                                            const uint32_t k1) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_red[SB / WAVE];
     const int64_t U = b.U[n];
-    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * SB >= U) return;          // workgroup-uniform
+    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
     const int nin = n == 0 ? 1 : 2 * n;
     const int S = (nin + 1 + 5 + 3) & ~3;
     {
@@ -75,55 +83,64 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
         f32x4 *dst = reinterpret_cast<f32x4 *>(s_w);
         for (int e = threadIdx.x; e < total / 4; e += SB) dst[e] = src[e];
     }
-    const int64_t u = (int64_t)blockIdx.x * SB + threadIdx.x;
+    // a quad of lanes per prefix: the hidden units are split four ways, then lanes 0/1 draw the two independent
+    // second-level binomials of the multinomial split in parallel
+    const int q = threadIdx.x & 3;
+    const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
     const bool active = u < U;
     const uint32_t ab = active ? b.ab[cur][u] : 0u;
     const uint32_t abits = ab & 0xffffu, bbits = ab >> 16;
     const bool swap = d.sym && abits > bbits;                                  // nade.py:519-530
     const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
+    const int per = (d.Ha + 3) / 4;
+    const int j0 = min(d.Ha, q * per), j1 = min(d.Ha, j0 + per);
     float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     switch (n) {
-#define CASE(NB) case NB: naqs::amp_partial<NB>(d, s_w, first, second, 0, d.Ha, o); break;
+#define CASE(NB) case NB: naqs::amp_partial<NB>(d, s_w, first, second, j0, j1, o); break;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
         CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
 #undef CASE
         default: break;
     }
+    const float *b2 = s_w + d.Ha * S;
+    float t[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + quad_sum(o[c]);
+    float la[4];
+    bool ok[4], phys[4];
+    naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
+    naqs::amp_budget_mask(d, n, abits, bbits, phys);
+    float p[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float e = ok[c] ? expf(la[c]) : 0.0f;
+        p[c] = e * e;                                                           // float32, nade.py:673
+    }
+    // multinomial(count; p) as a binary tree of binomials (same distribution as the reference's conditional chain,
+    // nade.py:31-35, two dependent rounds instead of three; the float64 renormalisation of :682-683 cancels in the
+    // ratios): first {2,3} against {0,1}, then 1 within {0,1} and 3 within {2,3}
+    const double p01 = (double)p[0] + (double)p[1], p23 = (double)p[2] + (double)p[3], tot = p01 + p23;
+    const int64_t cnt = active ? b.cnt[cur][u] : 0;
+    int64_t n23 = 0;
+    if (q == 0 && tot > 0.0) {
+        naqs::RngStream g{k0, k1, ab, (uint32_t)n | (1u << 8), 0u, 0u};
+        n23 = naqs::binomial(cnt, fmin(1.0, p23 / tot), g);
+    }
+    n23 = __shfl(n23, (int)(threadIdx.x & 63) & ~3, 64);
+    const int64_t n01 = tot > 0.0 ? cnt - n23 : 0;
+    int64_t hi = 0;                              // lane 0: outcome 1 out of {0,1}; lane 1: outcome 3 out of {2,3}
+    if (q < 2) {
+        const int64_t m = q == 0 ? n01 : n23;
+        const double den = q == 0 ? p01 : p23, num = q == 0 ? (double)p[1] : (double)p[3];
+        naqs::RngStream g{k0, k1, ab, (uint32_t)n | ((uint32_t)(2 + q) << 8), 0u, 0u};
+        hi = den > 0.0 ? naqs::binomial(m, fmin(1.0, num / den), g) : 0;
+    }
+    const int64_t n3 = __shfl(hi, ((int)(threadIdx.x & 63) & ~3) + 1, 64);
     uint32_t survivors = 0;
-    if (active) {
-        const float *b2 = s_w + d.Ha * S;
-        float t[5];
-#pragma unroll
-        for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + o[c];
-        float la[4];
-        bool ok[4], phys[4];
-        naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
-        naqs::amp_budget_mask(d, n, abits, bbits, phys);
-        float p[4];
-        double cs[4], acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float e = ok[c] ? expf(la[c]) : 0.0f;
-            p[c] = e * e;                                                       // float32, nade.py:673
-            acc += (double)p[c];
-            cs[c] = acc;
-        }
-        int64_t remaining = b.cnt[cur][u];
+    if (active && q == 0) {
+        int64_t out[4] = {n01 - hi, hi, n23 - n3, n3};
         const float pr = b.prob[cur][u];
-        int64_t out[4] = {0, 0, 0, 0};
-        // conditional-binomial chain from the last outcome down (multinomial_arr, nade.py:31-35); the float64
-        // renormalisation of :682-683 cancels in p[j] / cumsum[j]
-#pragma unroll
-        for (int j = 3; j >= 1; --j) {
-            double cp = cs[j] > 0.0 ? (double)p[j] / cs[j] : 0.0;
-            cp = cp < 0.0 ? 0.0 : (cp > 1.0 ? 1.0 : cp);
-            naqs::RngStream g{k0, k1, ab, (uint32_t)n | ((uint32_t)j << 8), 0u, 0u};
-            const int64_t draw = naqs::binomial(remaining, cp, g);
-            out[j] = draw;
-            remaining -= draw;
-        }
-        out[0] = acc > 0.0 ? remaining : 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (!phys[c]) out[c] = 0;                                           // un-physical samples are thrown away, :695
@@ -138,9 +155,9 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = survivors;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < SB / WAVE; ++i) tot += s_red[i];
-        b.wg_total[blockIdx.x] = tot;
+        uint32_t tot_s = 0;
+        for (int i = 0; i < SB / WAVE; ++i) tot_s += s_red[i];
+        b.wg_total[blockIdx.x] = tot_s;
     }
 }
 
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(SB) void sample_scatter_kernel(const NetDims d, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // offset of this workgroup = survivors of all preceding workgroups
     int64_t part = 0;
-    for (int64_t wg = threadIdx.x; wg < (int64_t)blockIdx.x; wg += SB) part += b.wg_total[wg];
+    for (int64_t wg = threadIdx.x; wg < (int64_t)blockIdx.x * (SB / EXP_PARENTS); wg += SB) part += b.wg_total[wg];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
     if (lane == 0) s_off[wave] = part;
@@ -240,7 +257,7 @@ NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, 
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     const int64_t cap = max_unique;
-    const int64_t nwg_cap = (cap + SB - 1) / SB;
+    const int64_t nwg_cap = (cap + EXP_PARENTS - 1) / EXP_PARENTS;
     // carve the scratch: 2 x (ab, cnt, prob), children counts / probs, workgroup totals, level sizes
     size_t off = 0;
     size_t o_ab[2], o_cnt[2], o_prob[2];
@@ -281,7 +298,8 @@ NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, 
         const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const int nin = n == 0 ? 1 : 2 * n;
         const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-        hipLaunchKernelGGL(sample_expand_kernel, dim3(grid), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
+        const unsigned grid_e = (unsigned)((std::min(bound, cap) + EXP_PARENTS - 1) / EXP_PARENTS);
+        hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, n & 1, cap, n == d.P - 1 ? 1 : 0,
                            keys_dev, counts_dev, probs_dev);

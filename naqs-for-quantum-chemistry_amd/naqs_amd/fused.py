@@ -7,6 +7,7 @@ symmetry, <= 16 orbital pairs, phase layers <= 512 wide.  Anything else raises
 ``NotImplementedError`` — callers then stay on the PyTorch modules (same numbers, more launches).
 """
 import ctypes
+import os
 
 import torch
 
@@ -88,6 +89,7 @@ class FusedLogPsi:
         _lib.check(self._lib.naqs_net_param_count(self._h, ctypes.byref(n)), "naqs_net_param_count")
         self.n_params = n.value
         self._samp = None
+        self.train_mode = os.environ.get("NAQS_TRAIN_MODE", "hip")     # "hip" | "blas" (phase MLP through torch/rocBLAS)
         assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
         _lib.check(self._lib.naqs_net_amp_param_count(self._h, ctypes.byref(n)), "naqs_net_amp_param_count")
         self.n_amp_params = n.value
@@ -127,22 +129,41 @@ class FusedLogPsi:
     # ---- training step without the autograd engine --------------------------------------------------------
     @torch.no_grad()
     def forward_saved(self, keys):
-        """log psi [M, 2] of int64 device keys plus what ``backward_saved`` needs (phase activations), evaluated
-        without recording an autograd graph: HIP amplitude kernels + one addmm/relu per phase layer."""
-        m = self.wf.model
+        """log psi [M, 2] of int64 device keys, evaluated without recording an autograd graph, plus the token
+        ``backward_saved`` needs.  ``mode="hip"`` (default): ``naqs_net_train_forward`` — the inference kernels, the
+        phase activations stay in the handle.  ``mode="blas"``: HIP amplitude kernels + one addmm/relu per phase layer."""
         keys = keys.contiguous()
         M = keys.shape[0]
+        if self.train_mode == "hip":
+            log_psi = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+            st = self._lib.naqs_net_train_forward(self._h, M, keys.data_ptr(), log_psi.data_ptr(), _stream_ptr(self.device))
+            _lib.check(st, "naqs_net_train_forward")
+            return log_psi, (keys, None, None)
+        m = self.wf.model
         log_amp = torch.empty(M, dtype=torch.float32, device=self.device)
         st = self._lib.naqs_net_logamp(self._h, M, keys.data_ptr(), log_amp.data_ptr(), _stream_ptr(self.device))
         _lib.check(st, "naqs_net_logamp")
         lin = m.phase_layers[0].linears()
-        acts = [((keys.unsqueeze(-1) >> self._phase_shifts) & 1).to(torch.float32).mul_(2.0).sub_(1.0)]
+        x = torch.empty((M, lin[0].in_features), dtype=torch.float32, device=self.device)
+        occ = torch.empty((M, 1), dtype=torch.int64, device=self.device)
+        st = self._lib.naqs_net_phase_inputs(self._h, M, keys.data_ptr(), x.data_ptr(), occ.data_ptr(),
+                                             _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_phase_inputs")
+        acts = [x]
         for layer in lin[:-1]:
             acts.append(torch.addmm(layer.bias, acts[-1], layer.weight.t()).relu_())
         out = torch.addmm(lin[-1].bias, acts[-1], lin[-1].weight.t())
-        occ = (((keys >> self._last_a) & 1) + 2 * ((keys >> self._last_b) & 1)).unsqueeze(1)
         log_psi = torch.stack([log_amp, out.gather(1, occ).squeeze(1)], -1)
         return log_psi, (keys, acts, occ)
+
+    def vmc_loss_grad(self, e_loc, weights, sums):
+        """g [M, 2] float32 = d loss / d (log|psi|, phase) of the VMC loss (``naqs_vmc_loss_grad``)."""
+        M = e_loc.shape[0]
+        g = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+        st = self._lib.naqs_vmc_loss_grad(M, e_loc.data_ptr(), weights.data_ptr(), sums.data_ptr(), g.data_ptr(),
+                                          _stream_ptr(self.device))
+        _lib.check(st, "naqs_vmc_loss_grad")
+        return g
 
     @torch.no_grad()
     def backward_saved(self, saved, g):
@@ -152,6 +173,18 @@ class FusedLogPsi:
         keys, acts, occ = saved
         m = self.wf.model
         g = g.to(torch.float32)
+        if acts is None:                     # naqs_net_train_backward: every gradient in one flat buffer
+            g = g.contiguous()
+            flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            st = self._lib.naqs_net_train_backward(self._h, keys.shape[0], keys.data_ptr(), g.data_ptr(), flat.data_ptr(),
+                                                   _stream_ptr(self.device))
+            _lib.check(st, "naqs_net_train_backward")
+            off = 0
+            for p in m.parameters():
+                n = p.numel()
+                _accumulate(p, flat[off:off + n].view(p.shape))
+                off += n
+            return
         flat = torch.empty(self.n_amp_params, dtype=torch.float32, device=self.device)
         ga = g[:, 0].contiguous()
         st = self._lib.naqs_net_amp_backward(self._h, keys.shape[0], keys.data_ptr(), ga.data_ptr(), flat.data_ptr(),

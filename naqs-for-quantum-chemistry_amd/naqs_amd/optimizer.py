@@ -93,11 +93,36 @@ class OptimizerBase:
             self.generator.manual_seed(int(seed))
         else:
             self.generator.manual_seed(torch.initial_seed() % (2 ** 63))
-        self.sampled_idxs = Counter()
+        self._sampled_idxs, self._sampled_pending = Counter(), []
         self.track_sampled_idxs = True
+        self._loss_terms = self._last_loss = None
         self.use_fused = True                # HIP sampler / amplitude forward-backward when the network supports them
         self.reset_log()
         self.reset_optimizer()
+
+    # how often each basis state has appeared as a unique sample (reference: a Counter updated every step)
+    def _flush_sampled_idxs(self):
+        if self._sampled_pending:
+            k, c = torch.unique(torch.cat(self._sampled_pending), return_counts=True)
+            self._sampled_pending = []
+            self._sampled_idxs.update(dict(zip(k.cpu().numpy().tolist(), c.cpu().numpy().tolist())))
+
+    @property
+    def sampled_idxs(self):
+        self._flush_sampled_idxs()
+        return self._sampled_idxs
+
+    @sampled_idxs.setter
+    def sampled_idxs(self, value):
+        self._sampled_idxs, self._sampled_pending = Counter(value), []
+
+    @property
+    def last_loss(self):
+        """The loss of the last ``_SGD_step`` (evaluated on demand when the step ran on the graph-free path)."""
+        if self._last_loss is None and self._loss_terms is not None:
+            g, lp = self._loss_terms
+            self._last_loss = (g * lp).sum()
+        return self._last_loss
 
     # ---- bookkeeping (energy.py:141-187) ----
     def reset_log(self):
@@ -166,8 +191,10 @@ class OptimizerBase:
         world, rank = (dist.get_world_size(), dist.get_rank()) if dist else (1, 0)
         keys = keys_to_device(states_idx, self.device)
         M = keys.shape[0]
-        if self.track_sampled_idxs:
-            self.sampled_idxs.update(keys.cpu().numpy().tolist())
+        if self.track_sampled_idxs:          # energy.py:300; folded into the Counter in batches (no per-step sync)
+            self._sampled_pending.append(keys)
+            if len(self._sampled_pending) >= 64:
+                self._flush_sampled_idxs()
         # shard of rows this rank owns (the whole table when single-process)
         b, e_ = shard_bounds(M, rank, world)
         saved = None
@@ -177,7 +204,7 @@ class OptimizerBase:
         else:
             # gradients only for the owned rows; the table needed for the psi look-ups is evaluated
             # without autograd (the rows of other ranks are theirs to differentiate)
-            fused = self.wavefunction.fused(need_phase=world > 1) if self.use_fused else None
+            fused = self.wavefunction.fused(need_phase=True) if self.use_fused else None
             if fused is not None and regularisation_loss is None and not self.normalize_grads:
                 # HIP amplitude forward/backward + explicit chain rule of the phase MLP: no autograd graph at all
                 lp_mine, saved = fused.forward_saved(keys[b:e_])
@@ -210,10 +237,8 @@ class OptimizerBase:
         self.optimizer.zero_grad()
         if saved is not None:
             # d loss / d log psi of vmc_loss, written out: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>))
-            ec = e_loc.to(torch.float32) - e_mean.to(torch.float32)
-            g = ec.mul_(2.0 * w[b:e_].to(torch.float32).unsqueeze(1))
-            g[:, 1].neg_()
-            self.last_loss = (g * lp_mine).sum()
+            g = fused.vmc_loss_grad(e_loc, w[b:e_].contiguous(), sums)
+            self._loss_terms, self._last_loss = (g, lp_mine), None
             fused.backward_saved(saved, g)
         else:
             loss = vmc_loss(lp_mine, e_loc.to(lp_mine.dtype), w[b:e_].to(lp_mine.dtype), e_mean.to(lp_mine.dtype))
@@ -222,7 +247,7 @@ class OptimizerBase:
             if regularisation_loss is not None:
                 loss = loss + regularisation_loss
             loss.backward()
-            self.last_loss = loss.detach()
+            self._loss_terms, self._last_loss = None, loss.detach()
         if dist:
             params = [p for g in self.optimizer.param_groups for p in g['params'] if p.grad is not None]
             flat = torch.cat([p.grad.reshape(-1) for p in params])
@@ -321,8 +346,9 @@ class PartialSamplingOptimizer(OptimizerBase):
         or when the unique-prefix tree exceeds ``n_unq_samples_max``."""
         action = 0
         try:
-            states, counts, probs = self.wavefunction.sample(
-                self.n_samples, ret_log_psi=False, max_batch_size=self.n_unq_samples_max, generator=self.generator)
+            states, counts, probs, self._sample_keys = self.wavefunction.sample(
+                self.n_samples, ret_log_psi=False, max_batch_size=self.n_unq_samples_max, generator=self.generator,
+                ret_keys=True)
             n_unq, completed = len(states), True
         except MaxBatchSizeExceededError:
             print("MaxBatchSizeExceededError")
@@ -378,7 +404,7 @@ class PartialSamplingOptimizer(OptimizerBase):
             t0 = time.time()
             states, counts, probs = self.get_samples()
             weights = counts.double() / counts.sum().double()                         # energy.py:993
-            keys = self.hilbert.state2idx(states).squeeze(-1)
+            keys = self._sample_keys                                                  # = hilbert.state2idx(states)
             e, var = self._SGD_step(states, keys, None, sample_weights=weights)
             self.n_steps += 1
             self.run_time += time.time() - t0

@@ -220,8 +220,9 @@ def test_fused_training_forward_backward_matches_autograd(mol):
     assert all(torch.equal(a, b) for a, b in zip(grads, grads2) if a is not None)
 
 
+@pytest.mark.parametrize("mode", ["hip", "blas"])
 @pytest.mark.parametrize("mol", ["LiH", "N2"])
-def test_graph_free_training_step_matches_autograd(mol):
+def test_graph_free_training_step_matches_autograd(mol, mode):
     """forward_saved / backward_saved (no autograd engine) give the same values and .grad as the Function path."""
     from test_nade import make_wf
     from naqs_amd.fused import FusedLogPsi
@@ -229,6 +230,7 @@ def test_graph_free_training_step_matches_autograd(mol):
     z = golden(f"nade_{mol}.npz")
     hil, wf = make_wf(mol, z, device="cuda")
     fused = FusedLogPsi(wf)
+    fused.train_mode = mode
     keys = keys_to_device(z["eval_keys"].astype(np.int64), "cuda")
     gen = torch.Generator(device="cuda").manual_seed(4)
     g = torch.randn((len(keys), 2), device="cuda", generator=gen) / len(keys)
@@ -244,6 +246,6 @@ def test_graph_free_training_step_matches_autograd(mol):
         assert p.grad is not None, name
         ref = torch.zeros_like(p) if b is None else b
         scale = float(ref.abs().max()) + 1e-12
-        assert float((p.grad - ref).abs().max()) < 1e-5 * scale + 1e-10, (name, float((p.grad - ref).abs().max()), scale)
+        assert float((p.grad - ref).abs().max()) < 2e-5 * scale + 1e-10, (name, float((p.grad - ref).abs().max()), scale)
     fused.backward_saved(saved, g)                               # accumulates like autograd does
     assert torch.allclose(params[-1].grad, 2 * grads_ref[-1], rtol=1e-5, atol=1e-10)
