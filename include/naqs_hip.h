@@ -249,6 +249,11 @@ int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, 
 int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream);
 int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev,
                             void *stream);
+/* One Adam step on a flat float32 parameter vector (device pointers): torch.optim.Adam's rule without amsgrad —
+ * the reference's optimiser, experiments/_base.py:228 (betas (0.9, 0.99), eps 1e-15).  `step` is the 1-based count
+ * after this update (bias corrections 1 - beta^step are formed on the host in float64). */
+int naqs_adam_step(int64_t n, float *param_dev, const float *grad_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, void *stream);
 /* Inputs of the phase block from key bits: x_dev [M][2 (n_qubits/2 - 1)] float32 (+-1 occupations: alpha strings of
  * model pairs 0..P-2, then beta), occ_dev [M] int64 = realised outcome (alpha + 2 beta) of the last pair, which selects
  * the phase output (nade.py:563-569). */

@@ -15,6 +15,7 @@
 // workgroup.  Partial sums per workgroup go to scratch in state_dict order; amp_reduce_kernel adds them in order.
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 
 #include "naqs_common.hpp"
@@ -249,8 +250,40 @@ __global__ __launch_bounds__(256) void vmc_grad_kernel(const int64_t M, const do
     g[i] = make_float2(((float)e.x - m_re) * two_w, -(((float)e.y - m_im) * two_w));
 }
 
+// Adam (Kingma & Ba) on one flat parameter vector, torch.optim.Adam's update rule (no amsgrad):
+// m <- m + (1 - b1)(g - m); v <- b2 v + (1 - b2) g^2; p <- p - step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(const int64_t n, float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, const float step_size,
+                                                   const float beta1, const float beta2, const float bc2_sqrt, const float eps,
+                                                   const float weight_decay) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    const float pi = p[i];
+    if (weight_decay != 0.0f) gi = fmaf(weight_decay, pi, gi);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+}
+
 // the amp kernel of naqs_logpsi.hip is reached through naqs::net_amp_forward
 }  // namespace
+
+NAQS_API int naqs_adam_step(int64_t n, float *param_dev, const float *grad_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                            void *stream) {
+    if (n < 0 || step < 1 || (n > 0 && (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev))) return NAQS_ERR_INVALID;
+    if (n == 0) return NAQS_OK;
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, param_dev,
+                       grad_dev, exp_avg_dev, exp_avg_sq_dev, (float)(lr / bc1), (float)beta1, (float)beta2, (float)std::sqrt(bc2),
+                       (float)eps, (float)weight_decay);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
 
 NAQS_API int naqs_net_phase_inputs(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *x_dev, int64_t *occ_dev,
                                    void *stream) {

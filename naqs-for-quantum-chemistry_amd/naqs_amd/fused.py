@@ -107,8 +107,11 @@ class FusedLogPsi:
         """Re-pack the current network parameters (after every optimiser step).  ``amp_only`` packs just the
         amplitude blocks — all that sampling and the training forward/backward need; the phase layers are then
         stale for ``log_psi`` / ``log_psi_and_local_energy`` until a full refresh."""
-        params = self._amp_params if amp_only else list(self.wf.model.parameters())
-        flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
+        all_params = list(self.wf.model.parameters())
+        flat = getattr(self.wf, "_flat_params", None)
+        if flat is None or not self.wf._views_of(flat, all_params):       # parameters not (or no longer) flattened: gather
+            params = self._amp_params if amp_only else all_params
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
         fn = self._lib.naqs_net_set_amp_weights if amp_only else self._lib.naqs_net_set_weights
         _lib.check(fn(self._h, flat.data_ptr(), flat.numel(), _stream_ptr(self.device)), "naqs_net_set_weights")
         self._flat = flat          # keep alive until the async copy has been consumed

@@ -95,8 +95,8 @@ class OptimizerBase:
             self.generator.manual_seed(torch.initial_seed() % (2 ** 63))
         self._sampled_idxs, self._sampled_pending = Counter(), []
         self.track_sampled_idxs = True
+        self.use_fused = True                # HIP sampler / training kernels / FlatAdam when the network supports them
         self._loss_terms = self._last_loss = None
-        self.use_fused = True                # HIP sampler / amplitude forward-backward when the network supports them
         self.reset_log()
         self.reset_optimizer()
 
@@ -140,10 +140,16 @@ class OptimizerBase:
                 a = dict(a)
                 a['params'] = self.wavefunction.parameters(idx)
                 groups.append(a)
-            extra = {}
-            if self.optimizer_callable is torch.optim.Adam and self.device.type == "cuda" and any(len(g['params']) for g in groups):
-                extra['fused'] = True         # one multi-tensor kernel per step instead of ~10 foreach launches
-            self.optimizer = self.optimizer_callable(groups, **extra)
+            self.optimizer = None
+            if (self.optimizer_callable is torch.optim.Adam and self.use_fused and cond_idx is None
+                    and not any(g.get('amsgrad') for g in groups) and self.wavefunction.fused() is not None):
+                # same rule and state_dict as torch.optim.Adam, one launch per step on the flattened parameters
+                from .flat_adam import FlatAdam
+                flat = self.wavefunction.flatten_parameters()
+                self.wavefunction.parameters_changed()
+                self.optimizer = FlatAdam(groups, flat)
+            if self.optimizer is None:
+                self.optimizer = self.optimizer_callable(groups)
         self.scheduler = (self.scheduler_callable(self.optimizer, **self.scheduler_args)
                           if self.scheduler_callable is not None else None)
 

@@ -78,6 +78,7 @@ class NAQSComplex_NADE_orbitals:
         self.model.predict()
         self._fused, self._fused_version, self._fused_amp_version = None, None, None
         self._param_epoch = 0
+        self._flat_params = None
 
     # ---- mode helpers (wavefunction.py:90-100)
     def train_model(self):
@@ -172,6 +173,32 @@ class NAQSComplex_NADE_orbitals:
             self._fused_amp_version = v
             self._fused_version = None
         return self._fused
+
+    def flatten_parameters(self):
+        """Make every network parameter a view into one flat float32 buffer (state_dict order) and return it.  The
+        fused kernels then read the parameters without gathering them, and ``FlatAdam`` updates them in one launch.
+        ``load_state_dict`` / optimiser steps write through the views, so the buffer is always current."""
+        params = list(self.model.parameters())
+        flat = getattr(self, "_flat_params", None)
+        if flat is not None and self._views_of(flat, params):
+            return flat
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self._flat_params = flat
+        return flat
+
+    @staticmethod
+    def _views_of(flat, params):
+        off, size = 0, flat.element_size()
+        for p in params:
+            if p.data_ptr() != flat.data_ptr() + off * size or not p.is_contiguous():
+                return False
+            off += p.numel()
+        return off == flat.numel()
 
     def _param_version(self):
         return (self._param_epoch,) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())

@@ -74,3 +74,61 @@ def test_get_h_matches_oracle(tmp_path):
     want = oracle.eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi)
     got = np.conj(H @ psi / psi)
     assert np.max(np.abs(got - want)) < 1e-10
+
+
+def test_flat_adam_is_torch_adam(tmp_path):
+    """FlatAdam (one HIP launch on the flattened parameters) follows torch.optim.Adam step for step with the reference's
+    hyper-parameters, and the two exchange state_dicts."""
+    import copy
+    from naqs_amd.flat_adam import FlatAdam
+    from test_nade import make_wf
+    from test_optimizer import ADAM
+    z = golden("nade_LiH.npz")
+    _, wf_a = make_wf("LiH", z, device="cuda")
+    _, wf_b = make_wf("LiH", z, device="cuda")
+    flat = wf_a.flatten_parameters()
+    pa, pb = list(wf_a.model.parameters()), list(wf_b.model.parameters())
+    assert wf_a._views_of(flat, pa)
+    args = {k: v for k, v in ADAM[0].items()}
+    opt_a = FlatAdam([dict(args, params=pa), {'lr': 1e-2, 'params': []}], flat)
+    opt_b = torch.optim.Adam([dict(args, params=pb), {'lr': 1e-2, 'params': []}])
+    gen = torch.Generator(device="cuda").manual_seed(0)
+
+    def one_step(opts_params, scale):
+        grads = [torch.randn(p.shape, device="cuda", generator=gen) * scale for p in pa]
+        for opt, params in opts_params:
+            for p, g in zip(params, grads):
+                p.grad = g.clone()
+            opt.step()
+            opt.zero_grad()
+
+    for it in range(20):
+        one_step([(opt_a, pa), (opt_b, pb)], 10.0 ** (-it % 7))
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-7), float((a - b).abs().max())
+    # state_dict interchange, both directions, then keep stepping together
+    sd_a, sd_b = copy.deepcopy(opt_a.state_dict()), copy.deepcopy(opt_b.state_dict())
+    assert set(sd_a["param_groups"][0]) == set(sd_b["param_groups"][0])
+    assert set(sd_a["state"][0]) == set(sd_b["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    opt_b.load_state_dict(sd_a)
+    opt_a.load_state_dict(sd_b)
+    for it in range(5):
+        one_step([(opt_a, pa), (opt_b, pb)], 1e-3)
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=5e-5, atol=5e-7), float((a - b).abs().max())
+    assert int(opt_a.state_dict()["state"][0]["step"]) == 25 and int(opt_b.state_dict()["state"][3]["step"]) == 25
+
+
+def test_optimizer_uses_flat_adam_and_checkpoint_round_trip(tmp_path):
+    from naqs_amd.flat_adam import FlatAdam
+    z, hil, wf, opt = make_opt_gpu("LiH", tmp_path)
+    assert isinstance(opt.optimizer, FlatAdam)
+    opt.run(3, output_freq=1000)
+    opt.save()
+    w = [p.detach().clone() for p in wf.model.parameters()]
+    m = opt.optimizer._m.clone()
+    z2, hil2, wf2, opt2 = make_opt_gpu("LiH", tmp_path)
+    opt2.load()
+    assert all(torch.equal(a, b) for a, b in zip(w, wf2.model.parameters()))
+    assert torch.equal(m, opt2.optimizer._m) and opt2.optimizer._t == 3 and opt2.n_steps == 3
+    assert wf2._views_of(wf2._flat_params, list(wf2.model.parameters()))      # still flattened after load_state_dict

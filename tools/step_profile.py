@@ -41,7 +41,7 @@ def step(record):
     keys_h = hil.state2idx(states).squeeze(-1)
     keys = keys_to_device(keys_h, dev)
     if record: t = tick("state2idx", t)
-    fused = wf.fused(need_phase=False)
+    fused = wf.fused(need_phase=True)
     if record: t = tick("repack", t)
     lp, saved = fused.forward_saved(keys)
     if record: t = tick("forward", t)
