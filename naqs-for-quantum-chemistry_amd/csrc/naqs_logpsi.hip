@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -342,12 +343,27 @@ __device__ __forceinline__ void split3(float x, ushort_t &h1, ushort_t &h2, usho
     h3 = f32_to_bf16_rne(r2);
 }
 
+// exact 3-way split by truncation (activations, on the critical path of every layer's write-back): each part keeps the
+// top 8 significant bits of what is left, so h1 + h2 + h3 == x exactly like the rounding split, in a third of the
+// instructions
+__device__ __forceinline__ void split3t(float x, ushort_t &h1, ushort_t &h2, ushort_t &h3) {
+    uint32_t u = __float_as_uint(x);
+    h1 = (ushort_t)(u >> 16);
+    const float r1 = x - __uint_as_float(u & 0xFFFF0000u);
+    u = __float_as_uint(r1);
+    h2 = (ushort_t)(u >> 16);
+    const float r2 = r1 - __uint_as_float(u & 0xFFFF0000u);
+    h3 = (ushort_t)(__float_as_uint(r2) >> 16);
+}
+
 template <int RB, int NC>
 __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
                                                  const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
                                                  f32x4 (&acc)[RB][CBT]) {
     // a_ptr: this lane's row/k-group inside plane 0 of the activation tile; w_ptr: this lane's 8 weights of
-    // column block 0, chunk 0, plane 0.  Chunks are 32 wide (one MFMA K).
+    // column block 0, chunk 0, plane 0.  Chunks are 32 wide (one MFMA K).  (Register double buffering of the weight
+    // fragments was tried: 96 VGPRs of fragments on top of the accumulators spill — 89 VGPRs to scratch, +20 us; the
+    // second wave of the SIMD is what hides the L2 latency here.)
     for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
         bf16x8 a[3][RB], b[3][NC];
 #pragma unroll
@@ -431,7 +447,7 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
                 else {
                     ushort_t h1, h2, h3;
                     const float hv = fmaxf(v[u], 0.0f);
-                    split3(hv, h1, h2, h3);
+                    split3t(hv, h1, h2, h3);
                     const int o = (t >> 4) * ldh + (t & 15);
                     planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
                     if (save != nullptr && row0 + (t >> 4) < M) save[(row0 + (t >> 4)) * save_ld + (t & 15)] = hv;
@@ -462,7 +478,7 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
                 for (int r = 0; r < 4; ++r) {
                     ushort_t h1, h2, h3;
                     const float hv = fmaxf(acc[rb][c][r] + bv, 0.0f);
-                    split3(hv, h1, h2, h3);
+                    split3t(hv, h1, h2, h3);
                     const int row = rb * 16 + kg * 4 + r;
                     const int o = row * ldh + col;
                     planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
@@ -473,22 +489,213 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// amplitude conditionals on the bf16 matrix cores, inside the phase kernel's workgroups (no amp_kernel launch):
+// one wave evaluates orbital pair n for a tile of 16 samples.  Layer 1: the +-1 inputs are exact in bf16, so
+// x . (W1_hi + W1_mid + W1_lo) is three 16x16x32 MFMAs per 16 hidden units (2n <= 30 inputs fit one K chunk);
+// the ReLU output is split into three planes through the wave's LDS scratch and layer 2 (Ha -> 5) is the usual
+// six-term bf16x3 product.  Weight fragments are pre-tiled per pair (pack_amp_mfma_kernel):
+//   W1 planes [3][Ha/16][64 lanes][8], W2 planes [3][Ha/32][64 lanes][8]   (bf16)
+// ------------------------------------------------------------------------------------------------
+// per pair: the fragments, then b2 as 16 floats
+__device__ __host__ __forceinline__ size_t amp_mfma_pair_elems(int Ha) { return (size_t)3 * 512 * ((Ha >> 4) + (Ha >> 5)) + 32; }
+
+// registers of one (tile, pair) work item: every global load is issued up front, one item ahead of its use
+template <int CT>
+struct AmpFrag {
+    bf16x8 w1[3][CT];
+    bf16x8 w2[3][CT / 2];
+    float b2;
+};
+
+template <int CT>
+__device__ __forceinline__ void amp_mfma_load(const ushort_t *__restrict__ wp, int lane, AmpFrag<CT> &f) {
+    constexpr int KC = CT / 2;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            f.w1[p][ct] = *reinterpret_cast<const bf16x8 *>(wp + ((size_t)(p * CT + ct) * 64 + lane) * 8);
+    const ushort_t *w2 = wp + (size_t)3 * CT * 512;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            f.w2[p][kc] = *reinterpret_cast<const bf16x8 *>(w2 + ((size_t)(p * KC + kc) * 64 + lane) * 8);
+    f.b2 = reinterpret_cast<const float *>(w2 + (size_t)3 * KC * 512)[lane & 15];
+}
+
+// one wave, one (tile of 16 samples, pair n): the block's 5 raw outputs -> outs[sample][8]
+template <int CT>
+__device__ __forceinline__ void amp_mfma_item(const NetDims &d, const AmpFrag<CT> &f, int n, uint32_t ab,
+                                              int lane, ushort_t *__restrict__ hs, float *__restrict__ outs) {
+    constexpr int KC = CT / 2, HLD = CT * 16 + 8;
+    const int m = lane & 15, kg = lane >> 4;
+    const uint32_t mask = (1u << n) - 1u;
+    {
+        const uint32_t abits = ab & mask, bbits = (ab >> 16) & mask;
+        const bool swap = d.sym && abits > bbits;                               // nade.py:519-530
+        const uint32_t xbits = (swap ? bbits : abits) | ((swap ? abits : bbits) << n);
+        bf16x8 ax;
+        ushort_t *axu = reinterpret_cast<ushort_t *>(&ax);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * kg + e;
+            axu[e] = k < 2 * n ? (((xbits >> k) & 1u) ? (ushort_t)0x3F80 : (ushort_t)0xBF80)
+                               : (k == 31 ? (ushort_t)0x3F80 : (ushort_t)0);  // input 31 is the constant 1 that carries b1
+        }
+        f32x4 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 2; p >= 0; --p)                                            // smallest plane first; CT independent chains
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, f.w1[p][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                       // D: row = 4 kg + r (sample), col = m (hidden)
+                ushort_t h1, h2, h3;
+                split3t(fmaxf(acc[ct][r], 0.0f), h1, h2, h3);
+                const int o = (4 * kg + r) * HLD + ct * 16 + m;
+                hs[o] = h1; hs[16 * HLD + o] = h2; hs[32 * HLD + o] = h3;
+            }
+    }
+    // the scratch is private to this wave: LDS operations of a wave complete in order, so a wave-level fence suffices
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        f32x4 v[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {                                       // one accumulation chain per K chunk
+            bf16x8 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                a[p] = *reinterpret_cast<const bf16x8 *>(hs + p * 16 * HLD + m * HLD + kc * 32 + 8 * kg);
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], f.w2[1][kc], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], f.w2[0][kc], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], f.w2[2][kc], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], f.w2[0][kc], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], f.w2[1][kc], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], f.w2[0][kc], c, 0, 0, 0);
+            v[kc] = c;
+        }
+        if (m < 8) {                                                            // D: row = 4 kg + r (sample), col = m (output)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = v[0][r];
+#pragma unroll
+                for (int kc = 1; kc < KC; ++kc) o += v[kc][r];
+                outs[(4 * kg + r) * 8 + m] = o + f.b2;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                            // hs is rewritten by the wave's next item
+}
+
+// all (tile, pair) items of the workgroup, dealt round-robin to its waves, the loads of item k+1 in flight under item k;
+// then the conditionals (symmetrise, mask, log-softmax, gather) for all (pair, sample) at once -> s_lan
+template <int CT, int RB>
+__device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort_t *__restrict__ wamp, int64_t M, int64_t row0,
+                                                  const uint64_t *__restrict__ keys, const ElocFeed &feed, uint32_t *s_ab,
+                                                  float (*s_lan)[RB * 16], ushort_t *__restrict__ planes, int tid,
+                                                  long long *clk) {
+    constexpr int HLD = CT * 16 + 8, BM = RB * 16;
+    const int lane = tid & 63, wave = tid >> 6;
+    ushort_t *hs = planes + (size_t)wave * (48 * HLD);                     // per wave: 3 planes [16][HLD] bf16
+    float *s_o = reinterpret_cast<float *>(planes + (size_t)PH_WAVES * (48 * HLD));       // [P][BM][8] raw outputs
+    const size_t pair_elems = amp_mfma_pair_elems(CT * 16);
+    const int P = d.P, items = RB * P;
+    // items in pair-major order (q = n * RB + t), a contiguous range per wave: consecutive items share the pair, so its
+    // 18 KB of fragments are fetched once per wave (the CU's 64 B/clk vector-memory path is what bounds this stage) and
+    // the next pair's are in flight while the current one is used
+    const int q0 = items * wave / PH_WAVES, q1 = items * (wave + 1) / PH_WAVES;
+    AmpFrag<CT> f0, f1;
+    int na = q0 < q1 ? q0 / RB : -1, nb = -1;
+    const int n_last = q0 < q1 ? (q1 - 1) / RB : -1;
+    if (q0 < q1) amp_mfma_load<CT>(wamp + (size_t)na * pair_elems, lane, f0);
+    if (tid < BM) {                      // model-order occupation strings of the tile's samples; E_loc hand-over of the key
+        const int64_t i = row0 + tid;
+        const uint64_t key = i < M ? keys[i] : 0ull;
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {                  // unrolled: the qa/qb look-ups are independent scalar loads
+            if (k < P) {
+                a |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+                b |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+            }
+        }
+        s_ab[tid] = a | (b << 16);
+        if (feed.tab != nullptr && i < M) {           // fused log-psi + E_loc call: narrow the key, build the hash table
+            if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, i, key);
+            else naqs::feed_key<uint64_t>(feed, i, key);
+        }
+    }
+    __syncthreads();
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 1] = clock64();
+    for (int q = q0; q < q1; ++q) {
+        const int n = q / RB, t = q - n * RB;
+        const uint32_t ab = s_ab[t * 16 + (lane & 15)];
+        float *outs = s_o + ((size_t)n * BM + t * 16) * 8;
+        if (n == na) {
+            if (nb < n && n_last > n) { nb = n + 1; amp_mfma_load<CT>(wamp + (size_t)nb * pair_elems, lane, f1); }
+            __builtin_amdgcn_sched_barrier(0);
+            amp_mfma_item<CT>(d, f0, n, ab, lane, hs, outs);
+        } else {
+            if (na < n && n_last > n) { na = n + 1; amp_mfma_load<CT>(wamp + (size_t)na * pair_elems, lane, f0); }
+            __builtin_amdgcn_sched_barrier(0);
+            amp_mfma_item<CT>(d, f1, n, ab, lane, hs, outs);
+        }
+    }
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 8] = clock64();
+    __syncthreads();
+    for (int e = tid; e < P * BM; e += PH_THREADS) {
+        const int n = e / BM, r = e - n * BM;
+        float o[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o[c] = s_o[(size_t)e * 8 + c];
+        const uint32_t ab = s_ab[r], mask = (1u << n) - 1u;
+        const int occ = (int)((ab >> n) & 1u) + 2 * (int)((ab >> (16 + n)) & 1u);
+        s_lan[n][r] = naqs::amp_finish(d, n, o, ab & mask, (ab >> 16) & mask, occ);
+    }
+    __syncthreads();
+}
+
 template <int RB>
 __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims d, const float *__restrict__ w,
                                                                   const ushort_t *__restrict__ wh, int64_t M,
                                                                   const uint64_t *__restrict__ keys,
                                                                   const float *__restrict__ scratch,
                                                                   float2 *__restrict__ out, const ElocFeed feed,
-                                                                  const naqs::PhaseSave save) {
+                                                                  const naqs::PhaseSave save,
+                                                                  const ushort_t *__restrict__ wamp) {
     extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
+    __shared__ uint32_t s_ab[RB * 16];                 // model-order occupation strings of the tile's samples
+    __shared__ float s_lan[MAXP][RB * 16];             // conditional log-amplitudes, pair-major
     constexpr int BM = RB * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int P = d.P, ldh = d.ldh;
 
+#define NAQS_MARK(idx) do { if (save.clk != nullptr && blockIdx.x == 0 && lane == 0) save.clk[wave * 16 + (idx)] = clock64(); } while (0)
+    NAQS_MARK(0);
     float la = 0.0f;
-    if (tid < BM && row0 + tid < M)
-        for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
+    if (wamp == nullptr) {
+        if (tid < BM && row0 + tid < M)
+            for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
+    } else {
+        // amplitude conditionals of this tile on the matrix cores; the activation planes are still free -> scratch
+        if (d.Ha == 64) amp_mfma_prologue<4, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, planes, tid, save.clk);
+        else amp_mfma_prologue<2, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, planes, tid, save.clk);
+        NAQS_MARK(2);
+        if (tid < BM)
+            for (int n = 0; n < P; ++n) la += s_lan[n][tid];                           // fixed order: block 0..P-1
+        __syncthreads();                                                                // scratch becomes the activation planes
+    }
+    NAQS_MARK(3);
 
     // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero)
     const int K0 = d.Kh_pad[0];
@@ -497,10 +704,17 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
         const int64_t i = row0 + r;
         ushort_t v = 0;
         if (i < M && k < 2 * (P - 1)) {
-            const uint64_t key = keys[i];
-            const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
-            v = ((key >> q) & 1ull) ? (ushort_t)0x3F80 : (ushort_t)0xBF80;      // +1.0 / -1.0
-            if (save.x != nullptr) save.x[i * save.x_ld + k] = ((key >> q) & 1ull) ? 1.0f : -1.0f;
+            bool set;
+            if (wamp != nullptr) {                                              // occupation strings already gathered in LDS
+                const uint32_t ab = s_ab[r];
+                set = k < P - 1 ? ((ab >> k) & 1u) : ((ab >> (16 + k - (P - 1))) & 1u);
+            } else {
+                const uint64_t key = keys[i];
+                const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
+                set = (key >> q) & 1ull;
+            }
+            v = set ? (ushort_t)0x3F80 : (ushort_t)0xBF80;                      // +1.0 / -1.0
+            if (save.x != nullptr) save.x[i * save.x_ld + k] = set ? 1.0f : -1.0f;
         }
         planes[r * ldh + k] = v;
         planes[BM * ldh + r * ldh + k] = 0;
@@ -508,9 +722,12 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     }
     __syncthreads();
 
-    for (int l = 0; l < d.n_lin; ++l)
+    NAQS_MARK(4);
+    for (int l = 0; l < d.n_lin; ++l) {
         mlp_layer_h<RB>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
                         l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M);
+        NAQS_MARK(5 + l);
+    }
 
     if (tid < BM) {
         const int64_t i = row0 + tid;
@@ -544,6 +761,41 @@ __global__ __launch_bounds__(256) void pack_phase_bf16_kernel(const float *__res
 // amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]] ->
 // Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
 struct AmpSrcOff { int64_t off[MAXP]; };
+
+// amplitude blocks as MFMA operand fragments (3 bf16 planes): per pair W1 [3][Ha/16][64][8] then W2 [3][Ha/32][64][8]
+__global__ __launch_bounds__(256) void pack_amp_mfma_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
+                                                            ushort_t *__restrict__ wamp) {
+    const int n = blockIdx.y;
+    const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
+    const int CT = Ha >> 4, KC = Ha >> 5;
+    const float *src = flat + so.off[n];
+    const float *W1 = src, *W2 = src + Ha * nin + Ha;
+    const size_t pair = amp_mfma_pair_elems(Ha);
+    ushort_t *dst = wamp + (size_t)n * pair;
+    if (blockIdx.x == 0 && threadIdx.x < 16)
+        reinterpret_cast<float *>(dst + (size_t)3 * 512 * (CT + KC))[threadIdx.x] =
+            (int)threadIdx.x < nout ? src[Ha * nin + Ha + nout * Ha + threadIdx.x] : 0.0f;
+    const int frag1 = CT * 512, frag2 = KC * 512;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < frag1 + frag2; e += gridDim.x * 256) {
+        float x;
+        size_t o0, plane;
+        if (e < frag1) {            // e = (ct * 64 + l) * 8 + j  <-  W1[ct*16 + (l&15)][8 (l>>4) + j]
+            const int j = e & 7, l = (e >> 3) & 63, ct = e >> 9;
+            const int h = ct * 16 + (l & 15), k = 8 * (l >> 4) + j;
+            x = (n > 0 && k < nin) ? W1[h * nin + k] : (k == 31 ? src[Ha * nin + h] : 0.0f);     // input 31 == 1 carries b1
+            o0 = (size_t)e; plane = (size_t)frag1;
+        } else {                    // e' = (kc * 64 + l) * 8 + j  <-  W2[l&15][kc*32 + 8 (l>>4) + j]
+            const int e2 = e - frag1;
+            const int j = e2 & 7, l = (e2 >> 3) & 63, kc = e2 >> 9;
+            const int c = l & 15, k = kc * 32 + 8 * (l >> 4) + j;
+            x = c < nout ? W2[c * Ha + k] : 0.0f;
+            o0 = (size_t)3 * frag1 + e2; plane = (size_t)frag2;
+        }
+        ushort_t h1, h2, h3;
+        split3(x, h1, h2, h3);
+        dst[o0] = h1; dst[o0 + plane] = h2; dst[o0 + 2 * plane] = h3;
+    }
+}
 
 // every amplitude block in one launch: blockIdx.y = pair n, rows [W1[j][:] | b1[j] | W2[:][j] | pad] + b2
 __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
@@ -676,6 +928,10 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cu_count = prop.multiProcessorCount;
         if (hipMalloc((void **)&net->d_w, (size_t)net->w_floats * sizeof(float)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMalloc((void **)&net->d_wh, (size_t)net->wh_elems * sizeof(unsigned short)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        if (st == NAQS_OK && (d.Ha == 32 || d.Ha == 64)) {   // amplitude blocks as MFMA fragments (phase kernel prologue);
+            const size_t elems = (size_t)P * amp_mfma_pair_elems(d.Ha);   // input slot 31 must be free for the bias: 2 (P - 1) <= 30
+            if (hipMalloc((void **)&net->d_wamp, elems * sizeof(unsigned short)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        }
         // the activation tile of 48/64 rows x 516 floats exceeds the 64 KiB default of dynamic LDS
         const int lds_max = 4 * 16 * d.ld * (int)sizeof(float);
         if (lds_max > 160 * 1024) st = NAQS_ERR_UNSUPPORTED;
@@ -702,6 +958,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     (void)net->prof.enable(0);
     if (net->d_w) (void)hipFree(net->d_w);
     if (net->d_wh) (void)hipFree(net->d_wh);
+    if (net->d_wamp) (void)hipFree(net->d_wamp);
     if (net->d_scratch) (void)hipFree(net->d_scratch);
     if (net->d_samp) (void)hipFree(net->d_samp);
     if (net->d_gpart) (void)hipFree(net->d_gpart);
@@ -762,6 +1019,13 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
                            d.Kh_pad[l], d.N_pad[l], net->d_wh + d.wh_off[l]);
         HIP_TRY(hipGetLastError());
     }
+    if (net->d_wamp) {
+        AmpSrcOff so;
+        for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
+        const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
+        hipLaunchKernelGGL(pack_amp_mfma_kernel, dim3((frag + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_wamp);
+        HIP_TRY(hipGetLastError());
+    }
     st = naqs::net_pack_backward_weights(net, flat_dev, s);
     if (st != NAQS_OK) return st;
     net->have_weights = net->have_amp_weights = true;
@@ -798,13 +1062,27 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
-    if (st != NAQS_OK) return st;
-
-    // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA
     const size_t lds_h16 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
     const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;
+    // amplitude conditionals inside the phase kernel (matrix cores) unless NAQS_AMP_MODE=0 or the width does not tile
+    const size_t amp_scratch = (size_t)PH_WAVES * 48 * (d.Ha + 8) * sizeof(unsigned short) + (size_t)d.P * 48 * 8 * sizeof(float);
+    const bool amp_in_phase = use_h && net->d_wamp != nullptr && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
+                              amp_scratch <= 3 * lds_h16;
+    if (!amp_in_phase) {
+        st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
+        if (st != NAQS_OK) return st;
+    }
+    const unsigned short *wamp = amp_in_phase ? net->d_wamp : nullptr;
+    naqs::PhaseSave save_dbg = save;
+    long long *clk_dev = nullptr;
+    if (naqs::env_int("NAQS_DEBUG_CLOCKS", 0) == 1) {            // developer aid: phase boundaries of workgroup 0, in cycles
+        HIP_TRY(hipMalloc((void **)&clk_dev, 128 * sizeof(long long)));
+        HIP_TRY(hipMemset(clk_dev, 0, 128 * sizeof(long long)));
+        save_dbg.clk = clk_dev;
+    }
+
+    // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the bf16x3 kernel only
     const int rb_max = use_h ? 3 : 4;
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
@@ -815,11 +1093,11 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
     if (use_h) {
-        const size_t lds = rb * lds_h16;
+        const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save); break;
-            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save); break;
-            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save); break;
+            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
+            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
+            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
         }
     } else {
         const size_t lds = (size_t)bm * d.ld * sizeof(float);
@@ -832,6 +1110,16 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     }
     HIP_TRY(hipGetLastError());
     if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
+    if (clk_dev) {
+        long long h[128];
+        HIP_TRY(hipMemcpy(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(clk_dev);
+        for (int wv = 0; wv < 8; ++wv) {
+            std::fprintf(stderr, "[naqs clocks] wave %d:", wv);
+            for (int k = 1; k < 9; ++k) std::fprintf(stderr, " %lld", h[wv * 16 + k] ? h[wv * 16 + k] - h[wv * 16] : 0ll);
+            std::fprintf(stderr, "\n");
+        }
+    }
     return NAQS_OK;
 }
 

@@ -140,6 +140,7 @@ struct naqs_net {
     float *d_w = nullptr;                   // [amp params | packed phase layers]
     unsigned short *d_wh = nullptr;         // phase layers as 3 bf16 planes (phase_kernel_bf16x3)
     int64_t wh_elems = 0;
+    unsigned short *d_wamp = nullptr;       // amplitude blocks as bf16x3 MFMA fragments (phase kernel prologue); null: amp_kernel
     int64_t w_floats = 0;
     float *d_scratch = nullptr;             // [P][cap_M] log-amplitude contributions
     int64_t cap_M = 0;
@@ -165,6 +166,7 @@ struct PhaseSave {
     int x_ld = 0;
     float *act[MAXL] = {};                  // post-ReLU activations of hidden layer l: [M][act_ld[l]]
     int act_ld[MAXL] = {};
+    long long *clk = nullptr;               // NAQS_DEBUG_CLOCKS=1: [8 waves][16 marks] cycle counter of workgroup 0
 };
 // naqs_logpsi.hip: amp_kernel + phase kernel -> (log|psi|, phase)
 int net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,

@@ -208,7 +208,7 @@ def test_fused_training_forward_backward_matches_autograd(mol):
     lp = fused.log_psi_train(keys)
     grads = torch.autograd.grad((lp * g).sum(), params, allow_unused=True)
     assert torch.max(torch.abs(lp - lp_ref)).item() < 5e-5
-    assert torch.equal(lp[:, 0], fused.log_psi(keys)[:, 0])              # same kernel as the inference path
+    assert torch.allclose(lp[:, 0], fused.log_psi(keys)[:, 0], rtol=0, atol=2e-6)   # VALU amp_kernel vs the MFMA prologue of the phase kernel
     for (name, _), a, b in zip(wf.model.named_parameters(), grads, grads_ref):
         if b is None:
             assert a is None or float(a.abs().max()) == 0.0, name
