@@ -154,7 +154,7 @@ def main():
                    n_beta_electrons=ham_p.n_beta)
     wf = NAQSComplex_NADE_orbitals(hil, device=dev, **wf_args)
     from naqs_amd.fused import FusedLogPsi
-    fused = FusedLogPsi(wf)                            # libnaqs_hip.so: amp_kernel + MFMA phase_kernel
+    fused = FusedLogPsi(wf)                            # libnaqs_hip.so: MFMA log-psi kernel
     log_psi = torch.empty((M, 2), dtype=torch.float32, device=dev)
     weights = torch.as_tensor(counts_np / counts_np.sum(), dtype=torch.float64, device=dev)
     ham.reserve(M)
@@ -162,7 +162,8 @@ def main():
     acc = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def step():
-        # one library call: amp_kernel (+ hash build) -> phase kernel (+ psi in f64) -> eloc_kernel -> reduce_kernel
+        # one library call: phase kernel (amplitude conditionals + phase MLP on the matrix cores; builds the key hash and
+        # psi in f64) -> eloc_kernel -> reduce_kernel
         fused.log_psi_and_local_energy(ham, keys, weights=weights, log_psi_out=log_psi, eloc_out=eloc, sums_out=acc)
         if world > 1:
             dist.all_reduce(acc)
@@ -206,6 +207,11 @@ def main():
         # phase MLP: 2*(K*N) flops per layer and sample (18->512->512->4 for N2), f32 matrix cores
         dims = [max(1, 2 * (ham.n_qubits // 2 - 1)), 512, 512, 4]
         flops = 2.0 * M * sum(a * b for a, b in zip(dims, dims[1:]))
+        # ... and, unless NAQS_AMP_MODE=0 keeps them in their own kernel, the amplitude blocks (pair n: 2n -> 64 -> 5)
+        # evaluated in the same launch (2 * sum_n (max(1, 2n) * 64 + 64 * 5) flops per sample)
+        amp_in_kernel = os.environ.get("NAQS_AMP_MODE", "1") == "1" and os.environ.get("NAQS_PHASE_MODE", "1") == "1"
+        if amp_in_kernel:
+            flops += 2.0 * M * sum(max(1, 2 * n) * 64 + 64 * 5 for n in range(ham.n_qubits // 2))
         t_mlp = mlp_ms / max(mlp_launches, 1) * 1e-3
         mlp_tf = flops / t_mlp / 1e12 if t_mlp > 0 else 0.0
         # The kernel evaluates the f32 network with every operand split into three bf16 planes (six exact cross
@@ -216,7 +222,8 @@ def main():
         bf16_mode = os.environ.get("NAQS_PHASE_MODE", "1") == "1"
         mlp_roof = {"bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": mlp_tf / MFMA_F32_PEAK_TF, "traffic": None,
-                    "kernel": "phase_kernel_bf16x3 (f32 via 3-way bf16 split, v_mfma_f32_16x16x32_bf16)" if bf16_mode
+                    "kernel": ("phase_kernel_bf16x3 (" + ("amplitude conditionals + " if amp_in_kernel else "") +
+                               "phase MLP; f32 via 3-way bf16 split, v_mfma_f32_16x16x32_bf16)") if bf16_mode
                               else "phase_kernel (f32 MFMA 16x16x4)",
                     "kernel_us": t_mlp * 1e6, "algorithmic_flops_per_launch": flops}
         if bf16_mode:

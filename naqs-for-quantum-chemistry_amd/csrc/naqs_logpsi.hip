@@ -356,6 +356,26 @@ __device__ __forceinline__ void split3t(float x, ushort_t &h1, ushort_t &h2, ush
     h3 = (ushort_t)(__float_as_uint(r2) >> 16);
 }
 
+// Output column of MFMA tile cb, tile column nn.  When a layer's width is a multiple of 64 the four tiles of a wave are
+// interleaved (column = 64 (cb / 4) + 4 nn + cb % 4): a lane then owns four ADJACENT columns of every row, and the
+// write-back packs them into one 8-byte LDS store per plane with no cross-lane traffic.
+__host__ __device__ __forceinline__ int tile_col(int cb, int nn, int N_pad) {
+    return (CBT == 4 && (N_pad & 63) == 0) ? ((cb >> 2) << 6) + 4 * nn + (cb & 3) : cb * 16 + nn;
+}
+
+// the same split for two values at once, each plane already packed as (hi << 16) | lo: v_perm_b32 picks the two upper
+// halves in one instruction (the write-back is VALU-bound: two waves per SIMD, 48 values per lane)
+__device__ __forceinline__ void split3t_pair(float lo, float hi, uint32_t &w1, uint32_t &w2, uint32_t &w3) {
+    constexpr uint32_t SEL = 0x07060302u;                  // bytes {hi.3, hi.2, lo.3, lo.2}
+    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+    w1 = __builtin_amdgcn_perm(b, a, SEL);
+    const float ra = lo - __uint_as_float(a & 0xFFFF0000u), rb = hi - __uint_as_float(b & 0xFFFF0000u);
+    a = __float_as_uint(ra); b = __float_as_uint(rb);
+    w2 = __builtin_amdgcn_perm(b, a, SEL);
+    const float sa = ra - __uint_as_float(a & 0xFFFF0000u), sb = rb - __uint_as_float(b & 0xFFFF0000u);
+    w3 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), SEL);
+}
+
 template <int RB, int NC>
 __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
                                                  const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
@@ -393,11 +413,11 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
 }
 
 // one layer: planes[3][BM][ldh] (bf16) -> planes (hidden layers) or f32 out[BM][16] in the same LDS (last layer)
-template <int RB>
+template <int RB, bool SAVE>
 __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int ldh, int Kh_pad, int N_pad,
                                             const ushort_t *__restrict__ W, const float *__restrict__ bias, bool last,
                                             int wave, int lane, float *__restrict__ save = nullptr, int save_ld = 0,
-                                            int64_t row0 = 0, int64_t M = 0) {
+                                            int64_t row0 = 0, int64_t M = 0, long long *clk = nullptr) {
     // save != nullptr (training forward): the post-ReLU activations of this hidden layer also go to HBM
     // ([M][save_ld] float32) for the backward pass
     constexpr int BM = RB * 16;
@@ -450,7 +470,7 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
                     split3t(hv, h1, h2, h3);
                     const int o = (t >> 4) * ldh + (t & 15);
                     planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
-                    if (save != nullptr && row0 + (t >> 4) < M) save[(row0 + (t >> 4)) * save_ld + (t & 15)] = hv;
+                    if (SAVE && save != nullptr && row0 + (t >> 4) < M) save[(row0 + (t >> 4)) * save_ld + (t & 15)] = hv;
                 }
             }
         }
@@ -459,31 +479,75 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
     }
     const int cb0 = wave * CBT;
     const int my_cb = min(CBT, max(0, ncb - cb0));       // wave-uniform
+    const bool inter = CBT == 4 && (N_pad & 63) == 0;     // interleaved column map (tile_col): my_cb == CBT for every wave
+    float bvs[CBT];                                       // fetched under the MFMAs, not after the barrier
+#pragma unroll
+    for (int c = 0; c < CBT; ++c) bvs[c] = c < my_cb ? bias[tile_col(cb0 + c, m, N_pad)] : 0.0f;
     const ushort_t *w_ptr = W + (size_t)cb0 * Kh_pad * 16 + lane * 8;
     if (my_cb == CBT) mlp_accumulate_h<RB, CBT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb >= 4) mlp_accumulate_h<RB, (CBT > 4 ? 4 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 3) mlp_accumulate_h<RB, (CBT > 3 ? 3 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 2) mlp_accumulate_h<RB, (CBT > 2 ? 2 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 1) mlp_accumulate_h<RB, 1>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 9] = clock64();
     __syncthreads();                                      // everyone is done reading the input
-    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the three planes
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 10] = clock64();
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the three planes.
+    // Neighbouring lanes hold neighbouring columns: the even lane takes rows 0,1 of both columns and the odd lane rows
+    // 2,3 (two DPP exchanges), so every LDS store is a full dword (two bf16) instead of a 2-byte store — half the
+    // store instructions of the write-back and no sub-dword merging.
+    if (inter && my_cb == CBT) {
+        const int col0 = (cb0 >> 2) * 64 + 4 * m;         // this lane's four adjacent columns: tile c <-> col0 + c
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = fmaxf(acc[rb][c % CBT][r] + bvs[c % CBT], 0.0f);
+                const int row = rb * 16 + kg * 4 + r;
+                if (SAVE && save != nullptr && row0 + row < M)
+                    *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) = (f32x4){h[0], h[1], h[2], h[3]};
+                uint32_t a1, a2, a3, b1, b2, b3;
+                split3t_pair(h[0], h[1], a1, a2, a3);
+                split3t_pair(h[2], h[3], b1, b2, b3);
+                ushort_t *dst = planes + row * ldh + col0;                              // 8-byte aligned
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(dst + 2 * plane_stride) = make_uint2(a3, b3);
+            }
+        __syncthreads();
+        return;
+    }
+    uint32_t *planes32 = reinterpret_cast<uint32_t *>(planes);
+    const int ldw = ldh >> 1, plane_w = plane_stride >> 1;
+    const bool odd = m & 1;
 #pragma unroll
     for (int c = 0; c < CBT; ++c) {
         if (c < my_cb) {
             const int col = (cb0 + c) * 16 + m;
-            const float bv = bias[col];
+            const float bv = bvs[c];
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb) {
+                float h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    ushort_t h1, h2, h3;
-                    const float hv = fmaxf(acc[rb][c][r] + bv, 0.0f);
-                    split3t(hv, h1, h2, h3);
+                    h[r] = fmaxf(acc[rb][c][r] + bv, 0.0f);
                     const int row = rb * 16 + kg * 4 + r;
-                    const int o = row * ldh + col;
-                    planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
-                    if (save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = hv;
+                    if (SAVE && save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = h[r];
                 }
+                const float x0 = __shfl_xor(odd ? h[0] : h[2], 1, 64), x1 = __shfl_xor(odd ? h[1] : h[3], 1, 64);
+                const float lo[2] = {odd ? x0 : h[0], odd ? x1 : h[1]}, hi[2] = {odd ? h[2] : x0, odd ? h[3] : x1};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t w1, w2, w3;
+                    split3t_pair(lo[j], hi[j], w1, w2, w3);
+                    const int o = (rb * 16 + kg * 4 + (odd ? 2 : 0) + j) * ldw + (col >> 1);
+                    planes32[o] = w1;
+                    planes32[plane_w + o] = w2;
+                    planes32[2 * plane_w + o] = w3;
+                }
+            }
         }
     }
     __syncthreads();
@@ -552,14 +616,22 @@ __device__ __forceinline__ void amp_mfma_item(const NetDims &d, const AmpFrag<CT
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, f.w1[p][ct], acc[ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                                       // D: row = 4 kg + r (sample), col = m (hidden)
-                ushort_t h1, h2, h3;
-                split3t(fmaxf(acc[ct][r], 0.0f), h1, h2, h3);
-                const int o = (4 * kg + r) * HLD + ct * 16 + m;
-                hs[o] = h1; hs[16 * HLD + o] = h2; hs[32 * HLD + o] = h3;
+        for (int r = 0; r < 4; ++r) {                       // D: row = 4 kg + r (sample); tile ct of lane m = hidden unit CT m + ct
+            ushort_t *dst = hs + (4 * kg + r) * HLD + CT * m;
+            uint32_t a1, a2, a3;
+            split3t_pair(fmaxf(acc[0][r], 0.0f), fmaxf(acc[1][r], 0.0f), a1, a2, a3);
+            if (CT == 4) {
+                uint32_t b1, b2, b3;
+                split3t_pair(fmaxf(acc[2 % CT][r], 0.0f), fmaxf(acc[3 % CT][r], 0.0f), b1, b2, b3);
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(dst + 16 * HLD) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(dst + 32 * HLD) = make_uint2(a3, b3);
+            } else {
+                *reinterpret_cast<uint32_t *>(dst) = a1;
+                *reinterpret_cast<uint32_t *>(dst + 16 * HLD) = a2;
+                *reinterpret_cast<uint32_t *>(dst + 32 * HLD) = a3;
             }
+        }
     }
     // the scratch is private to this wave: LDS operations of a wave complete in order, so a wave-level fence suffices
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -664,7 +736,9 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
     __syncthreads();
 }
 
-template <int RB>
+// SAVE: training forward (inputs and hidden activations also go to HBM); a template parameter because the stores'
+// address arithmetic and bounds branches are ~40 % of the write-back's instructions even when they are skipped
+template <int RB, bool SAVE>
 __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims d, const float *__restrict__ w,
                                                                   const ushort_t *__restrict__ wh, int64_t M,
                                                                   const uint64_t *__restrict__ keys,
@@ -714,7 +788,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
                 set = (key >> q) & 1ull;
             }
             v = set ? (ushort_t)0x3F80 : (ushort_t)0xBF80;                      // +1.0 / -1.0
-            if (save.x != nullptr) save.x[i * save.x_ld + k] = set ? 1.0f : -1.0f;
+            if (SAVE && save.x != nullptr) save.x[i * save.x_ld + k] = set ? 1.0f : -1.0f;
         }
         planes[r * ldh + k] = v;
         planes[BM * ldh + r * ldh + k] = 0;
@@ -724,8 +798,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
 
     NAQS_MARK(4);
     for (int l = 0; l < d.n_lin; ++l) {
-        mlp_layer_h<RB>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
-                        l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M);
+        mlp_layer_h<RB, SAVE>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
+                        l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M, l == 0 ? save.clk : nullptr);
         NAQS_MARK(5 + l);
     }
 
@@ -749,7 +823,7 @@ __global__ __launch_bounds__(256) void pack_phase_bf16_kernel(const float *__res
         // e = ((cb * KC + kc) * 64 + kg * 16 + nn) * 8 + j   <-   W[cb*16 + nn][kc*32 + kg*8 + j]
         const int j = e & 7, nn = (e >> 3) & 15, kg = (e >> 7) & 3, blk = e >> 9;
         const int KC = Kh_pad >> 5, cb = blk / KC, kc = blk - cb * KC;
-        const int n = cb * 16 + nn, k = kc * 32 + kg * 8 + j;
+        const int n = tile_col(cb, nn, N_pad), k = kc * 32 + kg * 8 + j;
         const float x = (n < N && k < K) ? src[n * K + k] : 0.0f;
         ushort_t h1, h2, h3;
         split3(x, h1, h2, h3);
@@ -781,7 +855,7 @@ __global__ __launch_bounds__(256) void pack_amp_mfma_kernel(const float *__restr
         size_t o0, plane;
         if (e < frag1) {            // e = (ct * 64 + l) * 8 + j  <-  W1[ct*16 + (l&15)][8 (l>>4) + j]
             const int j = e & 7, l = (e >> 3) & 63, ct = e >> 9;
-            const int h = ct * 16 + (l & 15), k = 8 * (l >> 4) + j;
+            const int h = CT * (l & 15) + ct, k = 8 * (l >> 4) + j;      // a lane's CT tiles are CT adjacent hidden units
             x = (n > 0 && k < nin) ? W1[h * nin + k] : (k == 31 ? src[Ha * nin + h] : 0.0f);     // input 31 == 1 carries b1
             o0 = (size_t)e; plane = (size_t)frag1;
         } else {                    // e' = (kc * 64 + l) * 8 + j  <-  W2[l&15][kc*32 + 8 (l>>4) + j]
@@ -941,9 +1015,13 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4 * 3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
             const int ldsh = 3 * 16 * d.ldh * (int)sizeof(unsigned short);      // per 16 rows
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            // (the amplitude prologue's scratch can exceed one 16-row slab: allow the maximum for every variant)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
         }
     }
     if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
@@ -1095,9 +1173,12 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     if (use_h) {
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel_bf16x3<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
-            case 2: hipLaunchKernelGGL(phase_kernel_bf16x3<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
-            default: hipLaunchKernelGGL(phase_kernel_bf16x3<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
+            case 1: if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_bf16x3<1, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp);
+                    else hipLaunchKernelGGL((phase_kernel_bf16x3<1, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
+            case 2: if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_bf16x3<2, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp);
+                    else hipLaunchKernelGGL((phase_kernel_bf16x3<2, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
+            default: if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_bf16x3<3, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp);
+                    else hipLaunchKernelGGL((phase_kernel_bf16x3<3, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
         }
     } else {
         const size_t lds = (size_t)bm * d.ld * sizeof(float);
@@ -1116,7 +1197,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         (void)hipFree(clk_dev);
         for (int wv = 0; wv < 8; ++wv) {
             std::fprintf(stderr, "[naqs clocks] wave %d:", wv);
-            for (int k = 1; k < 9; ++k) std::fprintf(stderr, " %lld", h[wv * 16 + k] ? h[wv * 16 + k] - h[wv * 16] : 0ll);
+            for (int k = 1; k < 11; ++k) std::fprintf(stderr, " %lld", h[wv * 16 + k] ? h[wv * 16 + k] - h[wv * 16] : 0ll);
             std::fprintf(stderr, "\n");
         }
     }
