@@ -109,3 +109,38 @@ def test_large_sample_counts_n2():
     f = counts.double().cpu().numpy() / n
     big = p > 1e-6
     assert np.max(np.abs(f[big] / p[big] - 1)) < 5e-3
+
+
+def test_thirty_qubit_network_sample_logpsi_and_gradients():
+    """Li2O-sized network (15 orbital pairs: the widest amplitude blocks, 28 inputs) with random weights: the sampler's
+    structural guarantees, probs == |psi|^2 of the matrix-core log-psi kernel, and the HIP backward against autograd."""
+    from naqs_amd.hilbert import Encoding, Hilbert
+    from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+    torch.manual_seed(3)
+    hil = Hilbert.get(30, 7, 7, encoding=Encoding.SIGNED)
+    wf = NAQSComplex_NADE_orbitals(hil, device="cuda", qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512],
+                                   use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=False,
+                                   n_alpha_electrons=7, n_beta_electrons=7)
+    fused = wf.fused()
+    keys, counts, probs = fused.sample(60000, seed=9, max_unique=100000)          # (10^7 draws would exceed the cap: near-uniform psi)
+    k = keys.cpu().numpy()
+    assert len(k) > 1000 and np.all(np.diff(k) > 0) and hil.is_physical(k).all()
+    assert 0 < counts.sum().item() <= 60000
+    lp = fused.log_psi(keys)
+    assert torch.allclose(probs.double(), (2.0 * lp[:, 0].double()).exp(), rtol=3e-4, atol=1e-30)
+    # torch modules on the same states
+    sub = keys[:: max(1, len(keys) // 2000)].contiguous()
+    states = hil.idx2state(sub)
+    lp_ref = wf.log_psi(states).reshape(-1, 2)
+    assert torch.max(torch.abs(fused.log_psi(sub) - lp_ref.detach())).item() < 1e-4
+    g = torch.randn((len(sub), 2), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) / len(sub)
+    params = list(wf.model.parameters())
+    grads_ref = torch.autograd.grad((lp_ref * g).sum(), params, allow_unused=True)
+    for p in params:
+        p.grad = None
+    lp_t, saved = fused.forward_saved(sub)
+    fused.backward_saved(saved, g)
+    for (name, p), b in zip(wf.model.named_parameters(), grads_ref):
+        ref = torch.zeros_like(p) if b is None else b
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((p.grad - ref).abs().max()) < 2e-4 * scale + 1e-9, (name, float((p.grad - ref).abs().max()), scale)
