@@ -69,10 +69,7 @@ __global__ __launch_bounds__(PREP_BLOCK) void prep_kernel(int64_t M, const uint6
         const KT k = (KT)keys[i];
         keys_out[i] = k;
         hash_insert(tab, bits, tag, k, (uint32_t)i);
-        if (bloom != nullptr) {
-            const uint32_t b = bloom_bit(k);
-            atomicOr(&bloom[b >> 5], 1u << (b & 31));
-        }
+        if (bloom != nullptr) naqs::bloom_insert<KT>(bloom, k);
         double a, b;
         if (psi_kind == NAQS_PSI_F32 || psi_kind == NAQS_LOGPSI_F32) {
             const float2 v = reinterpret_cast<const float2 *>(psi_in)[i];
@@ -225,10 +222,7 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
     // LDS-resident Bloom filter does not rule it out
     auto physical = [&](KT j) {
         bool ok = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
-        if (BLOOM && ok) {
-            const uint32_t b = bloom_bit(j);
-            ok = (s_bloom[b >> 5] >> (b & 31)) & 1u;
-        }
+        if (BLOOM && ok) ok = naqs::bloom_test<KT>(s_bloom, j);
         return ok;
     };
 
