@@ -51,7 +51,8 @@ constexpr int BLOCK = 256;                 // helper kernels: 4 waves, one per S
 #define NAQS_LIGHT_BATCH 2
 #endif
 constexpr int LIGHT_BATCH = NAQS_LIGHT_BATCH;             // 64-group chunks probed together (all loads in flight before any is used)
-constexpr int QUEUE_CAP = 64 * (LIGHT_BATCH + 1);   // per-wave hit queue: < 64 carried + LIGHT_BATCH x 64 pushed per batch
+constexpr int LIGHT_BATCH_BLOOM = 4;                      // Bloom variant (VALU-bound candidate loop): amortise the per-batch scaffolding
+constexpr int queue_cap(bool bloom) { return 64 * ((bloom ? LIGHT_BATCH_BLOOM : LIGHT_BATCH) + 1); }   // per-wave hit queue: < 64 carried + batch x 64 pushed
 constexpr int LDS_BUDGET = 78 * 1024;      // per-workgroup dynamic LDS budget (160 KiB/CU -> 2 WGs/CU)
 constexpr int LDS_BUDGET_BLOOM = 152 * 1024;   // Bloom variant: one workgroup per CU
 constexpr int HEAVY_TERMS = 8;             // groups with more terms than this are "heavy"
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
     // LDS layout: [c_t: K doubles][queue: NWAVES*QUEUE_CAP int2][row_ptr: Kxy+1 (+pad)][xy: Kxy KT][yz: K KT]
     double *s_c = reinterpret_cast<double *>(smem);
     int2 *s_queue = reinterpret_cast<int2 *>(s_c + (STAGE >= 2 ? p.K : 0));
+    constexpr int QUEUE_CAP = queue_cap(BLOOM);
     int32_t *s_rp = reinterpret_cast<int32_t *>(s_queue + NWAVES * QUEUE_CAP);
     KT *s_xy = reinterpret_cast<KT *>(s_rp + (STAGE >= 1 ? (p.Kxy + 2) & ~1 : 0));
     KT *s_yz = s_xy + (STAGE >= 1 ? p.Kxy : 0);
@@ -289,22 +291,23 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
                 qn += __popcll(hits);
             }
         };
-        for (int g0 = p.light_begin; g0 < p.Kxy; g0 += LIGHT_BATCH * WAVE) {
-            // all LIGHT_BATCH probes of a lane are issued before the first one is looked at: one L2 round trip
+        constexpr int LB = BLOOM ? LIGHT_BATCH_BLOOM : LIGHT_BATCH;
+        for (int g0 = p.light_begin; g0 < p.Kxy; g0 += LB * WAVE) {
+            // all LB probes of a lane are issued before the first one is looked at: one L2 round trip
             // per 256 groups instead of one per 64
-            KT j[LIGHT_BATCH];
-            uint32_t hh[LIGHT_BATCH];
-            bool ph[LIGHT_BATCH];
-            decltype(probe_load(tab, 0u)) first[LIGHT_BATCH];
+            KT j[LB];
+            uint32_t hh[LB];
+            bool ph[LB];
+            decltype(probe_load(tab, 0u)) first[LB];
 #pragma unroll
-            for (int u = 0; u < LIGHT_BATCH; ++u) {
+            for (int u = 0; u < LB; ++u) {
                 const int g = g0 + u * WAVE + lane;
                 j[u] = 0; hh[u] = 0; ph[u] = false;
                 if (g < p.Kxy) { j[u] = key ^ xy[g]; ph[u] = physical(j[u]); }
                 if (ph[u]) { hh[u] = hash_key(j[u], p.bits); first[u] = probe_load(tab, hh[u]); }
             }
 #pragma unroll
-            for (int u = 0; u < LIGHT_BATCH; ++u) {
+            for (int u = 0; u < LB; ++u) {
                 const int idx = ph[u] ? probe_resolve(tab, p.bits, p.tag, j[u], hh[u], first[u]) : -1;
                 push(g0 + u * WAVE + lane, idx);
             }
@@ -555,7 +558,7 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
         p.rows_per_block = rpb;
     }
     const int grid2 = (int)((n_rows + rpb - 1) / rpb);
-    const size_t q_bytes = (size_t)nwaves * QUEUE_CAP * sizeof(int2) + 16;
+    const size_t q_bytes = (size_t)nwaves * queue_cap(bloom) * sizeof(int2) + 16;
     const size_t g_bytes = (size_t)((h->Kxy + 2) & ~1ll) * sizeof(int32_t) + (size_t)h->Kxy * sizeof(KT);
     const size_t t_bytes = (size_t)h->K * (sizeof(double) + sizeof(KT));
     const int force = env_int("NAQS_STAGE", -1);   // tuning/testing: 0 none, 1 groups, 2 groups+terms
