@@ -125,6 +125,15 @@ int naqs_eloc_reduced(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const 
 int naqs_eloc_reduce(naqs_ham_t *h, int64_t n, const double *w_dev, const double *eloc_dev,
                      double *out4_dev, void *stream);
 
+/*
+ * Matrix-free product with the Hamiltonian restricted to the sampled states: out_i = sum_j H_ij v_j over the M keys
+ * (complex float64 [M][2] in and out; H is real symmetric).  The mat-vec of get_H(idxs) (src/optimizer/hamiltonian.py:93-111)
+ * without materialising the sub-matrix — what the sampled-subspace diagonalisation of solve_H (src/optimizer/energy.py:762-786)
+ * needs once the sample set is too large for a dense M x Kxy table.  Same kernel and row sharding as naqs_eloc.
+ */
+int naqs_hmatvec(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const double *v_dev, int64_t row_begin,
+                 int64_t n_rows, double *out_dev, void *stream);
+
 /* ---- inner ring: device versions of the three Cython entry points the reference imports ---- */
 
 /* src.utils.hamiltonian_math.popcount_parity (hamiltonian_math.pyx:455-484):

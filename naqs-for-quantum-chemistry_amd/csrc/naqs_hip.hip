@@ -114,6 +114,7 @@ struct ElocParams {
     // rows to produce
     int64_t row_begin, n_rows;
     int32_t rows_per_block;
+    int32_t matvec;          // 1: store sum_j H_ij psi_j itself (naqs_hmatvec) instead of conj(. / psi_i)
     double2 *eloc;           // [n_rows]
 };
 
@@ -324,8 +325,12 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
         sr = wave_sum(sr);
         si = wave_sum(si);
         if (lane == 0) {
-            const double2 q = cdiv(make_double2(sr, si), psi_i);
-            p.eloc[r] = make_double2(q.x, -q.y);   // conj, energy.py:248
+            if (p.matvec) {
+                p.eloc[r] = make_double2(sr, si);
+            } else {
+                const double2 q = cdiv(make_double2(sr, si), psi_i);
+                p.eloc[r] = make_double2(q.x, -q.y);   // conj, energy.py:248
+            }
         }
     }
 
@@ -513,7 +518,7 @@ int launch_prep(naqs_ham *h, int64_t M, const uint64_t *keys_dev, const void *ps
 
 template <typename KT>
 int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_begin, int64_t n_rows, double *eloc_dev,
-                const double *w_dev, double *out4_dev, hipStream_t s) {
+                const double *w_dev, double *out4_dev, hipStream_t s, bool matvec = false) {
     const int bits = f.bits;
     const uint32_t tag = f.tag;
     auto *tab = reinterpret_cast<Slot<KT> *>(f.tab);
@@ -533,6 +538,7 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
     p.tab = tab; p.bits = bits; p.tag = tag;
     p.row_begin = row_begin; p.n_rows = n_rows;
     p.eloc = reinterpret_cast<double2 *>(eloc_dev);
+    p.matvec = matvec ? 1 : 0;
 
     // Workgroup shape.  The term tables are staged per workgroup, so big workgroups amortise the
     // staging; small batches still want every CU busy.  1024 threads = 16 waves = 4 per SIMD.
@@ -750,7 +756,7 @@ NAQS_API int naqs_ham_reserve(naqs_ham_t *h, int64_t M) {
 
 static int eloc_common(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const void *psi_dev, int psi_kind,
                        int64_t row_begin, int64_t n_rows, double *eloc_dev, const double *w_dev, double *out4_dev,
-                       void *stream) {
+                       void *stream, bool matvec = false) {
     if (!h || M < 0 || row_begin < 0 || n_rows < 0 || row_begin + n_rows > M) return NAQS_ERR_INVALID;
     if (psi_kind < NAQS_PSI_F32 || psi_kind > NAQS_LOGPSI_F64) return NAQS_ERR_INVALID;
     if (M > (int64_t)IDX_MASK) return NAQS_ERR_UNSUPPORTED;          // 24-bit sample index in a hash slot
@@ -770,8 +776,13 @@ static int eloc_common(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const
     st = h->key_bits == 32 ? launch_prep<uint32_t>(h, M, keys_dev, psi_dev, psi_kind, feed, s)
                            : launch_prep<uint64_t>(h, M, keys_dev, psi_dev, psi_kind, feed, s);
     if (st != NAQS_OK) return st;
-    return h->key_bits == 32 ? launch_main<uint32_t>(h, M, feed, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s)
-                             : launch_main<uint64_t>(h, M, feed, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s);
+    return h->key_bits == 32 ? launch_main<uint32_t>(h, M, feed, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s, matvec)
+                             : launch_main<uint64_t>(h, M, feed, row_begin, n_rows, eloc_dev, w_dev, out4_dev, s, matvec);
+}
+
+NAQS_API int naqs_hmatvec(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const double *v_dev, int64_t row_begin,
+                          int64_t n_rows, double *out_dev, void *stream) {
+    return eloc_common(h, M, keys_dev, v_dev, NAQS_PSI_F64, row_begin, n_rows, out_dev, nullptr, nullptr, stream, true);
 }
 
 // hooks for the fused log-psi + E_loc entry point in naqs_logpsi.hip

@@ -30,6 +30,7 @@ SIGNATURES = {
     "naqs_eloc": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp]),
     "naqs_eloc_reduced": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_eloc_reduce": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_hmatvec": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "naqs_popcount_parity": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "naqs_get_hij": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "naqs_csr_mv": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -120,6 +120,59 @@ class DevicePauliHamiltonian:
         _lib.check(st, "naqs_eloc_reduce")
         return out
 
+    # ---- H restricted to the sampled states, matrix-free ----------------------------------------
+    def matvec(self, keys, v, out=None):
+        """out_i = sum_j H_ij v_j over the sampled keys (``naqs_hmatvec``).  v: real [M] or complex-as-pairs [M, 2]
+        float64 device tensor; returns the same shape."""
+        M = keys.shape[0]
+        real = v.dim() == 1
+        vv = torch.stack([v, torch.zeros_like(v)], -1) if real else v
+        vv = vv.to(device=self.device, dtype=torch.float64).contiguous()
+        res = torch.empty((M, 2), dtype=torch.float64, device=self.device) if out is None or real else out
+        st = self._lib.naqs_hmatvec(self._h, M, keys.contiguous().data_ptr(), vv.data_ptr(), 0, M, res.data_ptr(),
+                                    _stream_ptr(self.device))
+        _lib.check(st, "naqs_hmatvec")
+        return res[:, 0].contiguous() if real else res
+
+    @torch.no_grad()
+    def lowest_eigenpair(self, keys, max_iter=400, tol=1e-10, seed=0):
+        """Lowest eigenpair of H restricted to the sampled keys by Lanczos with full re-orthogonalisation, every
+        product matrix-free on the device (no M x M or M x Kxy matrix is formed): the scalable form of the
+        sampled-subspace diagonalisation of solve_H (energy.py:762-786).  -> (eigenvalue, eigenvector float64 [M])."""
+        M = keys.shape[0]
+        if M == 0:
+            raise ValueError("empty sample set")
+        gen = torch.Generator(device=self.device).manual_seed(int(seed))
+        v = torch.randn(M, dtype=torch.float64, device=self.device, generator=gen)
+        v /= v.norm()
+        m_max = int(min(max_iter, M))
+        V = torch.empty((m_max, M), dtype=torch.float64, device=self.device)
+        alpha, beta = [], []
+        theta, s_vec, k = None, None, 0
+        for k in range(m_max):
+            V[k] = v
+            w = self.matvec(keys, v)
+            a = torch.dot(v, w)
+            w = w - a * v - (beta[-1] * V[k - 1] if k > 0 else 0.0)
+            for _ in range(2):                                   # full re-orthogonalisation, twice is enough
+                w = w - V[:k + 1].t() @ (V[:k + 1] @ w)
+            b = w.norm()
+            alpha.append(float(a))
+            T = np.diag(alpha)
+            if k > 0:
+                off = np.array(beta)
+                T = T + np.diag(off, 1) + np.diag(off, -1)
+            evals, evecs = np.linalg.eigh(T)
+            theta, s_vec = evals[0], evecs[:, 0]
+            resid = abs(float(b) * s_vec[-1])
+            if resid < tol * max(1.0, abs(theta)) or float(b) < 1e-14:
+                break
+            beta.append(float(b))
+            v = w / b
+        vec = torch.as_tensor(s_vec, dtype=torch.float64, device=self.device) @ V[:k + 1]
+        vec = vec / vec.norm()
+        return float(theta), vec
+
     # ---- inner ring ----------------------------------------------------------------------------
     def dense_hij(self, keys):
         """Device counterpart of get_Hij_cy: float64 [M, Kxy], H[i, key_i ^ xy_g]."""

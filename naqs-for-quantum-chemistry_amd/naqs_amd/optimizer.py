@@ -95,6 +95,7 @@ class OptimizerBase:
             self.generator.manual_seed(torch.initial_seed() % (2 ** 63))
         self._sampled_idxs, self._sampled_pending = Counter(), []
         self.track_sampled_idxs = True
+        self.solve_H_max_states = 10000       # energy.py:773-776
         self.use_fused = True                # HIP sampler / training kernels / FlatAdam when the network supports them
         self._loss_terms = self._last_loss = None
         self.reset_log()
@@ -382,10 +383,18 @@ class PartialSamplingOptimizer(OptimizerBase):
         with torch.no_grad():
             states, counts, probs = self.wavefunction.sample(n_samps, ret_log_psi=False, generator=self.generator)
         n_unq = len(states)
-        if n_unq > 10000:
-            print(f"Limiting number of sampled states from {n_unq} is to most likely 10000.")
-            states = states[torch.argsort(counts)[-10000:]]
+        limit = self.solve_H_max_states
+        if n_unq > limit:
+            print(f"Limiting number of sampled states from {n_unq} is to most likely {limit}.")
+            states = states[torch.argsort(counts)[-limit:]]
         keys = self.hilbert.state2idx(states).squeeze(-1)
+        if self.device.type == "cuda" and len(keys) >= 3:
+            # matrix-free Lanczos on the device: no sub-matrix is formed, so the reference's 10 000-state cap
+            # (there for the cost of the CSR slice) is only kept as the default of solve_H_max_states
+            val, vec = self.pauli_hamiltonian.lowest_eigenpair(keys_to_device(keys, self.device))
+            vec = vec.cpu().numpy()
+            vec = vec * np.sign(vec[0])
+            return (float(val), vec[0], n_unq) if ret_n_samps else (float(val), vec[0])
         H = self.pauli_hamiltonian.get_H(keys)
         if H.shape[0] < 3:
             w, v = np.linalg.eigh(H.toarray())
