@@ -7,8 +7,12 @@ M = 10 000 unique samples per GPU (BASELINE.json configs[1]).
 
 One "step" = one pass of the hot path over one batch of M unique sampled bit-strings that is
 already resident in HBM: (log-psi evaluation of the batch ->) hash build -> matrix-free E_loc ->
-weighted energy accumulators; with N > 1 every rank owns an independent batch (weak scaling) and
-the 4 energy accumulators are all-reduced over RCCL — the only collective on the path.
+weighted energy accumulators.  The K timed steps are K independent batches; two are in flight at
+a time (`--pipeline`, two HIP streams) so that the E_loc / reduce kernels of one batch overlap the
+log-psi kernel of the next; the serial figures are measured in the same run (`serial`,
+`roofline.isolated`).  With N > 1 every rank owns an independent batch stream (weak scaling) and the
+per-step energy accumulators [K, 4] are summed over the ranks by one RCCL all-reduce at the end of
+the timed region — the only collective on the path.
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and
 `cpu_baseline`.
 """
@@ -121,6 +125,10 @@ def main():
     ap.add_argument("--molecule", default="N2")
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-segment", action="store_true",
+                    help="after the timed region, run 200 more steps one batch at a time and report them under `serial`")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="independent batches in flight (HIP streams, one Hamiltonian/network handle pair each); 1 = serial")
     args = ap.parse_args()
 
     import torch
@@ -156,56 +164,87 @@ def main():
                    n_beta_electrons=ham_p.n_beta)
     wf = NAQSComplex_NADE_orbitals(hil, device=dev, **wf_args)
     from naqs_amd.fused import FusedLogPsi
-    fused = FusedLogPsi(wf)                            # libnaqs_hip.so: MFMA log-psi kernel
-    log_psi = torch.empty((M, 2), dtype=torch.float32, device=dev)
+    # Throughput of a STREAM of independent batches: `depth` of them are in flight, each on its own HIP stream with its
+    # own handle pair (a handle owns per-call scratch: hash table, psi table), so the E_loc / reduce kernels of one batch
+    # run beside the log-psi kernel of the next (which leaves 47 of 256 CUs idle on its own).  --pipeline 1 = one batch
+    # at a time; its step time is measured too and reported as `serial_ms_per_step`.
+    depth = max(1, args.pipeline)
+    hams = [ham] + [hamiltonian.DevicePauliHamiltonian(ham_p, device=dev) for _ in range(depth - 1)]
+    nets = [FusedLogPsi(wf) for _ in range(depth)]       # libnaqs_hip.so: MFMA log-psi kernel
+    fused = nets[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream(dev)]
+    log_psis = [torch.empty((M, 2), dtype=torch.float32, device=dev) for _ in range(depth)]
+    elocs = [torch.empty((M, 2), dtype=torch.float64, device=dev) for _ in range(depth)]
+    log_psi = log_psis[0]
     weights = torch.as_tensor(counts_np / counts_np.sum(), dtype=torch.float64, device=dev)
-    ham.reserve(M)
-    eloc = torch.empty((M, 2), dtype=torch.float64, device=dev)
+    for h_ in hams:
+        h_.reserve(M)
+    torch.cuda.synchronize()
     # energy accumulators: two buffers, so that the RCCL all-reduce of step k (4 doubles, latency-bound on xGMI) runs on
     # the collective stream under the kernels of step k+1 instead of in front of them
-    accs = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]
-    works = [None, None]
+    # energy accumulators: one row of 4 doubles per step, written by the reduce kernel of that step; with N > 1 GPUs the
+    # rows of the whole timed region are summed over the ranks by ONE RCCL all-reduce at its end (few, larger
+    # collectives: a per-step 32-byte all-reduce is pure xGMI latency and only a training step needs <E> that early)
+    acc_all = torch.zeros((args.warmup + args.steps + 201, 4), dtype=torch.float64, device=dev)
     use_dist = world > 1 or os.environ.get("NAQS_BENCH_FORCE_DIST") == "1"      # (forced at world 1: exercises the path)
     n_done = [0]
 
-    def step():
-        k = n_done[0] & 1
-        if works[k] is not None:
-            works[k].wait()                      # stream-side wait for the all-reduce that used this buffer two steps ago
-            works[k] = None
-        # one library call: phase kernel (amplitude conditionals + phase MLP on the matrix cores; builds the key hash and
-        # psi in f64) -> eloc_kernel -> reduce_kernel
-        fused.log_psi_and_local_energy(ham, keys, weights=weights, log_psi_out=log_psi, eloc_out=eloc, sums_out=accs[k])
-        if use_dist:
-            works[k] = dist.all_reduce(accs[k], async_op=True)
+    def step(d_override=None):
+        row = acc_all[n_done[0]]
+        d = (n_done[0] % depth) if d_override is None else d_override
+        with torch.cuda.stream(streams[d]):
+            # one library call: phase kernel (amplitude conditionals + phase MLP on the matrix cores; builds the key hash
+            # and psi in f64) -> eloc_kernel -> reduce_kernel
+            nets[d].log_psi_and_local_energy(hams[d], keys, weights=weights, log_psi_out=log_psis[d], eloc_out=elocs[d],
+                                             sums_out=row)
         n_done[0] += 1
 
-    def fence():
-        for k in range(2):
-            if works[k] is not None:
-                works[k].wait()
-                works[k] = None
+    def fence(first_row=None):
+        torch.cuda.synchronize()                 # every stream of this rank
         if use_dist:
+            if first_row is not None:
+                dist.all_reduce(acc_all[first_row:n_done[0]])
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    fence()
+    fence(first_row=0)                           # (also sets the communicator up outside the timed region)
     # kernel durations: hipEvent pairs on the launch stream around every PROF_STRIDE-th launch of the timed
     # region (an event pair costs ~4 us of queue time; recording all of them slows the step by ~15 %)
     stride = max(1, min(PROF_STRIDE, args.steps // 8))
-    ham.prof_enable(args.steps // stride + 1, stride)
-    fused.prof_enable(args.steps // stride + 1, stride)
+    for h_, n_ in zip(hams, nets):
+        h_.prof_enable(args.steps // stride + 1, stride)
+        n_.prof_enable(args.steps // stride + 1, stride)
+    first_timed = n_done[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    fence(first_row=first_timed)
     dt = time.perf_counter() - t0
-    kern_ms, launches = ham.prof_read()
-    ham.prof_enable(0)
-    mlp_ms, mlp_launches = fused.prof_read()
-    fused.prof_enable(0)
+    last_row = n_done[0] - 1
+    kern_ms = launches = mlp_ms = mlp_launches = 0
+    for h_, n_ in zip(hams, nets):
+        a, b = h_.prof_read(); kern_ms += a; launches += b
+        h_.prof_enable(0)
+        a, b = n_.prof_read(); mlp_ms += a; mlp_launches += b
+        n_.prof_enable(0)
+    # the same K steps one batch at a time (single stream, first handle pair): latency of a batch, and the kernels'
+    # durations when each has the GPU to itself
+    serial = None
+    if depth > 1 and world == 1 and args.serial_segment:
+        ks = min(args.steps, 200)
+        hams[0].prof_enable(ks // stride + 1, stride)
+        nets[0].prof_enable(ks // stride + 1, stride)
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            step(0)
+        fence()
+        dts = time.perf_counter() - t1
+        e_ms, e_n = hams[0].prof_read(); hams[0].prof_enable(0)
+        p_ms, p_n = nets[0].prof_read(); nets[0].prof_enable(0)
+        serial = {"ms_per_step": dts / ks * 1e3, "steps": ks, "eloc_kernel_us": e_ms / max(e_n, 1) * 1e3,
+                  "logpsi_kernel_us": p_ms / max(p_n, 1) * 1e3}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -213,7 +252,7 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
-        s = accs[(n_done[0] - 1) & 1].cpu().numpy()
+        s = acc_all[last_row].cpu().numpy()
         b_alg = algorithmic_bytes(M, ham.K, ham.Kxy)
         t_kernel = kern_ms / max(launches, 1) * 1e-3
         achieved = b_alg / t_kernel / 1e9 if t_kernel > 0 else 0.0
@@ -255,6 +294,25 @@ def main():
                 mlp_roof["traffic"] = pmc["phase_kernel"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        if serial is None and depth > 1 and args.molecule == "N2" and M == 10000:
+            # kernel durations of `bench.py --pipeline 1` on this workload, from the committed run (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_bench_n2_10k_serial.json")) as f:
+                    ser = json.load(f)
+                serial = {"ms_per_step": ser["ms_per_step"], "steps": ser["steps"], "source": "profiles/r01_bench_n2_10k_serial.json",
+                          "logpsi_kernel_us": ser["roofline"]["kernel_us"],
+                          "eloc_kernel_us": ser["roofline"]["other_kernels"][0]["kernel_us"]}
+            except (OSError, KeyError, ValueError, IndexError):
+                serial = None
+        if serial is not None:
+            # the same kernels with the GPU to themselves (one batch at a time): what the kernel itself achieves; the
+            # durations above are longer because the next batch's kernels share the CUs during the timed region
+            if serial["logpsi_kernel_us"] > 0:
+                tf = flops / (serial["logpsi_kernel_us"] * 1e-6) / 1e12
+                mlp_roof["isolated"] = {"kernel_us": serial["logpsi_kernel_us"], "achieved": tf, "frac": tf / MFMA_F32_PEAK_TF}
+            if serial["eloc_kernel_us"] > 0:
+                gb = b_alg / (serial["eloc_kernel_us"] * 1e-6) / 1e9
+                eloc_roof["isolated"] = {"kernel_us": serial["eloc_kernel_us"], "achieved": gb, "frac": gb / HBM_PEAK_GBS}
         dominant, other = (mlp_roof, eloc_roof) if t_mlp >= t_kernel else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]
@@ -270,11 +328,16 @@ def main():
                                    f"Kxy={ham.Kxy}), {M} unique samples per GPU, 1xMI355X per rank",
                        "stages": "fused NADE log-psi eval (amp 1x64, phase 2x512; builds the key hash + psi table) + matrix-free E_loc "
                                  "(f64) + weighted energy reduction"
-                                 + (" + RCCL all-reduce of 4 accumulators" if world > 1 else ""),
+                                 + (" + one RCCL all-reduce of the per-step accumulators [K, 4] at the end of the timed region"
+                                    if world > 1 else ""),
+                       "pipeline": (f"{depth} independent batches in flight on {depth} HIP streams (one handle pair each)"
+                                    if depth > 1 else "one batch at a time"),
                        "input": "unique sampled bit-strings (keys + int8 occupations) resident in HBM; random-init network",
                        "energy": float(s[0] / s[3])},
             "roofline": roofline,
         }
+        if serial is not None:
+            out["serial"] = serial
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np, wf_args)
     else:
