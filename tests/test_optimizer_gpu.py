@@ -132,3 +132,16 @@ def test_optimizer_uses_flat_adam_and_checkpoint_round_trip(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(w, wf2.model.parameters()))
     assert torch.equal(m, opt2.optimizer._m) and opt2.optimizer._t == 3 and opt2.n_steps == 3
     assert wf2._views_of(wf2._flat_params, list(wf2.model.parameters()))      # still flattened after load_state_dict
+
+
+def test_distributed_branches_of_the_step_on_one_gpu():
+    """nccl group of world size 1: the sharded-rows code of _SGD_step (table log psi through the inference kernel, row
+    shard through the training kernels, accumulator and flat-gradient all-reduces) gives the single-process energies."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_probe.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "distributed branches == single-process path" in r.stdout
