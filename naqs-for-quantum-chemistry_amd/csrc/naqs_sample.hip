@@ -68,34 +68,22 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, const float *__restrict__ w, const int n,
-                                                           const SampleBufs b, const int cur, const uint32_t k0,
-                                                           const uint32_t k1) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];
-    __shared__ uint32_t s_red[SB / WAVE];
-    const int64_t U = b.U[n];
-    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
+// One prefix, one quad of lanes (q = lane & 3): the hidden units of block n are split four ways, then lanes 0/1 draw the
+// two independent second-level binomials of the multinomial split in parallel.  Weights of pair n are in s_w (staged and
+// synchronised by the caller).  On return lane q == 0 holds the children counts (un-physical ones zeroed, nade.py:695)
+// and the float32 conditional probabilities p[c] = exp(log-amp)^2 (nade.py:673).
+__device__ __forceinline__ void expand_quad(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
+                                            const int64_t cnt, const uint32_t k0, const uint32_t k1, int64_t (&out)[4],
+                                            float (&p)[4]) {
+    const int q = threadIdx.x & 3;
     const int nin = n == 0 ? 1 : 2 * n;
     const int S = (nin + 1 + 5 + 3) & ~3;
-    {
-        const int total = d.Ha * S + 8;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(w + d.amp_off[n]);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(s_w);
-        for (int e = threadIdx.x; e < total / 4; e += SB) dst[e] = src[e];
-    }
-    // a quad of lanes per prefix: the hidden units are split four ways, then lanes 0/1 draw the two independent
-    // second-level binomials of the multinomial split in parallel
-    const int q = threadIdx.x & 3;
-    const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
-    const bool active = u < U;
-    const uint32_t ab = active ? b.ab[cur][u] : 0u;
     const uint32_t abits = ab & 0xffffu, bbits = ab >> 16;
     const bool swap = d.sym && abits > bbits;                                  // nade.py:519-530
     const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
     const int per = (d.Ha + 3) / 4;
     const int j0 = min(d.Ha, q * per), j1 = min(d.Ha, j0 + per);
     float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
     switch (n) {
 #define CASE(NB) case NB: naqs::amp_partial<NB>(d, s_w, first, second, j0, j1, o); break;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
@@ -111,17 +99,15 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
     bool ok[4], phys[4];
     naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
     naqs::amp_budget_mask(d, n, abits, bbits, phys);
-    float p[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float e = ok[c] ? expf(la[c]) : 0.0f;
-        p[c] = e * e;                                                           // float32, nade.py:673
+        p[c] = e * e;
     }
     // multinomial(count; p) as a binary tree of binomials (same distribution as the reference's conditional chain,
     // nade.py:31-35, two dependent rounds instead of three; the float64 renormalisation of :682-683 cancels in the
     // ratios): first {2,3} against {0,1}, then 1 within {0,1} and 3 within {2,3}
     const double p01 = (double)p[0] + (double)p[1], p23 = (double)p[2] + (double)p[3], tot = p01 + p23;
-    const int64_t cnt = active ? b.cnt[cur][u] : 0;
     int64_t n23 = 0;
     if (q == 0 && tot > 0.0) {
         naqs::RngStream g{k0, k1, ab, (uint32_t)n | (1u << 8), 0u, 0u};
@@ -137,13 +123,42 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
         hi = den > 0.0 ? naqs::binomial(m, fmin(1.0, num / den), g) : 0;
     }
     const int64_t n3 = __shfl(hi, ((int)(threadIdx.x & 63) & ~3) + 1, 64);
+    out[0] = n01 - hi; out[1] = hi; out[2] = n23 - n3; out[3] = n3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (!phys[c]) out[c] = 0;
+}
+
+__device__ __forceinline__ void stage_pair_weights(const NetDims &d, const float *__restrict__ w, const int n, float *s_w,
+                                                   const int nthreads) {
+    const int nin = n == 0 ? 1 : 2 * n;
+    const int total = d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(w + d.amp_off[n]);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(s_w);
+    for (int e = threadIdx.x; e < total / 4; e += nthreads) dst[e] = src[e];
+}
+
+__global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, const float *__restrict__ w, const int n,
+                                                           const SampleBufs b, const int cur, const uint32_t k0,
+                                                           const uint32_t k1) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    __shared__ uint32_t s_red[SB / WAVE];
+    const int64_t U = b.U[n];
+    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
+    stage_pair_weights(d, w, n, s_w, SB);
+    const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
+    const bool active = u < U;
+    const uint32_t ab = active ? b.ab[cur][u] : 0u;
+    const int64_t cnt = active ? b.cnt[cur][u] : 0;
+    __syncthreads();
+    int64_t out[4];
+    float p[4];
+    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
     uint32_t survivors = 0;
-    if (active && q == 0) {
-        int64_t out[4] = {n01 - hi, hi, n23 - n3, n3};
+    if (active && (threadIdx.x & 3) == 0) {
         const float pr = b.prob[cur][u];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (!phys[c]) out[c] = 0;                                           // un-physical samples are thrown away, :695
             b.child_cnt[u * 4 + c] = out[c];
             b.child_prob[u * 4 + c] = pr * p[c];
             survivors += out[c] > 0 ? 1u : 0u;
@@ -158,6 +173,71 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
         uint32_t tot_s = 0;
         for (int i = 0; i < SB / WAVE; ++i) tot_s += s_red[i];
         b.wg_total[blockIdx.x] = tot_s;
+    }
+}
+
+// The first HEAD_LEVELS levels of the tree in ONE launch: level n has at most 4^n <= 64 prefixes there, so a single
+// workgroup (a quad of lanes per prefix) expands, compacts in LDS and moves on — these levels are pure latency
+// (~30 us each as separate expand + scatter launches whatever their size).  Leaves the level-HEAD_LEVELS prefixes
+// (<= 256) in the global ping-pong arrays where the per-level kernels continue.
+constexpr int HEAD_LEVELS = 4;
+__global__ __launch_bounds__(SB) void sample_head_kernel(const NetDims d, const float *__restrict__ w, const SampleBufs b,
+                                                         const int64_t n_samples, const uint32_t k0, const uint32_t k1) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    __shared__ uint32_t s_ab[2][EXP_PARENTS];
+    __shared__ int64_t s_cnt[2][EXP_PARENTS];
+    __shared__ float s_prob[2][EXP_PARENTS];
+    __shared__ int s_surv[EXP_PARENTS], s_pos[EXP_PARENTS + 1];
+    const int tid = threadIdx.x, u = tid >> 2, q = tid & 3;
+    if (tid == 0) {
+        for (int i = 0; i < MAXP + 2; ++i) b.U[i] = 0;
+        b.U[0] = 1;
+        s_ab[0][0] = 0u; s_cnt[0][0] = n_samples; s_prob[0][0] = 1.0f;
+    }
+    int U = 1;
+    for (int n = 0; n < HEAD_LEVELS; ++n) {
+        const int cur = n & 1, nxt = cur ^ 1;
+        __syncthreads();                                   // previous level's LDS writes / everyone done with s_w
+        stage_pair_weights(d, w, n, s_w, SB);
+        const bool active = u < U;
+        const uint32_t ab = active ? s_ab[cur][u] : 0u;
+        const int64_t cnt = active ? s_cnt[cur][u] : 0;
+        __syncthreads();
+        int64_t out[4];
+        float p[4];
+        expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
+        if (q == 0) {
+            int sv = 0;
+            if (active)
+                for (int c = 0; c < 4; ++c) sv += out[c] > 0 ? 1 : 0;
+            s_surv[u] = sv;
+        }
+        __syncthreads();
+        if (tid == 0) {                                    // <= 64 entries: a serial scan is a few hundred cycles
+            int run = 0;
+            for (int i = 0; i < EXP_PARENTS; ++i) { s_pos[i] = run; run += s_surv[i]; }
+            s_pos[EXP_PARENTS] = run;
+        }
+        __syncthreads();
+        const int total = s_pos[EXP_PARENTS];
+        const bool to_global = n + 1 == HEAD_LEVELS;       // the last head level feeds the per-level kernels
+        if (active && q == 0) {
+            int pos = s_pos[u];
+            const float pr = s_prob[cur][u];
+            for (int c = 0; c < 4; ++c) {
+                if (out[c] > 0) {
+                    const uint32_t child = ab | ((uint32_t)(c & 1) << n) | ((uint32_t)(c >> 1) << (16 + n));
+                    if (to_global) {
+                        b.ab[(n + 1) & 1][pos] = child; b.cnt[(n + 1) & 1][pos] = out[c]; b.prob[(n + 1) & 1][pos] = pr * p[c];
+                    } else {
+                        s_ab[nxt][pos] = child; s_cnt[nxt][pos] = out[c]; s_prob[nxt][pos] = pr * p[c];
+                    }
+                    ++pos;
+                }
+            }
+        }
+        U = total;
+        if (tid == 0) b.U[n + 1] = total;
     }
 }
 
@@ -290,11 +370,21 @@ NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, 
     b.U = reinterpret_cast<int64_t *>(base + o_U);
 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sample_init_kernel, dim3(1), dim3(64), 0, s, b, n_samples);
-    HIP_TRY(hipGetLastError());
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     int64_t bound = 1;                                     // worst-case prefixes entering level n: min(4^n, cap)
-    for (int n = 0; n < d.P; ++n) {
+    int n_first = 0;
+    if (d.P > HEAD_LEVELS && cap >= 4 * EXP_PARENTS && naqs::env_int("NAQS_SAMPLE_HEAD", 1) == 1) {
+        const int nin = 2 * (HEAD_LEVELS - 1);
+        const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+        hipLaunchKernelGGL(sample_head_kernel, dim3(1), dim3(SB), lds, s, d, net->d_w, b, n_samples, k0, k1);
+        HIP_TRY(hipGetLastError());
+        n_first = HEAD_LEVELS;
+        for (int n = 0; n < HEAD_LEVELS; ++n) bound *= 4;
+    } else {
+        hipLaunchKernelGGL(sample_init_kernel, dim3(1), dim3(64), 0, s, b, n_samples);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int n = n_first; n < d.P; ++n) {
         const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const int nin = n == 0 ? 1 : 2 * n;
         const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);

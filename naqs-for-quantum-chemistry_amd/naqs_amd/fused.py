@@ -89,6 +89,7 @@ class FusedLogPsi:
         _lib.check(self._lib.naqs_net_param_count(self._h, ctypes.byref(n)), "naqs_net_param_count")
         self.n_params = n.value
         self._samp = None
+        self._grad_flat, self._grad_views = None, None
         self.train_mode = os.environ.get("NAQS_TRAIN_MODE", "hip")     # "hip" | "blas" (phase MLP through torch/rocBLAS)
         assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
         _lib.check(self._lib.naqs_net_amp_param_count(self._h, ctypes.byref(n)), "naqs_net_amp_param_count")
@@ -107,7 +108,7 @@ class FusedLogPsi:
         """Re-pack the current network parameters (after every optimiser step).  ``amp_only`` packs just the
         amplitude blocks — all that sampling and the training forward/backward need; the phase layers are then
         stale for ``log_psi`` / ``log_psi_and_local_energy`` until a full refresh."""
-        all_params = list(self.wf.model.parameters())
+        all_params = self.wf.param_list()
         flat = getattr(self.wf, "_flat_params", None)
         if flat is None or not self.wf._views_of(flat, all_params):       # parameters not (or no longer) flattened: gather
             params = self._amp_params if amp_only else all_params
@@ -178,15 +179,33 @@ class FusedLogPsi:
         g = g.to(torch.float32)
         if acts is None:                     # naqs_net_train_backward: every gradient in one flat buffer
             g = g.contiguous()
-            flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            params = self.wf.param_list()
+            fresh = all(p.grad is None for p in params)
+            if fresh:
+                # the usual case (zero_grad before every step): the kernels write straight into a persistent flat
+                # buffer whose per-parameter views were made once
+                if self._grad_flat is None:
+                    self._grad_flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+                    self._grad_views, off = [], 0
+                    for p in params:
+                        n = p.numel()
+                        self._grad_views.append(self._grad_flat[off:off + n].view(p.shape))
+                        off += n
+                flat = self._grad_flat
+            else:
+                flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
             st = self._lib.naqs_net_train_backward(self._h, keys.shape[0], keys.data_ptr(), g.data_ptr(), flat.data_ptr(),
                                                    _stream_ptr(self.device))
             _lib.check(st, "naqs_net_train_backward")
-            off = 0
-            for p in m.parameters():
-                n = p.numel()
-                _accumulate(p, flat[off:off + n].view(p.shape))
-                off += n
+            if fresh:
+                for p, gv in zip(params, self._grad_views):
+                    p.grad = gv
+            else:
+                off = 0
+                for p in params:
+                    n = p.numel()
+                    _accumulate(p, flat[off:off + n].view(p.shape))
+                    off += n
             return
         flat = torch.empty(self.n_amp_params, dtype=torch.float32, device=self.device)
         ga = g[:, 0].contiguous()

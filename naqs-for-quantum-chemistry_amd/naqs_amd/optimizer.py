@@ -200,7 +200,7 @@ class OptimizerBase:
         M = keys.shape[0]
         if self.track_sampled_idxs:          # energy.py:300; folded into the Counter in batches (no per-step sync)
             self._sampled_pending.append(keys)
-            if len(self._sampled_pending) >= 64:
+            if len(self._sampled_pending) >= 256:
                 self._flush_sampled_idxs()
         # shard of rows this rank owns (the whole table when single-process)
         b, e_ = shard_bounds(M, rank, world)

@@ -78,6 +78,7 @@ class NAQSComplex_NADE_orbitals:
         self.model.predict()
         self._fused, self._fused_version, self._fused_amp_version = None, None, None
         self._param_epoch = 0
+        self._param_list = None
         self._flat_params = None
 
     # ---- mode helpers (wavefunction.py:90-100)
@@ -174,11 +175,18 @@ class NAQSComplex_NADE_orbitals:
             self._fused_version = None
         return self._fused
 
+    def param_list(self):
+        """The network's parameters in state_dict order, cached: ``nn.Module.parameters()`` walks the module tree on
+        every call (~0.4 ms for this network), which the per-step bookkeeping below would pay several times."""
+        if self._param_list is None:
+            self._param_list = list(self.model.parameters())
+        return self._param_list
+
     def flatten_parameters(self):
         """Make every network parameter a view into one flat float32 buffer (state_dict order) and return it.  The
         fused kernels then read the parameters without gathering them, and ``FlatAdam`` updates them in one launch.
         ``load_state_dict`` / optimiser steps write through the views, so the buffer is always current."""
-        params = list(self.model.parameters())
+        params = self.param_list()
         flat = getattr(self, "_flat_params", None)
         if flat is not None and self._views_of(flat, params):
             return flat
@@ -201,7 +209,12 @@ class NAQSComplex_NADE_orbitals:
         return off == flat.numel()
 
     def _param_version(self):
-        return (self._param_epoch,) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        flat = self._flat_params
+        if flat is not None:
+            # flattened: every parameter is a view of `flat` and views share their base's version counter, so one
+            # counter covers in-place updates of any of them (the views themselves are re-checked when re-packing)
+            return (self._param_epoch, flat.data_ptr(), flat._version)
+        return (self._param_epoch,) + tuple((p.data_ptr(), p._version) for p in self.param_list())
 
     def parameters_changed(self):
         """Tell the fused kernels that the parameters were modified by something that does not bump the tensors'

@@ -144,3 +144,14 @@ def test_thirty_qubit_network_sample_logpsi_and_gradients():
         ref = torch.zeros_like(p) if b is None else b
         scale = float(ref.abs().max()) + 1e-12
         assert float((p.grad - ref).abs().max()) < 2e-4 * scale + 1e-9, (name, float((p.grad - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("mol", ["H2O", "N2"])
+def test_fused_head_levels_change_nothing(mol, monkeypatch):
+    """The first four levels in one launch (sample_head_kernel) vs one expand + scatter launch per level: identical output."""
+    hil, wf, fused = _setup(mol)
+    monkeypatch.setenv("NAQS_SAMPLE_HEAD", "1")
+    a = fused.sample(10 ** 8, seed=77, max_unique=100000)
+    monkeypatch.setenv("NAQS_SAMPLE_HEAD", "0")
+    b = fused.sample(10 ** 8, seed=77, max_unique=100000)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and len(a[0]) > 100
