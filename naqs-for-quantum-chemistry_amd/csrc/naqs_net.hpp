@@ -36,6 +36,18 @@ struct NetDims {
     int32_t ldh;                       // LDS row stride of one activation plane (bf16 units)
 };
 
+// one packed row [W1[j][0..NIN) | b1[j] | W2[0..5)[j] | pad] from LDS as 16-byte reads (rows are 16-byte multiples);
+// element-wise `row[k]` reads compile to one ds_read_b32 each and those, not the FMAs, were the time of this loop
+template <int S>
+__device__ __forceinline__ void load_row(const float *__restrict__ row, float (&v)[S]) {
+    const f32x4 *r4 = reinterpret_cast<const f32x4 *>(row);
+#pragma unroll
+    for (int q = 0; q < S / 4; ++q) {
+        const f32x4 t = r4[q];
+        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+}
+
 // partial output sums of pair NB over hidden units [j0, j1): o[c] += W2[c][j] * relu(W1[j].x + b1[j])
 template <int NB>
 __device__ __forceinline__ void amp_partial(const NetDims &d, const float *__restrict__ w, uint32_t first,
@@ -56,7 +68,8 @@ __device__ __forceinline__ void amp_partial(const NetDims &d, const float *__res
     const float *rows = w;                             // this pair's rows, staged in LDS by the workgroup
 #pragma unroll 4
     for (int j = j0; j < j1; ++j) {
-        const float *row = rows + j * S;               // same address in every lane -> LDS broadcast reads
+        float row[S];                                  // same address in every lane -> LDS broadcast reads, 16 bytes each
+        load_row<S>(rows + j * S, row);
         // two interleaved accumulation chains keep the FMA pipe busier than one 2n-long dependent chain
         float h0 = row[NIN], h1 = 0.0f;
 #pragma unroll
