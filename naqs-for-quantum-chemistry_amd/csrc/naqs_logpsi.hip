@@ -816,8 +816,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
 }
 
 // f32 [N][K] -> three bf16 planes, zero-padded and tiled [plane][N_pad/16][Kh_pad/32][64 lanes][8]
-__global__ __launch_bounds__(256) void pack_phase_bf16_kernel(const float *__restrict__ src, int K, int N, int Kh_pad,
-                                                              int N_pad, ushort_t *__restrict__ Wd) {
+__device__ __forceinline__ void pack_phase_bf16(const float *__restrict__ src, int K, int N, int Kh_pad,
+                                                int N_pad, ushort_t *__restrict__ Wd) {
     const int total = N_pad * Kh_pad;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         // e = ((cb * KC + kc) * 64 + kg * 16 + nn) * 8 + j   <-   W[cb*16 + nn][kc*32 + kg*8 + j]
@@ -893,8 +893,8 @@ __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void pack_phase_kernel(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
-                                                         float *__restrict__ Wd, float *__restrict__ bd) {
+__device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
+                                               float *__restrict__ Wd, float *__restrict__ bd) {
     const int total = N_pad * K_pad;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total + N_pad; e += gridDim.x * 256) {
         if (e < total) {
@@ -908,6 +908,20 @@ __global__ __launch_bounds__(256) void pack_phase_kernel(const float *__restrict
             bd[n] = n < N ? src[N * K + n] : 0.0f;
         }
     }
+}
+
+// every phase layer in one launch (blockIdx.y = layer): f32 MFMA tiles + bias, and the three bf16 planes
+struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
+__global__ __launch_bounds__(256) void pack_phase_all_kernel(const float *__restrict__ flat, const NetDims d, const PhasePackJobs jobs,
+                                                             float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32) {
+    const int l = blockIdx.y;
+    const float *src = flat + jobs.src_off[l];
+    if (with_f32) pack_phase_f32(src, jobs.K[l], jobs.N[l], d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l]);
+    else {                                              // the bf16x3 kernel only needs the (padded) bias from this buffer
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < d.N_pad[l]; n += gridDim.x * 256)
+            w[d.b_off[l] + n] = n < jobs.N[l] ? src[jobs.N[l] * jobs.K[l] + n] : 0.0f;
+    }
+    pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
 }
 
 }  // namespace
@@ -1085,16 +1099,22 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     net->have_weights = net->have_amp_weights = net->have_wb = false;
     st = pack_amp_blocks(net, flat_dev, s);
     if (st != NAQS_OK) return st;
-    for (int l = 0; l < d.n_lin; ++l) {
-        const int total = d.N_pad[l] * d.K_pad[l] + d.N_pad[l];
-        hipLaunchKernelGGL(pack_phase_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
-                           flat_dev + net->phase_src_off[(size_t)l], net->phase_K[(size_t)l], net->phase_N[(size_t)l],
-                           d.K_pad[l], d.N_pad[l], net->d_w + d.w_off[l], net->d_w + d.b_off[l]);
-        HIP_TRY(hipGetLastError());
-        const int total_h = d.N_pad[l] * d.Kh_pad[l];
-        hipLaunchKernelGGL(pack_phase_bf16_kernel, dim3((total_h + 255) / 256), dim3(256), 0, s,
-                           flat_dev + net->phase_src_off[(size_t)l], net->phase_K[(size_t)l], net->phase_N[(size_t)l],
-                           d.Kh_pad[l], d.N_pad[l], net->d_wh + d.wh_off[l]);
+    {
+        PhasePackJobs jobs{};
+        int biggest = 0;
+        for (int l = 0; l < d.n_lin; ++l) {
+            jobs.src_off[l] = net->phase_src_off[(size_t)l];
+            jobs.K[l] = net->phase_K[(size_t)l];
+            jobs.N[l] = net->phase_N[(size_t)l];
+            biggest = std::max(biggest, d.N_pad[l] * std::max(d.K_pad[l], d.Kh_pad[l]));
+        }
+        // the f32-MFMA weight tiles are only read by phase_kernel (NAQS_PHASE_MODE=0)
+        const bool use_h = naqs::env_int("NAQS_PHASE_MODE", 1) == 1 &&
+                           3 * (3 * 16 * (size_t)d.ldh * sizeof(unsigned short)) <= 160 * 1024;      // as in net_logpsi_impl
+        const int with_f32 = use_h ? 0 : 1;
+        net->packed_f32 = with_f32 != 0;
+        const int gx = std::min(256, (biggest + 255) / 256);
+        hipLaunchKernelGGL(pack_phase_all_kernel, dim3(gx, d.n_lin), dim3(256), 0, s, flat_dev, d, jobs, net->d_w, net->d_wh, with_f32);
         HIP_TRY(hipGetLastError());
     }
     if (net->d_wamp) {
@@ -1162,6 +1182,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
 
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the bf16x3 kernel only
+    if (!use_h && !net->packed_f32) return NAQS_ERR_INVALID;                  // NAQS_PHASE_MODE changed since naqs_net_set_weights
     const int rb_max = use_h ? 3 : 4;
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
     if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));

@@ -161,6 +161,7 @@ struct naqs_net {
     int64_t samp_cap = 0;
     int cu_count = 256;
     bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
+    bool packed_f32 = false;                // the f32-MFMA weight tiles are current (only packed when phase_kernel will run)
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)

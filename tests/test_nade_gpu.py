@@ -147,6 +147,7 @@ def test_bf16x3_phase_kernel_is_f32_equivalent():
     for mode in ("0", "1"):
         os.environ["NAQS_PHASE_MODE"] = mode
         try:
+            fused.refresh()                       # the f32-MFMA weight tiles are only packed when that kernel is selected
             lp = fused.log_psi(keys)
             torch.cuda.synchronize()
         finally:
