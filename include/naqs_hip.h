@@ -258,6 +258,10 @@ int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, 
 int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream);
 int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev,
                             void *stream);
+/* naqs_net_train_forward and the local energies of the same table in one call (= naqs_logpsi_eloc that also keeps the
+ * activations for naqs_net_train_backward): the single-GPU training step's forward half, three launches. */
+int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev, const double *w_dev,
+                                float *logpsi_dev, double *eloc_dev, double *out4_dev, void *stream);
 /* One Adam step on a flat float32 parameter vector (device pointers): torch.optim.Adam's rule without amsgrad —
  * the reference's optimiser, experiments/_base.py:228 (betas (0.9, 0.99), eps 1e-15).  `step` is the 1-based count
  * after this update (bias corrections 1 - beta^step are formed on the host in float64). */

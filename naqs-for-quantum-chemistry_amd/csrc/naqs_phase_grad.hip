@@ -309,6 +309,40 @@ NAQS_API int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *
     return naqs::net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, none, save);
 }
 
+NAQS_API int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev,
+                                         const double *w_dev, float *logpsi_dev, double *eloc_dev, double *out4_dev,
+                                         void *stream) {
+    if (!net || !ham || M < 0 || (w_dev == nullptr) != (out4_dev == nullptr)) return NAQS_ERR_INVALID;
+    if (M > 0 && (!keys_dev || !logpsi_dev || !eloc_dev)) return NAQS_ERR_INVALID;
+    if (!net->have_weights) return NAQS_ERR_INVALID;
+    if (naqs::ham_device(ham) != net->device) return NAQS_ERR_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    if (M == 0) {
+        if (out4_dev) HIP_TRY(hipMemsetAsync(out4_dev, 0, 4 * sizeof(double), s));
+        return NAQS_OK;
+    }
+    st = ensure_train_scratch(net, M);
+    if (st != NAQS_OK) return st;
+    const TrainLayout L = train_layout(net, net->train_cap);
+    char *base = static_cast<char *>(net->d_train);
+    naqs::PhaseSave save;
+    save.x = reinterpret_cast<float *>(base + L.x);
+    save.x_ld = L.x_ld;
+    for (int l = 0; l + 1 < net->dims.n_lin; ++l) {
+        save.act[l] = reinterpret_cast<float *>(base + L.act[l]);
+        save.act_ld[l] = L.act_ld[l];
+    }
+    naqs::ElocFeed feed{};
+    st = naqs::eloc_begin(ham, M, s, &feed);
+    if (st != NAQS_OK) return st;
+    st = naqs::net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, feed, save);     // also fills the E_loc tables
+    if (st != NAQS_OK) return st;
+    return naqs::eloc_main(ham, M, feed, eloc_dev, w_dev, out4_dev, s);
+}
+
 NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
                                      float *grad_dev, void *stream) {
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;

@@ -52,6 +52,7 @@ SIGNATURES = {
     "naqs_net_logamp": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "naqs_net_amp_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_train_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "naqs_net_train_forward_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_train_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_adam_step": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, c_i64, c_vp]),

@@ -160,6 +160,21 @@ class FusedLogPsi:
         log_psi = torch.stack([log_amp, out.gather(1, occ).squeeze(1)], -1)
         return log_psi, (keys, acts, occ)
 
+    @torch.no_grad()
+    def forward_saved_with_local_energy(self, ham, keys, weights):
+        """``forward_saved`` (HIP mode) and the local energies of the same table in one library call
+        (``naqs_net_train_forward_eloc``): -> (log psi [M, 2] f32, saved token, E_loc [M, 2] f64, sums [4] f64)."""
+        keys = keys.contiguous()
+        M = keys.shape[0]
+        log_psi = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+        eloc = torch.empty((M, 2), dtype=torch.float64, device=self.device)
+        sums = torch.empty(4, dtype=torch.float64, device=self.device)
+        w = weights.to(device=self.device, dtype=torch.float64).contiguous()
+        st = self._lib.naqs_net_train_forward_eloc(self._h, ham._h, M, keys.data_ptr(), w.data_ptr(), log_psi.data_ptr(),
+                                                   eloc.data_ptr(), sums.data_ptr(), _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_train_forward_eloc")
+        return log_psi, (keys, None, None), eloc, sums
+
     def vmc_loss_grad(self, e_loc, weights, sums):
         """g [M, 2] float32 = d loss / d (log|psi|, phase) of the VMC loss (``naqs_vmc_loss_grad``)."""
         M = e_loc.shape[0]

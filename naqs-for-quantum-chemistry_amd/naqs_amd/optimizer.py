@@ -212,7 +212,14 @@ class OptimizerBase:
             # gradients only for the owned rows; the table needed for the psi look-ups is evaluated
             # without autograd (the rows of other ranks are theirs to differentiate)
             fused = self.wavefunction.fused(need_phase=True) if self.use_fused else None
-            if fused is not None and regularisation_loss is None and not self.normalize_grads:
+            pre = None
+            if (fused is not None and regularisation_loss is None and not self.normalize_grads and world == 1
+                    and fused.train_mode == "hip" and sample_weights is not None
+                    and os.environ.get("NAQS_TRAIN_FUSED_ELOC", "1") == "1"):
+                # single GPU: forward (activations kept) + E_loc + weighted sums in one library call
+                pre = fused.forward_saved_with_local_energy(self.pauli_hamiltonian, keys, sample_weights.reshape(-1))
+                lp_mine, saved = pre[0], pre[1]
+            elif fused is not None and regularisation_loss is None and not self.normalize_grads:
                 # HIP amplitude forward/backward + explicit chain rule of the phase MLP: no autograd graph at all
                 lp_mine, saved = fused.forward_saved(keys[b:e_])
             elif fused is not None:         # same kernels behind a torch.autograd.Function
@@ -235,8 +242,11 @@ class OptimizerBase:
         w = sample_weights.reshape(-1).to(self.device, torch.float64)
 
         # E_loc of the owned rows + (sum w Re, sum w Im, sum w Re^2, sum w) in one launch
-        e_loc, sums = self.pauli_hamiltonian.local_energy(keys, lp_all.detach(), kind="log_psi", row_begin=b,
-                                                          n_rows=e_ - b, weights=w[b:e_])
+        if log_psi is None and pre is not None:
+            e_loc, sums = pre[2], pre[3]
+        else:
+            e_loc, sums = self.pauli_hamiltonian.local_energy(keys, lp_all.detach(), kind="log_psi", row_begin=b,
+                                                              n_rows=e_ - b, weights=w[b:e_])
         if dist:
             dist.all_reduce(sums)
         e_mean = torch.stack([sums[0], sums[1]])                        # (sum w E_loc), like energy.py:328 (w not renormalised)
