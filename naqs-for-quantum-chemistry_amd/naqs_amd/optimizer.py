@@ -126,7 +126,20 @@ class OptimizerBase:
         return self._last_loss
 
     # ---- bookkeeping (energy.py:141-187) ----
+    def _flush_log(self):
+        """Move the steps whose <E>, Var are still device scalars into ``self.log`` (one transfer for all of them)."""
+        if not self._pending_log:
+            return
+        vals = torch.stack([p[1] for p in self._pending_log]).cpu().numpy()
+        for (step, _, n_unq, t), (e, var) in zip(self._pending_log, vals):
+            self.log[LogKey.E_LOC].append((step, float(e)))
+            self.log[LogKey.E_LOC_VAR].append((step, float(var)))
+            self.log[LogKey.N_UNIQUE_SAMP].append((step, n_unq))
+            self.log[LogKey.TIME].append((step, t))
+        self._pending_log = []
+
     def reset_log(self):
+        self._pending_log = []
         self.log = {LogKey.E: [], LogKey.E_LOC: [], LogKey.E_LOC_VAR: [], LogKey.N_UNIQUE_SAMP: [], LogKey.TIME: []}
         self.n_steps = self.n_epochs = 0
         self.run_time = 0
@@ -191,7 +204,7 @@ class OptimizerBase:
         return float(energy.item())
 
     def _SGD_step(self, states, states_idx, log_psi=None, sample_weights=None, log_psi_eval=None,
-                  regularisation_loss=None, n_samps=None, e_loc_clip_factor=None):
+                  regularisation_loss=None, n_samps=None, e_loc_clip_factor=None, lazy=False):
         """One VMC step for the sampled states (energy.py:273-377): E_loc (no grad) -> loss
         2 Re sum w log psi (E_loc - <E>) -> backward -> optimiser step -> (<E>, Var)."""
         dist = _dist()
@@ -282,6 +295,8 @@ class OptimizerBase:
         with torch.no_grad():                                           # energy.py:367-377
             energy = sums[0] / sums[3]
             variance = sums[2] / sums[3] - energy * energy
+        if lazy:        # device scalars: the caller reads them later, so the host can queue the next step meanwhile
+            return torch.stack([energy, variance])
         return float(energy.item()), float(variance.item())
 
     # ---- checkpoints / logs: same keys as the reference (energy.py:400-538) ----
@@ -293,6 +308,7 @@ class OptimizerBase:
         return fname
 
     def save(self, fname="energy_optimizer", quiet=False):
+        self._flush_log()
         dist = _dist()
         if dist and dist.get_rank() != 0:
             return
@@ -325,6 +341,7 @@ class OptimizerBase:
             print(f"Loading checkpoint {fname}...done.")
 
     def save_log(self, fname="log", quiet=False):
+        self._flush_log()
         import pandas as pd
         fname = os.path.splitext(os.path.join(self.save_loc, fname))[0] + ".pkl"
         os.makedirs(os.path.dirname(fname) or ".", exist_ok=True)
@@ -430,15 +447,16 @@ class PartialSamplingOptimizer(OptimizerBase):
             states, counts, probs = self.get_samples()
             weights = counts.double() / counts.sum().double()                         # energy.py:993
             keys = self._sample_keys                                                  # = hilbert.state2idx(states)
-            e, var = self._SGD_step(states, keys, None, sample_weights=weights)
+            # <E>, Var stay on the device until they are printed or saved: reading them here would drain the queue
+            # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU
+            ev = self._SGD_step(states, keys, None, sample_weights=weights, lazy=True)
             self.n_steps += 1
             self.run_time += time.time() - t0
-            self.log[LogKey.E_LOC].append((self.n_steps, e))
-            self.log[LogKey.E_LOC_VAR].append((self.n_steps, var))
-            self.log[LogKey.N_UNIQUE_SAMP].append((self.n_steps, len(weights)))
-            self.log[LogKey.TIME].append((self.n_steps, self.run_time))
+            self._pending_log.append((self.n_steps, ev, len(weights), self.run_time))
             self.n_epochs += 1
             if (self.n_epochs % output_freq == 0) or (self.n_epochs == 1):
+                self._flush_log()
+                var = self.log[LogKey.E_LOC_VAR][-1][1]
                 energy = self.calculate_energy(normalise_psi=True) if self.log_exact_energy else None
                 self.log[LogKey.E].append((self.n_steps, energy))
                 recent = [x[1] for x in self.log[LogKey.E_LOC][-min(output_freq, self.n_epochs):]]
@@ -455,5 +473,6 @@ class PartialSamplingOptimizer(OptimizerBase):
                       f"var(<E_loc>)={var:.5f}, epoch time={tpe:.2f}s, total time={self.run_time:.1f}s")
             if save_freq is not None and self.n_epochs % save_freq == 0:
                 self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=True)
+        self._flush_log()
         if save_final:
             self.save(quiet=False)
