@@ -209,11 +209,8 @@ class NAQSComplex_NADE_orbitals:
         return off == flat.numel()
 
     def _param_version(self):
-        flat = self._flat_params
-        if flat is not None:
-            # flattened: every parameter is a view of `flat` and views share their base's version counter, so one
-            # counter covers in-place updates of any of them (the views themselves are re-checked when re-packing)
-            return (self._param_epoch, flat.data_ptr(), flat._version)
+        # (a Parameter whose .data was pointed into the flat buffer keeps its OWN version counter, so load_state_dict /
+        # in-place edits of a parameter show up here and not on the flat tensor: every parameter is looked at)
         return (self._param_epoch,) + tuple((p.data_ptr(), p._version) for p in self.param_list())
 
     def parameters_changed(self):
@@ -321,6 +318,11 @@ class NAQSComplex_NADE_orbitals:
         self.model2qubit_permutation = np.asarray(ckpt["wavefunction:model2qubit_permutation"])
         self._q2m = torch.as_tensor(self.qubit2model_permutation, device=self.device)
         self._m2q = torch.as_tensor(self.model2qubit_permutation, device=self.device)
+        # the fused kernels hold a packed copy of the weights and the qubit permutation: rebuild on next use
+        if self._fused not in (None, False):
+            self._fused.close()
+        self._fused = None
+        self.parameters_changed()
         print("Loaded NAQSComplex wavefunction from {}.".format(fname))
 
     @torch.no_grad()

@@ -145,3 +145,31 @@ def test_distributed_branches_of_the_step_on_one_gpu():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "distributed branches == single-process path" in r.stdout
+
+
+def test_fused_kernels_follow_parameter_changes(tmp_path):
+    """load_state_dict / in-place edits / checkpoint loads must reach the packed weights of the HIP kernels (their
+    copy is refreshed from the tensors' version counters), also once the parameters are views of the flat buffer."""
+    from test_nade import make_wf
+    z = golden("nade_LiH.npz")
+    hil, wf = make_wf("LiH", z, device="cuda")
+    keys = torch.as_tensor(np.sort(hil._all_keys()), device="cuda")
+    wf.flatten_parameters()
+    a = wf.fused().log_psi(keys).clone()
+    sd = {k: v.clone() for k, v in wf.model.state_dict().items()}
+    with torch.no_grad():
+        for p in wf.model.parameters():
+            p.mul_(1.01)
+    b = wf.fused().log_psi(keys).clone()
+    assert not torch.allclose(a, b)
+    wf.model.load_state_dict(sd)
+    assert torch.equal(wf.fused().log_psi(keys), a)
+    fname = str(tmp_path / "wf.pth")
+    wf.save(fname, quiet=True)
+    with torch.no_grad():
+        for p in wf.model.parameters():
+            p.add_(0.01)
+    wf.load(fname)
+    assert torch.equal(wf.fused().log_psi(keys), a)
+    ref = wf.log_psi(hil.idx2state(keys)).reshape(-1, 2)
+    assert torch.max(torch.abs(ref - a)).item() < 5e-5
