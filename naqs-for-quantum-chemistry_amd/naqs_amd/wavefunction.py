@@ -78,6 +78,7 @@ class NAQSComplex_NADE_orbitals:
         self.model.predict()
         self._fused, self._fused_version, self._fused_amp_version = None, None, None
         self._param_epoch = 0
+        self._sample_calls = 0
         self._param_list = None
         self._flat_params = None
 
@@ -231,10 +232,14 @@ class NAQSComplex_NADE_orbitals:
             raise NotImplementedError("fused sampler: network not on a HIP device or architecture not supported")
         keys = None
         if fused is not None:
-            if generator is not None:
-                seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
-            else:
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # one 64-bit seed per call, derived on the host (splitmix64 of the generator's seed and a call counter):
+            # drawing it from a device generator would cost a queue-draining read-back before the sampler is queued
+            base = int(generator.initial_seed()) if generator is not None else int(torch.initial_seed())
+            self._sample_calls += 1
+            x = (base + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF
+            x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            seed = x ^ (x >> 31)
             if max_batch_size is not None:
                 cap = int(max_batch_size)
             else:       # live prefixes are bounded by the physical space unless no conditional is masked
