@@ -149,14 +149,24 @@ __device__ __forceinline__ double2 cdiv(double2 a, double2 b) {
 
 // sum_{t in [t0,t1)} c_t * (-1)^{popcount(key & yz_t)}, sequential, ascending t: the reference's
 // summation order for one matrix element (hamiltonian_math.pyx:95-98), so H_ij is bit-identical.
+// c * (-1)^parity without a select: flip the sign bit of the high word
+__device__ __forceinline__ double signed_term(double c, int parity) {
+    return __hiloint2double(__double2hiint(c) ^ (int)((uint32_t)(parity & 1) << 31), __double2loint(c));
+}
+
 template <typename KT>
 __device__ __forceinline__ double sign_sum(KT key, const KT *__restrict__ yz, const double *__restrict__ c,
                                            int t0, int t1) {
+    // two terms per trip (loads of both issued together), still added in ascending t
     double h = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const double ct = c[t];
-        h += (popc((KT)(key & yz[t])) & 1) ? -ct : ct;
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {
+        const double c0 = c[t], c1 = c[t + 1];
+        const KT y0 = yz[t], y1 = yz[t + 1];
+        h += signed_term(c0, popc((KT)(key & y0)));
+        h += signed_term(c1, popc((KT)(key & y1)));
     }
+    if (t < t1) h += signed_term(c[t], popc((KT)(key & yz[t])));
     return h;
 }
 
@@ -165,10 +175,7 @@ template <typename KT>
 __device__ __forceinline__ double sign_sum_strided(KT key, const KT *__restrict__ yz, const double *__restrict__ c,
                                                    int t0, int t1, int lane) {
     double h = 0.0;
-    for (int t = t0 + lane; t < t1; t += WAVE) {
-        const double ct = c[t];
-        h += (popc((KT)(key & yz[t])) & 1) ? -ct : ct;
-    }
+    for (int t = t0 + lane; t < t1; t += WAVE) h += signed_term(c[t], popc((KT)(key & yz[t])));
     return h;
 }
 
