@@ -280,12 +280,16 @@ class OptimizerBase:
             self._loss_terms, self._last_loss = None, loss.detach()
         if dist:
             params = [p for g in self.optimizer.param_groups for p in g['params'] if p.grad is not None]
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)                                       # shards SUM to the full-batch gradient
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+            gflat = getattr(fused, "_grad_flat", None) if saved is not None else None
+            if gflat is not None and params and params[0].grad.data_ptr() == gflat.data_ptr():
+                dist.all_reduce(gflat)                                  # the gradients ARE one flat buffer: in place
+            else:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                dist.all_reduce(flat)                                   # shards SUM to the full-batch gradient
+                off = 0
+                for p in params:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
         self.optimizer.step()
         self.wavefunction.parameters_changed()
         self.optimizer.zero_grad()
