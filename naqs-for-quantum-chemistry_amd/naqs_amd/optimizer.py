@@ -194,10 +194,16 @@ class OptimizerBase:
     @torch.no_grad()
     def calculate_energy(self, normalise_psi=None):
         """<psi|H|psi> over the whole restricted space (energy.py:189-217); small spaces only."""
-        states, idx = self.hilbert.get_subspace(ret_states=True, ret_idxs=True)
-        keys = keys_to_device(idx, self.device)
-        lp = self.wavefunction.log_psi(states.to(self.device)).reshape(-1, 2)
-        e = self.pauli_hamiltonian.local_energy(keys, lp, kind="log_psi")
+        fused = self.wavefunction.fused(need_phase=True) if self.use_fused else None
+        if fused is not None:               # keys in, one library call for log psi + E_loc
+            keys = keys_to_device(self.hilbert.get_subspace(ret_states=False, ret_idxs=True), self.device)
+            lp, e = fused.log_psi_and_local_energy(self.pauli_hamiltonian, keys)
+        else:
+            states, idx = self.hilbert.get_subspace(ret_states=True, ret_idxs=True)
+            keys = keys_to_device(idx, self.device)
+            with torch.no_grad():
+                lp = self.wavefunction.log_psi(states.to(self.device)).reshape(-1, 2)
+            e = self.pauli_hamiltonian.local_energy(keys, lp, kind="log_psi")
         p = (2.0 * lp[:, 0].double()).exp()
         sums = self.pauli_hamiltonian.reduce(p, e)
         energy = sums[0] / (sums[3] if normalise_psi else 1.0)
