@@ -120,8 +120,8 @@ def cpu_baseline(ham_p, keys, log_psi, wf_args, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--molecule", default="N2")
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
