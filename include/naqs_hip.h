@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 1
+#define NAQS_ABI_VERSION 2
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -137,13 +137,24 @@ int naqs_hmatvec(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const doubl
 /* ---- inner ring: device versions of the three Cython entry points the reference imports ---- */
 
 /* src.utils.hamiltonian_math.popcount_parity (hamiltonian_math.pyx:455-484):
- * out[i] = 1 - 2*(popcount(arr[i]) & 1), arr of signed ints with elem_bytes in {2,4,8}. */
+ * out[i] = 1 - 2*(popcount(arr[i]) & 1), arr of signed ints with elem_bytes in {1,2,4,8} (the sign extension of a
+ * narrow negative value adds an even number of bits, so unsigned arrays of the same width give the same parities). */
 int naqs_popcount_parity(const void *arr_dev, int elem_bytes, int64_t n, int8_t *out_dev, void *stream);
 
 /* src.utils.hamiltonian_math.get_Hij_cy (hamiltonian_math.pyx:198-288): dense matrix elements
  * hij_dev[i*Kxy + g] = H[i, key_i ^ xy_g] for M states, row-major, bit-identical to the reference
  * (same summation order). */
 int naqs_get_hij(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, double *hij_dev, void *stream);
+
+/* get_Hij_cy with the reference's own argument list (hamiltonian_math.pyx:198-288, body :85-100): the parity table
+ * parity_dev int8 [M][Kyz] (= popcount_parity(key & unique_YZ)), and the K terms GROUPED BY OUTPUT COLUMN
+ * (group_ptr_dev int32 [Kxy+1]; inside a column ascending original term index — a stable sort of unique2all_XY):
+ * term_yz_dev int32 [K] = unique2all_YZ of the term, term_coeff_dev [K] float64 (coeff_bytes 8) or float32 (4).
+ * hij_dev [M*Kxy] of the coupling type, hij[i*Kxy + g] = sum_{k in g} parity[i][yz(k)] * coeff[k], accumulated in
+ * ascending k in the coupling type: bit-identical to the reference's loop.  naqs_amd/compat/hamiltonian_math.py. */
+int naqs_hij_from_parity(int64_t M, int64_t Kxy, int64_t Kyz, int64_t K, const int8_t *parity_dev,
+                         const int32_t *group_ptr_dev, const int32_t *term_yz_dev, const void *term_coeff_dev,
+                         int coeff_bytes, void *hij_dev, void *stream);
 
 /* src.utils.sparse_math.sparse_dense_mv (sparse_math.pyx:47-100): CSR (f64 data, int32 indices)
  * times complex128 vector; v_dev/out_dev are [.][2] = (Re, Im). */

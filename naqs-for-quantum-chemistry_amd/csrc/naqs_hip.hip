@@ -378,6 +378,25 @@ __global__ __launch_bounds__(BLOCK) void parity_kernel(const T *__restrict__ a, 
     }
 }
 
+// get_Hij_cy with the reference's own argument list (hamiltonian_math.pyx:85-100): the caller hands over the parity
+// table P[M][Kyz] and the term -> (column, parity column) maps instead of bit masks.  Terms arrive grouped by output
+// column (stable, i.e. ascending term index inside a column), so the sequential sum of one thread reproduces the
+// reference's `H_ij[i*Kxy + g(k)] += P[i, y(k)] * c[k]` for k = 0..K-1 addend by addend.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void hij_parity_kernel(int64_t M, int32_t Kxy, int64_t Kyz, const int8_t *__restrict__ P,
+                                                           const int32_t *__restrict__ gp, const int32_t *__restrict__ yt,
+                                                           const T *__restrict__ ct, T *__restrict__ out) {
+    const int64_t total = M * (int64_t)Kxy;
+    for (int64_t e = blockIdx.x * (int64_t)BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = e / Kxy;
+        const int g = (int)(e - i * Kxy);
+        const int8_t *row = P + i * Kyz;
+        T acc = (T)0;
+        for (int t = gp[g]; t < gp[g + 1]; ++t) acc += (T)row[yt[t]] * ct[t];
+        out[e] = acc;
+    }
+}
+
 template <typename KT>
 __global__ __launch_bounds__(BLOCK) void hij_kernel(int64_t M, int32_t Kxy, const uint64_t *__restrict__ keys,
                                                     const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
@@ -830,11 +849,13 @@ NAQS_API int naqs_eloc_reduce(naqs_ham_t *h, int64_t n, const double *w_dev, con
 
 NAQS_API int naqs_popcount_parity(const void *arr_dev, int elem_bytes, int64_t n, int8_t *out_dev, void *stream) {
     if (n < 0 || (n > 0 && (!arr_dev || !out_dev))) return NAQS_ERR_INVALID;
-    if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return NAQS_ERR_UNSUPPORTED;
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return NAQS_ERR_UNSUPPORTED;
     if (n == 0) return NAQS_OK;
     const int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, 8192);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (elem_bytes == 2)
+    if (elem_bytes == 1)
+        hipLaunchKernelGGL(parity_kernel<int8_t>, dim3(grid), dim3(BLOCK), 0, s, (const int8_t *)arr_dev, n, out_dev);
+    else if (elem_bytes == 2)
         hipLaunchKernelGGL(parity_kernel<int16_t>, dim3(grid), dim3(BLOCK), 0, s, (const int16_t *)arr_dev, n, out_dev);
     else if (elem_bytes == 4)
         hipLaunchKernelGGL(parity_kernel<int32_t>, dim3(grid), dim3(BLOCK), 0, s, (const int32_t *)arr_dev, n, out_dev);
@@ -859,6 +880,26 @@ NAQS_API int naqs_get_hij(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, do
     else
         hipLaunchKernelGGL(hij_kernel<uint64_t>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)h->Kxy, keys_dev, h->d_rp,
                            h->d_col, (const uint64_t *)h->d_yz, h->d_c, hij_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_hij_from_parity(int64_t M, int64_t Kxy, int64_t Kyz, int64_t K, const int8_t *parity_dev,
+                                  const int32_t *group_ptr_dev, const int32_t *term_yz_dev, const void *term_coeff_dev,
+                                  int coeff_bytes, void *hij_dev, void *stream) {
+    if (M < 0 || Kxy < 0 || Kyz < 0 || K < 0 || Kxy > INT32_MAX || K > INT32_MAX) return NAQS_ERR_INVALID;
+    if (coeff_bytes != 4 && coeff_bytes != 8) return NAQS_ERR_UNSUPPORTED;
+    if (M == 0 || Kxy == 0) return NAQS_OK;
+    if (!group_ptr_dev || !hij_dev || (K > 0 && (!parity_dev || !term_yz_dev || !term_coeff_dev))) return NAQS_ERR_INVALID;
+    const int64_t total = M * Kxy;
+    const int grid = (int)std::min<int64_t>((total + BLOCK - 1) / BLOCK, 16384);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (coeff_bytes == 8)
+        hipLaunchKernelGGL(hij_parity_kernel<double>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)Kxy, Kyz, parity_dev,
+                           group_ptr_dev, term_yz_dev, (const double *)term_coeff_dev, (double *)hij_dev);
+    else
+        hipLaunchKernelGGL(hij_parity_kernel<float>, dim3(grid), dim3(BLOCK), 0, s, M, (int32_t)Kxy, Kyz, parity_dev,
+                           group_ptr_dev, term_yz_dev, (const float *)term_coeff_dev, (float *)hij_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }

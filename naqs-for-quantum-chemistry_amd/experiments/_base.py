@@ -118,6 +118,35 @@ def _setup_distributed(farm):
     return rank, world
 
 
+def _agree_on_seed(seed):
+    """Sharded multi-GPU runs replicate the network and the sampler on every rank, so every rank must seed
+    identically: with ``-s -1`` (draw a seed) rank 0 draws it and broadcasts it; an explicit seed is checked to be
+    the same everywhere.  Farm mode and single-process runs are untouched."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return seed
+    import random
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = int(seed) if seed >= 0 else random.randint(0, 2 ** 32)
+    t = torch.tensor([mine], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0)
+    agreed = int(t.item())
+    if seed >= 0 and agreed != int(seed):
+        raise RuntimeError(f"rank {dist.get_rank()}: seed {seed} differs from rank 0's {agreed}; sharded runs need "
+                           "one seed for all ranks")
+    return agreed
+
+
+def _broadcast_parameters(wavefunction):
+    """Belt and braces after seeding: every rank starts from rank 0's parameters."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        with torch.no_grad():
+            for p in wavefunction.model.parameters():
+                dist.broadcast(p.data, src=0)
+        wavefunction.parameters_changed()
+
+
 def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretrained_model_loc, continue_experiment,
          reset_optimizer, qubit_ordering, masking, lr, lr_lut, n_samps, n_samps_max, n_unq_samps_min, n_unq_samps_max,
          reweight_samples_by_psi, n_train, n_pretrain, output_freq, save_freq, n_lut, n_hid, n_layer, n_hid_phase,
@@ -129,7 +158,7 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
                                       ("-weight_by_psi", reweight_samples_by_psi)) if on]
     if rejected:
         raise NotImplementedError("options outside the MI355X hot path: " + ", ".join(rejected))
-    seed = set_global_seed(seed)
+    seed = set_global_seed(_agree_on_seed(seed))
     molecule, qubit_hamiltonian = load_molecule(molecule_fname, hamiltonian_fname=hamiltonian_fname, verbose=True)
     N = molecule.n_qubits
     results = []
@@ -159,6 +188,7 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
         wavefunction = NAQSComplex_NADE_orbitals(hilbert, **wf_args)
         if pretrained_model_loc is not None:
             wavefunction.load(pretrained_model_loc)
+        _broadcast_parameters(wavefunction)
         print("\n---Preparing Optimizer---\n")
         use_default_lr_schedule = lr < 0
         if use_default_lr_schedule:

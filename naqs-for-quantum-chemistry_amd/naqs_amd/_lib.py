@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(os.path.dirname(_HERE), "lib")
 
 NAQS_OK = 0
+ABI_VERSION = 2          # NAQS_ABI_VERSION of include/naqs_hip.h
 PSI_F32, PSI_F64, LOGPSI_F32, LOGPSI_F64 = 0, 1, 2, 3
 
 c_i64, c_u64p, c_f64p, c_vp = ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
@@ -33,6 +34,7 @@ SIGNATURES = {
     "naqs_hmatvec": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "naqs_popcount_parity": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "naqs_get_hij": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "naqs_hij_from_parity": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp]),
     "naqs_csr_mv": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
@@ -110,8 +112,8 @@ def load_library():
                 continue
             raise NaqsError(f"{path} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.naqs_abi_version() != 1:
-        raise NaqsError(f"{path}: ABI version {lib.naqs_abi_version()} != 1")
+    if lib.naqs_abi_version() != ABI_VERSION:
+        raise NaqsError(f"{path}: ABI version {lib.naqs_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -37,7 +37,6 @@ class FlatAdam(torch.optim.Optimizer):
         live = [g for g in self.param_groups if g['params']]
         if len(live) != 1 or sum(n for _, n in self._span.values()) != flat_param.numel():
             raise ValueError("FlatAdam: one non-empty parameter group covering flat_param exactly")
-        self._group = live[0]
         self._order = sorted(self._span, key=lambda p: self._span[p][0])
 
     def _bind_state(self):
@@ -81,7 +80,9 @@ class FlatAdam(torch.optim.Optimizer):
         if not self.state:
             self._bind_state()
         g = self._flat_grad()
-        grp = self._group
+        # looked up per step: load_state_dict() replaces the param_group dicts, and callers / LR schedulers edit
+        # ``param_groups[i]['lr']`` of whatever dict is current (experiments/_base.py: the 1e-3 -> 5e-4 schedule)
+        grp = next(g_ for g_ in self.param_groups if g_['params'])
         self._t += 1
         st = self._lib.naqs_adam_step(self._flat.numel(), self._flat.data_ptr(), g.data_ptr(), self._m.data_ptr(),
                                       self._v.data_ptr(), float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]),

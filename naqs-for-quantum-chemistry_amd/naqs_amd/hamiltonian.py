@@ -147,6 +147,7 @@ class DevicePauliHamiltonian:
         v /= v.norm()
         m_max = int(min(max_iter, M))
         V = torch.empty((m_max, M), dtype=torch.float64, device=self.device)
+        from scipy.linalg import eigh_tridiagonal
         alpha, beta = [], []
         theta, s_vec, k = None, None, 0
         for k in range(m_max):
@@ -157,17 +158,21 @@ class DevicePauliHamiltonian:
             for _ in range(2):                                   # full re-orthogonalisation, twice is enough
                 w = w - V[:k + 1].t() @ (V[:k + 1] @ w)
             b = w.norm()
-            alpha.append(float(a))
-            T = np.diag(alpha)
-            if k > 0:
-                off = np.array(beta)
-                T = T + np.diag(off, 1) + np.diag(off, -1)
-            evals, evecs = np.linalg.eigh(T)
-            theta, s_vec = evals[0], evecs[:, 0]
-            resid = abs(float(b) * s_vec[-1])
-            if resid < tol * max(1.0, abs(theta)) or float(b) < 1e-14:
-                break
-            beta.append(float(b))
+            a_h, b_h = torch.stack([a, b]).tolist()              # the iteration's one host synchronisation
+            alpha.append(a_h)
+            # lowest Ritz pair of the tridiagonal matrix only (O(k) bisection + inverse iteration, not a full eigh),
+            # and not on every iteration once the basis is large: the test costs more than the product it saves
+            last = k == m_max - 1 or b_h < 1e-14
+            if k < 32 or k % 8 == 0 or last:
+                if k == 0:
+                    theta, s_vec = alpha[0], np.ones(1)
+                else:
+                    ev, evec = eigh_tridiagonal(np.array(alpha), np.array(beta), select="i", select_range=(0, 0))
+                    theta, s_vec = float(ev[0]), evec[:, 0]
+                resid = abs(b_h * s_vec[-1])
+                if resid < tol * max(1.0, abs(theta)) or last:
+                    break
+            beta.append(b_h)
             v = w / b
         vec = torch.as_tensor(s_vec, dtype=torch.float64, device=self.device) @ V[:k + 1]
         vec = vec / vec.norm()

@@ -42,6 +42,23 @@ class LogKey(Enum):                       # src/optimizer/utils.py:9-17
         return self.value
 
 
+class _CheckpointPickle:
+    """``pickle_module`` for ``torch.load``: a checkpoint written by the reference pickles its log keys as
+    ``src.optimizer.utils.LogKey`` (energy.py:431, utils.py:9-17); they are mapped to the ``LogKey`` of this
+    module so that such files load without the reference on the import path."""
+    import pickle as _p
+    __name__ = "pickle"
+    load, loads, dump, dumps = _p.load, _p.loads, _p.dump, _p.dumps
+    Pickler, PickleError, UnpicklingError = _p.Pickler, _p.PickleError, _p.UnpicklingError
+    HIGHEST_PROTOCOL, DEFAULT_PROTOCOL = _p.HIGHEST_PROTOCOL, _p.DEFAULT_PROTOCOL
+
+    class Unpickler(_p.Unpickler):
+        def find_class(self, module, name):
+            if module == "src.optimizer.utils" and name == "LogKey":
+                return LogKey
+            return super().find_class(module, name)
+
+
 def _dist():
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized()) else None
@@ -65,9 +82,14 @@ class OptimizerBase:
                  reweight_samples_by_psi=False, normalise_psi=False, normalize_grads=False, grad_clip_factor=3,
                  grad_clip_memory_length=50, optimizer=torch.optim.Adam, optimizer_args={'lr': 1e-3},
                  scheduler=None, scheduler_args=None, save_loc='./', pauli_hamiltonian_fname=None,
-                 overwrite_pauli_hamiltonian=False, pauli_hamiltonian_dtype=np.float32, verbose=False, seed=None):
-        if grad_clip_factor is not None:
-            raise NotImplementedError("gradient clipping is unused by the reference's run path (_base.py:224)")
+                 overwrite_pauli_hamiltonian=False, pauli_hamiltonian_dtype=np.float32, verbose=False, seed=None,
+                 bug_compat_full_sample_order=False):
+        self.grad_clip_factor, self.grad_clip_memory_length = grad_clip_factor, int(grad_clip_memory_length)
+        # opt-in reproduction of the reference's full-sample quirk (hamiltonian.py:100-105): when a batch
+        # holds EVERY state of the restricted space, get_H returns H in restricted-basis order while psi stays in
+        # sample order.  Off by default (the mathematically correct E_loc); on only to retrace reference runs on
+        # small molecules whose sampler saturates the space (LiH, H2O).
+        self.bug_compat_full_sample_order = bool(bug_compat_full_sample_order)
         if n_fixed_electrons not in (None, 0) or n_excitations_max is not None:
             raise NotImplementedError("frozen-core / excitation-limited runs are out of scope")
         self.wavefunction = wavefunction
@@ -98,6 +120,7 @@ class OptimizerBase:
         self.solve_H_max_states = 10000       # energy.py:773-776
         self.use_fused = True                # HIP sampler / training kernels / FlatAdam when the network supports them
         self._loss_terms = self._last_loss = None
+        self._shard_mismatch = None
         self.reset_log()
         self.reset_optimizer()
 
@@ -128,6 +151,7 @@ class OptimizerBase:
     # ---- bookkeeping (energy.py:141-187) ----
     def _flush_log(self):
         """Move the steps whose <E>, Var are still device scalars into ``self.log`` (one transfer for all of them)."""
+        self._check_shards()
         if not self._pending_log:
             return
         vals = torch.stack([p[1] for p in self._pending_log]).cpu().numpy()
@@ -137,6 +161,13 @@ class OptimizerBase:
             self.log[LogKey.N_UNIQUE_SAMP].append((step, n_unq))
             self.log[LogKey.TIME].append((step, t))
         self._pending_log = []
+
+    def _check_shards(self):
+        """Raise if some step's ranks did not shard one and the same sample table (different seeds / parameters)."""
+        bad = getattr(self, "_shard_mismatch", None)
+        if bad is not None and bool(bad.item()):
+            raise RuntimeError("distributed VMC step: the ranks sampled different tables (sample count or key checksum "
+                               "differs across ranks) — seed every rank identically and broadcast the parameters")
 
     def reset_log(self):
         self._pending_log = []
@@ -166,6 +197,55 @@ class OptimizerBase:
                 self.optimizer = self.optimizer_callable(groups)
         self.scheduler = (self.scheduler_callable(self.optimizer, **self.scheduler_args)
                           if self.scheduler_callable is not None else None)
+        # clipping memory (energy.py:187): the last `grad_clip_memory_length` (clipped) gradient norms per parameter
+        # group, kept on the device so that clipping costs no host synchronisation
+        self._grad_norms = [[torch.zeros(max(1, self.grad_clip_memory_length), dtype=torch.float64, device=self.device), 0]
+                            for _ in self.optimizer.param_groups]
+
+    @torch.no_grad()
+    def _clip_grads(self):
+        """energy.py:383-395 with torch_utils.clip_grad_norm_ (network/torch_utils.py:24-53): per parameter group the
+        2-norm of all gradients is limited to grad_clip_factor x the mean of the remembered norms (1e3 while the
+        memory is empty) and min(limit, norm) is remembered."""
+        if self.grad_clip_factor is None:
+            return
+        for mem, group in zip(self._grad_norms, self.optimizer.param_groups):
+            hist, n = mem
+            L = hist.numel()
+            max_norm = (self.grad_clip_factor * hist[:min(n, L)].mean() if n > 0
+                        else torch.tensor(1e3, dtype=torch.float64, device=self.device))
+            grads = [p.grad for p in group['params'] if p.grad is not None]
+            if grads:
+                first = grads[0]
+                owner = first._base if first._base is not None else first
+                flat = None
+                if owner.dim() == 1 and owner.numel() == sum(g.numel() for g in grads) and all(
+                        g._base is owner or g is owner for g in grads):
+                    flat = owner                                  # the gradients are views of one flat buffer
+                norm = (flat.norm(2) if flat is not None
+                        else torch.norm(torch.stack([torch.norm(g.detach(), 2) for g in grads]), 2)).double()
+                coef = (max_norm / (norm + 1e-6)).clamp(max=1.0).to(first.dtype)
+                if flat is not None:
+                    flat.mul_(coef)
+                else:
+                    for g in grads:
+                        g.mul_(coef)
+            else:
+                norm = torch.zeros((), dtype=torch.float64, device=self.device)
+            hist[n % L] = torch.minimum(max_norm, norm)
+            mem[1] = n + 1
+
+    def _eloc_keys(self, keys):
+        """The key table handed to the E_loc kernel: the sample keys — or, with ``bug_compat_full_sample_order`` and
+        a batch that covers the whole restricted space, the keys in restricted-basis order.  Row i then belongs to
+        state rho_i but is paired with psi of sample i: exactly what the reference computes in that case,
+        conj(sum_j H[rho_i, rho_j] psi(s_j) / psi(s_i))  (hamiltonian.py:100-105 feeding energy.py:248)."""
+        if self.bug_compat_full_sample_order and keys.shape[0] == self.hilbert.size:
+            if getattr(self, "_restricted_order_keys", None) is None:
+                self._restricted_order_keys = keys_to_device(
+                    self.hilbert.get_subspace(ret_states=False, ret_idxs=True), self.device)
+            return self._restricted_order_keys
+        return keys
 
     # ---- the hot path ----
     @torch.no_grad()
@@ -180,6 +260,7 @@ class OptimizerBase:
         keys = keys_to_device(states_idx, self.device)
         if psi is None and log_psi is None:
             log_psi = self.wavefunction.log_psi(self.hilbert.idx2state(keys))
+        keys = self._eloc_keys(keys)
         if log_psi is not None:
             e = self.pauli_hamiltonian.local_energy(keys, log_psi.detach().to(self.device), kind="log_psi",
                                                     row_begin=row_begin, n_rows=n_rows)
@@ -232,8 +313,9 @@ class OptimizerBase:
             # without autograd (the rows of other ranks are theirs to differentiate)
             fused = self.wavefunction.fused(need_phase=True) if self.use_fused else None
             pre = None
+            quirk = self._eloc_keys(keys) is not keys
             if (fused is not None and regularisation_loss is None and not self.normalize_grads and world == 1
-                    and fused.train_mode == "hip" and sample_weights is not None
+                    and fused.train_mode == "hip" and sample_weights is not None and not quirk
                     and os.environ.get("NAQS_TRAIN_FUSED_ELOC", "1") == "1"):
                 # single GPU: forward (activations kept) + E_loc + weighted sums in one library call
                 pre = fused.forward_saved_with_local_energy(self.pauli_hamiltonian, keys, sample_weights.reshape(-1))
@@ -264,10 +346,20 @@ class OptimizerBase:
         if log_psi is None and pre is not None:
             e_loc, sums = pre[2], pre[3]
         else:
-            e_loc, sums = self.pauli_hamiltonian.local_energy(keys, lp_all.detach(), kind="log_psi", row_begin=b,
+            e_loc, sums = self.pauli_hamiltonian.local_energy(self._eloc_keys(keys), lp_all.detach(), kind="log_psi", row_begin=b,
                                                               n_rows=e_ - b, weights=w[b:e_])
+        shard_ok = None
         if dist:
-            dist.all_reduce(sums)
+            # one collective for the accumulators AND a proof that every rank sharded the same table: with
+            # (M, M^2, c, c^2) appended (c = 20 low bits of the key sum), W * sum x^2 == (sum x)^2 holds iff all
+            # ranks contributed the same x (Cauchy-Schwarz; everything is an exact integer in float64)
+            c = (keys.sum() & 0xFFFFF).double()
+            m = torch.tensor(float(M), dtype=torch.float64, device=self.device)
+            ext = torch.cat([sums, torch.stack([m, m * m, c, c * c])])
+            dist.all_reduce(ext)
+            sums = ext[:4]
+            shard_ok = (world * ext[5] == ext[4] * ext[4]) & (world * ext[7] == ext[6] * ext[6])
+            self._shard_mismatch = (~shard_ok if self._shard_mismatch is None else self._shard_mismatch | ~shard_ok)
         e_mean = torch.stack([sums[0], sums[1]])                        # (sum w E_loc), like energy.py:328 (w not renormalised)
 
         self.optimizer.zero_grad()
@@ -296,6 +388,7 @@ class OptimizerBase:
                 for p in params:
                     p.grad.copy_(flat[off:off + p.numel()].view_as(p))
                     off += p.numel()
+        self._clip_grads()
         self.optimizer.step()
         self.wavefunction.parameters_changed()
         self.optimizer.zero_grad()
@@ -305,8 +398,11 @@ class OptimizerBase:
         with torch.no_grad():                                           # energy.py:367-377
             energy = sums[0] / sums[3]
             variance = sums[2] / sums[3] - energy * energy
+            if shard_ok is not None:        # ranks that sampled different tables must not report a plausible energy
+                energy = torch.where(shard_ok, energy, torch.full_like(energy, float("nan")))
         if lazy:        # device scalars: the caller reads them later, so the host can queue the next step meanwhile
             return torch.stack([energy, variance])
+        self._check_shards()
         return float(energy.item()), float(variance.item())
 
     # ---- checkpoints / logs: same keys as the reference (energy.py:400-538) ----
@@ -336,9 +432,16 @@ class OptimizerBase:
 
     def load(self, fname="energy_optimizer", quiet=False):
         fname = self._fmt(fname)
-        ck = torch.load(fname, map_location=self.device, weights_only=False)
+        ck = torch.load(fname, map_location=self.device, weights_only=False, pickle_module=_CheckpointPickle)
+        # the wavefunction file: where the checkpoint says (energy.py:466-469), else next to the checkpoint under
+        # the name save() gives it (a checkpoint directory that was moved or copied)
+        wf_fname = ck['wavefunction:fname']
+        if not os.path.exists(wf_fname):
+            sibling = os.path.splitext(fname)[0] + '_naqs.pth'
+            if os.path.exists(sibling):
+                wf_fname = sibling
         try:
-            self.wavefunction.load(ck['wavefunction:fname'])
+            self.wavefunction.load(wf_fname)
         except Exception:
             print(f"\twavefunction not found (expected at {ck['wavefunction:fname']})")
         try:

@@ -27,6 +27,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_harness as rh  # noqa: E402
 
+OUT = os.environ.get("NAQS_GOLDEN_OUT", HERE)      # (a scratch directory when re-deriving fixtures to compare)
+
 rh.setup()
 
 import torch  # noqa: E402
@@ -114,7 +116,7 @@ def gen_ham_only(mol):
     ph.XY_sites_idx, ph.YZ_sites_idx, ph.couplings = ph._PauliHamiltonianDynamic__calc_coupling_info()
     ph._unique_XY_sites_idx, ph._unique2all_XY_sites_idx = np.unique(ph.XY_sites_idx, return_inverse=True)
     ph._unique_YZ_sites_idx, ph._unique2all_YZ_sites_idx = np.unique(ph.YZ_sites_idx, return_inverse=True)
-    pack_hamiltonian(mol, ph, N, os.path.join(HERE, f"ham_{mol}.npz"))
+    pack_hamiltonian(mol, ph, N, os.path.join(OUT, f"ham_{mol}.npz"))
     print(f"[ham] {mol}: N={N} K={len(ph.couplings)} Kxy={len(ph._unique_XY_sites_idx)} "
           f"Kyz={len(ph._unique_YZ_sites_idx)}")
 
@@ -158,13 +160,17 @@ def gen_li2o_subset():
     log_psi, psi = synthetic_psi(M, 1.5, seed=99)
     v = cplx.torch_to_numpy(psi)
     e = (sparse_dense_mv(H, v) / v).conj()
-    np.savez_compressed(os.path.join(HERE, "eloc_Li2O_subset.npz"), keys=keys.astype(np.uint64),
+    np.savez_compressed(os.path.join(OUT, "eloc_Li2O_subset.npz"), keys=keys.astype(np.uint64),
                         psi_f32=psi.numpy(), log_psi_f32=log_psi.numpy(), eloc_c128=e, nnz=np.int64(H.nnz))
     print(f"[eloc] Li2O subset: M={M} nnz={H.nnz} <E_loc>={e.real.mean():.6f}")
 
 
-def wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking=NadeMasking.PARTIAL):
+def wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking=NadeMasking.PARTIAL, **overrides):
     # experiments/_base.py:150-187 with the published flags (batch_train.sh:14)
+    return dict(_wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking), **overrides)
+
+
+def _wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking):
     return dict(qubit_ordering=-1, masking=masking, num_lut=0, input_encoding=InputEncoding.BINARY,
                 amp_hidden_size=[n_hid], amp_hidden_activation=nn.ReLU, amp_bias=True,
                 phase_hidden_size=[n_hid_phase] * n_layer_phase, phase_hidden_activation=nn.ReLU,
@@ -174,14 +180,14 @@ def wavefunction_args(na, nb, n_hid, n_hid_phase, n_layer_phase, masking=NadeMas
                 phase_activation=None, n_alpha_electrons=na, n_beta_electrons=nb)
 
 
-def make_optimizer(wf, qh, na, nb, n_samples):
+def make_optimizer(wf, qh, na, nb, n_samples, grad_clip_factor=None):
     # experiments/_base.py:209-246
     return PartialSamplingOptimizer(
         n_samples=n_samples, n_samples_max=1e12, n_unq_samples_min=10, n_unq_samples_max=1e5,
         log_exact_energy=False, wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False,
         n_electrons=na + nb, n_alpha_electrons=na, n_beta_electrons=nb, n_fixed_electrons=None,
         n_excitations_max=None, reweight_samples_by_psi=False, normalise_psi=True,
-        normalize_grads=False, grad_clip_factor=None, grad_clip_memory_length=50,
+        normalize_grads=False, grad_clip_factor=grad_clip_factor, grad_clip_memory_length=50,
         optimizer=torch.optim.Adam,
         optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'weight_decay': 0, 'eps': 1e-15,
                          'amsgrad': False}, {'lr': 1e-2}],
@@ -206,6 +212,55 @@ def fresh_pauli(opt):
                                 dtype=np.float64)
 
 
+def nade_vectors(wf, opt, hil, all_keys, n_draw=None):
+    """state_dict, teacher-forced log psi / conditionals on a fixed state set, one sampler draw (statistical use
+    only) and the scalars / gradients / parameters of the reference's own _SGD_step on that draw."""
+    nd = {}
+    for k, v_ in wf.model.state_dict().items():
+        nd["sd:" + k] = v_.detach().numpy().copy()
+    B = min(512, len(all_keys))
+    sel = np.sort(np.random.RandomState(3).choice(len(all_keys), B, replace=False))
+    states_eval = hil.basis_states[sel]
+    with torch.no_grad():
+        lp_eval = wf.log_psi(states_eval).numpy()
+        cond = wf._evaluate_log_psi(states_eval, gather_state=False).numpy()   # [B, N/2, 4, 2]
+    nd.update(eval_states=states_eval.numpy(), eval_keys=all_keys[sel].astype(np.uint64),
+              eval_log_psi=lp_eval, eval_cond=cond)
+
+    opt.pauli_hamiltonian = fresh_pauli(opt)
+    if n_draw is None:
+        n_draw = 2000 if len(all_keys) < 1000 else 200000
+    states, counts, probs, log_psi = wf.sample(n_draw)
+    idx = hil.state2idx(states)
+    nd.update(samp_n=n_draw, samp_states=states.numpy(), samp_counts=counts.numpy(),
+              samp_probs=probs.detach().numpy(), samp_log_psi=log_psi.detach().numpy(),
+              samp_keys=idx.squeeze().numpy().astype(np.uint64))
+    weights = counts.float() / counts.sum().float()
+    e_loc = opt.calculate_local_energy(idx.squeeze(), psi=cplx.exp(log_psi.detach()))
+    e128 = opt.calculate_local_energy(idx.squeeze(), psi=cplx.exp(log_psi.detach()), ret_complex=True)
+    w2 = weights.unsqueeze(-1)
+    e_corr = e_loc - (w2 * e_loc).sum(axis=0)
+    loss = 2 * cplx.real(w2 * cplx.scalar_mult(log_psi, e_corr)).sum(axis=0)
+    grads = {}
+    real_step = opt.optimizer.step
+
+    def capture_step(*a, **k):
+        for name, p in wf.model.named_parameters():
+            grads[name] = p.grad.detach().numpy().copy()
+        return real_step(*a, **k)
+
+    opt.optimizer.step = capture_step
+    E, Var = opt._SGD_step(states, idx, log_psi, sample_weights=weights.clone())
+    opt.optimizer.step = real_step
+    nd.update(sgd_eloc_f32=e_loc.numpy(), sgd_eloc_c128=e128, sgd_loss=np.float32(loss.item()),
+              sgd_E=np.float64(E), sgd_Var=np.float64(Var))
+    for k, g in grads.items():
+        nd["grad:" + k] = g
+    for k, v_ in wf.model.state_dict().items():
+        nd["sd_after:" + k] = v_.detach().numpy().copy()
+    return nd
+
+
 def gen_molecule(mol, M_sets, nade_cfg, seed=111, kat=None, time_it=False):
     set_global_seed(seed)
     qh = rh.load_qubit_hamiltonian(mol)
@@ -215,7 +270,7 @@ def gen_molecule(mol, M_sets, nade_cfg, seed=111, kat=None, time_it=False):
     wf = NAQSComplex_NADE_orbitals(hil, **wavefunction_args(na, nb, *nade_cfg))
     opt = make_optimizer(wf, qh, na, nb, n_samples=1000)
     ph = opt.pauli_hamiltonian
-    pack_hamiltonian(mol, ph, N, os.path.join(HERE, f"ham_{mol}.npz"))
+    pack_hamiltonian(mol, ph, N, os.path.join(OUT, f"ham_{mol}.npz"))
     all_keys = hil.restricted2full_basis_idxs.numpy().astype(np.int64)
 
     # ---------------- E_loc goldens on fixed synthetic sample sets ----------------
@@ -255,53 +310,15 @@ def gen_molecule(mol, M_sets, nade_cfg, seed=111, kat=None, time_it=False):
         arr = rs.randint(0, np.iinfo(dt).max, size=(7, 33), dtype=np.int64).astype(dt)
         out[f"pp_in_{np.dtype(dt).name}"] = arr
         out[f"pp_out_{np.dtype(dt).name}"] = np.asarray(popcount_parity(arr))
-    np.savez_compressed(os.path.join(HERE, f"eloc_{mol}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"eloc_{mol}.npz"), **out)
 
     # ---------------- NADE: log_psi, sampler draw, one SGD step ----------------
     nd = {"cfg_n_hid": nade_cfg[0], "cfg_n_hid_phase": nade_cfg[1], "cfg_n_layer_phase": nade_cfg[2],
           "seed": seed}
-    for k, v_ in wf.model.state_dict().items():
-        nd["sd:" + k] = v_.detach().numpy().copy()
-    B = min(512, len(all_keys))
-    sel = np.sort(np.random.RandomState(3).choice(len(all_keys), B, replace=False))
-    states_eval = hil.basis_states[sel]
-    with torch.no_grad():
-        lp_eval = wf.log_psi(states_eval).numpy()
-        cond = wf._evaluate_log_psi(states_eval, gather_state=False).numpy()   # [B, N/2, 4, 2]
-    nd.update(eval_states=states_eval.numpy(), eval_keys=all_keys[sel].astype(np.uint64),
-              eval_log_psi=lp_eval, eval_cond=cond)
-
-    opt.pauli_hamiltonian = fresh_pauli(opt)
-    n_draw = 2000 if len(all_keys) < 1000 else 200000
-    states, counts, probs, log_psi = wf.sample(n_draw)
-    idx = hil.state2idx(states)
-    nd.update(samp_n=n_draw, samp_states=states.numpy(), samp_counts=counts.numpy(),
-              samp_probs=probs.detach().numpy(), samp_log_psi=log_psi.detach().numpy(),
-              samp_keys=idx.squeeze().numpy().astype(np.uint64))
-    weights = counts.float() / counts.sum().float()
-    e_loc = opt.calculate_local_energy(idx.squeeze(), psi=cplx.exp(log_psi.detach()))
-    e128 = opt.calculate_local_energy(idx.squeeze(), psi=cplx.exp(log_psi.detach()), ret_complex=True)
-    w2 = weights.unsqueeze(-1)
-    e_corr = e_loc - (w2 * e_loc).sum(axis=0)
-    loss = 2 * cplx.real(w2 * cplx.scalar_mult(log_psi, e_corr)).sum(axis=0)
-    grads = {}
-    real_step = opt.optimizer.step
-
-    def capture_step(*a, **k):
-        for name, p in wf.model.named_parameters():
-            grads[name] = p.grad.detach().numpy().copy()
-        return real_step(*a, **k)
-
-    opt.optimizer.step = capture_step
-    E, Var = opt._SGD_step(states, idx, log_psi, sample_weights=weights.clone())
-    nd.update(sgd_eloc_f32=e_loc.numpy(), sgd_eloc_c128=e128, sgd_loss=np.float32(loss.item()),
-              sgd_E=np.float64(E), sgd_Var=np.float64(Var))
-    for k, g in grads.items():
-        nd["grad:" + k] = g
-    for k, v_ in wf.model.state_dict().items():
-        nd["sd_after:" + k] = v_.detach().numpy().copy()
-    np.savez_compressed(os.path.join(HERE, f"nade_{mol}.npz"), **nd)
-    print(f"[nade] {mol}: n_unq={len(states)} E={E:.6f} Var={Var:.6f} loss={loss.item():.6e}")
+    nd.update(nade_vectors(wf, opt, hil, all_keys))
+    np.savez_compressed(os.path.join(OUT, f"nade_{mol}.npz"), **nd)
+    print(f"[nade] {mol}: n_unq={len(nd['samp_keys'])} E={nd['sgd_E']:.6f} Var={nd['sgd_Var']:.6f} "
+          f"loss={nd['sgd_loss']:.6e}")
 
     # ---------------- physics known answer: FCI through the reference path ----------------
     if kat is not None:
@@ -336,6 +353,128 @@ def gen_molecule(mol, M_sets, nade_cfg, seed=111, kat=None, time_it=False):
         print("[time]", kat["timing"][mol])
 
 
+# ------------------------------------------------------------------------------------------------------------
+# round 2: the ansatz variants the reference's scripts run, the sweep geometries, and the small compat fixtures
+# ------------------------------------------------------------------------------------------------------------
+VARIANTS = {
+    # tag: (wavefunction_args overrides, (n_hid, n_hid_phase, n_layer_phase), masking)
+    # experiments/run.py:11-31 defaults: -n_hid 128 -n_layer 1, phase blocks like the amplitude ones, every block
+    # contributes a phase (aggregate_phase=True, nade.py:556-569)
+    "aggphase": (dict(aggregate_phase=True), (128, 128, 1), NadeMasking.PARTIAL),
+    # batch_train_no_amp_sym.sh:14
+    "noampsym": (dict(use_amp_spin_sym=False), "small", NadeMasking.PARTIAL),
+    # batch_train_no_mask.sh:14 / batch_train_full_mask.sh:14 (the N2 sweep, N2_energy_surface.sh:5-8)
+    "nomask": (dict(), "small", NadeMasking.NONE),
+    "fullmask": (dict(), None, NadeMasking.FULL),
+}
+PUBLISHED_CFG = {"LiH": (64, 32, 2), "H2O": (64, 32, 2)}        # small phase nets for the small fixtures; else 64/512x2
+SMALL_CFG = {"N2": (64, 128, 2)}                                 # keeps the fixture small where the 512-wide phase net is not the point
+
+
+def gen_variant(mol, tag, seed=111, with_eloc=None):
+    """nade_<mol>_<tag>.npz (+ eloc_<mol>.npz for molecules that do not have one yet, ``with_eloc`` = {name: (M, sigma)})."""
+    over, cfg, masking = VARIANTS[tag]
+    if cfg == "small":
+        cfg = SMALL_CFG.get(mol)
+    if cfg is None:
+        cfg = PUBLISHED_CFG.get(mol, (64, 512, 2))
+    set_global_seed(seed)
+    qh = rh.load_qubit_hamiltonian(mol)
+    na, nb = electrons(mol)
+    hil = make_hilbert(mol, qh)
+    wf = NAQSComplex_NADE_orbitals(hil, **wavefunction_args(na, nb, *cfg, masking=masking, **over))
+    opt = make_optimizer(wf, qh, na, nb, n_samples=1000)
+    all_keys = hil.restricted2full_basis_idxs.numpy().astype(np.int64)
+    if with_eloc:
+        out = {}
+        for name, (M, sigma) in with_eloc.items():
+            keys = np.sort(np.random.RandomState(1234).choice(all_keys, M, replace=False))
+            log_psi, psi = synthetic_psi(M, sigma)
+            opt.pauli_hamiltonian = fresh_pauli(opt)
+            idx = hil.to_idx_tensor(keys)
+            e128 = opt.calculate_local_energy(idx, psi=psi, ret_complex=True)
+            out.update({f"{name}_keys": keys.astype(np.uint64), f"{name}_log_psi_f32": log_psi.numpy(),
+                        f"{name}_psi_f32": psi.numpy(), f"{name}_eloc_c128": e128})
+            print(f"[eloc] {mol}/{name}: M={M} <E_loc>={e128.real.mean():.6f}")
+        np.savez_compressed(os.path.join(OUT, f"eloc_{mol}.npz"), **out)
+    nd = {"cfg_n_hid": cfg[0], "cfg_n_hid_phase": cfg[1], "cfg_n_layer_phase": cfg[2], "seed": seed,
+          "cfg_masking": masking.value, "cfg_aggregate_phase": bool(over.get("aggregate_phase", False)),
+          "cfg_use_amp_spin_sym": bool(over.get("use_amp_spin_sym", True))}
+    nd.update(nade_vectors(wf, opt, hil, all_keys))
+    np.savez_compressed(os.path.join(OUT, f"nade_{mol}_{tag}.npz"), **nd)
+    print(f"[nade] {mol}/{tag}: n_unq={len(nd['samp_keys'])} E={nd['sgd_E']:.6f} Var={nd['sgd_Var']:.6f} "
+          f"loss={nd['sgd_loss']:.6e}")
+
+
+def gen_compat_lih(seed=111):
+    """compat_LiH.npz + ckpt_LiH/: (a) three _SGD_steps on one fixed sample table with grad_clip_factor = 0.5 (the
+    reference constructor default is 3, energy.py:63; 0.5 makes the clip bite from the second step on, :383-395);
+    (b) E_loc of the reference when the batch holds all 225 states (the full-sample ordering quirk Q1,
+    hamiltonian.py:100-105); (c) a checkpoint written by the reference's own save() (energy.py:409-443,
+    wavefunction.py:240-253) after those steps."""
+    import shutil
+    mol = "LiH"
+    set_global_seed(seed)
+    qh = rh.load_qubit_hamiltonian(mol)
+    na, nb = electrons(mol)
+    hil = make_hilbert(mol, qh)
+    wf = NAQSComplex_NADE_orbitals(hil, **wavefunction_args(na, nb, 64, 32, 2))
+    opt = make_optimizer(wf, qh, na, nb, n_samples=1000, grad_clip_factor=0.5)
+    ck_dir = os.path.join(OUT, "ckpt_LiH")
+    shutil.rmtree(ck_dir, ignore_errors=True)
+    opt.save_loc = ck_dir
+    out = {}
+    for k, v_ in wf.model.state_dict().items():
+        out["sd:" + k] = v_.detach().numpy().copy()
+    states, counts, probs, _ = wf.sample(5000)
+    idx = hil.state2idx(states)
+    out.update(clip_states=states.numpy(), clip_counts=counts.numpy(), clip_factor=np.float64(0.5))
+    norms = []
+    real_clip = opt._clip_grads
+
+    def spy_clip():
+        norms.append(float(torch.norm(torch.stack([p.grad.norm(2) for p in wf.model.parameters()]), 2)))
+        return real_clip()
+
+    opt._clip_grads = spy_clip
+    for step in range(3):
+        log_psi = wf.log_psi(states)
+        w = counts.float() / counts.sum().float()
+        E, Var = opt._SGD_step(states, idx, log_psi, sample_weights=w.clone())
+        out[f"clip_E{step}"] = np.float64(E)
+        for k, v_ in wf.model.state_dict().items():
+            out[f"clip_sd{step}:" + k] = v_.detach().numpy().copy()
+    out["clip_grad_norms"] = np.array(norms)
+    opt.n_steps, opt.n_epochs, opt.run_time = 3, 3, 1.25
+    from src.optimizer.utils import LogKey
+    for step in range(3):
+        opt.log[LogKey.E_LOC].append((step + 1, float(out[f"clip_E{step}"])))
+    opt.overwrite_pauli_hamiltonian = False                         # (no Hamiltonian cache file to write)
+    opt.save(quiet=True)                                            # -> ckpt_LiH/energy_optimizer(.pth, _naqs.pth)
+
+    # Q1: every state of the space in one batch, ascending keys (what the sampler returns with qubit_ordering = -1)
+    all_keys = np.sort(hil.restricted2full_basis_idxs.numpy().astype(np.int64))
+    log_psi, psi = synthetic_psi(len(all_keys), 1.0, seed=77)
+    opt.pauli_hamiltonian = fresh_pauli(opt)
+    e_bug = opt.calculate_local_energy(hil.to_idx_tensor(all_keys), psi=psi, ret_complex=True)
+    out.update(q1_keys=all_keys.astype(np.uint64), q1_log_psi_f32=log_psi.numpy(), q1_psi_f32=psi.numpy(),
+               q1_eloc_c128=e_bug, q1_restricted_order_keys=hil.restricted2full_basis_idxs.numpy().astype(np.uint64))
+    np.savez_compressed(os.path.join(OUT, "compat_LiH.npz"), **out)
+    print(f"[compat] LiH: clip norms {norms}, E {[float(out[f'clip_E{i}']) for i in range(3)]}, "
+          f"Q1 <E_loc>={e_bug.real.mean():.6f}")
+
+
+def variants():
+    for mol in ("LiH", "N2"):
+        for tag in ("aggphase", "noampsym"):
+            gen_variant(mol, tag)
+    gen_variant("N2", "nomask")
+    gen_variant("LiH", "fullmask")
+    for mol in ("N2_0.75", "N2_2.25"):
+        gen_variant(mol, "fullmask", with_eloc={"c2": (10000, 2.0)})
+    gen_compat_lih()
+
+
 def main():
     kat = {}
     gen_molecule("LiH", {"c1": (150, 1.0), "half": (100, 2.0)}, (64, 32, 2), kat=kat)
@@ -345,9 +484,17 @@ def main():
     gen_li2o_subset()
     for mol in N2_SWEEP:
         gen_ham_only(mol)
-    with open(os.path.join(HERE, "kat.json"), "w") as f:
+    with open(os.path.join(OUT, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "base"):
+        main()
+    if which in ("all", "variants"):
+        variants()
+    if which == "compat":
+        gen_compat_lih()
+    if which == "check-LiH":            # re-derive one base fixture into $NAQS_GOLDEN_OUT (refactoring guard)
+        gen_molecule("LiH", {"c1": (150, 1.0), "half": (100, 2.0)}, (64, 32, 2), kat={})

@@ -13,13 +13,19 @@ from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
 ELECTRONS = {"LiH": (12, 2, 2), "H2O": (14, 5, 5), "N2": (20, 7, 7)}
 
 
-def make_wf(mol, z, device="cpu", masking=NadeMasking.PARTIAL):
-    N, na, nb = ELECTRONS[mol]
+def make_wf(mol, z, device="cpu", masking=None):
+    """The ansatz a ``nade_*.npz`` fixture was recorded with (variant fixtures carry masking / aggregate_phase /
+    use_amp_spin_sym; the base ones are the published single-phase, spin-symmetric, PARTIAL-masked network)."""
+    N, na, nb = ELECTRONS["N2" if mol.startswith("N2") else mol]
     hil = Hilbert.get(N, na, nb, encoding=Encoding.SIGNED, make_basis=True)
+    if masking is None:
+        masking = NadeMasking(int(z["cfg_masking"])) if "cfg_masking" in z.files else NadeMasking.PARTIAL
+    agg = bool(z["cfg_aggregate_phase"]) if "cfg_aggregate_phase" in z.files else False
+    sym = bool(z["cfg_use_amp_spin_sym"]) if "cfg_use_amp_spin_sym" in z.files else True
     wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=masking,
                                    amp_hidden_size=[int(z["cfg_n_hid"])],
                                    phase_hidden_size=[int(z["cfg_n_hid_phase"])] * int(z["cfg_n_layer_phase"]),
-                                   use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=False,
+                                   use_amp_spin_sym=sym, use_phase_spin_sym=False, aggregate_phase=agg,
                                    n_alpha_electrons=na, n_beta_electrons=nb, device=device)
     sd = {k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd:")}
     assert set(sd) == set(wf.model.state_dict()), "state_dict keys must match the reference's"

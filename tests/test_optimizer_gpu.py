@@ -134,17 +134,78 @@ def test_optimizer_uses_flat_adam_and_checkpoint_round_trip(tmp_path):
     assert wf2._views_of(wf2._flat_params, list(wf2.model.parameters()))      # still flattened after load_state_dict
 
 
-def test_distributed_branches_of_the_step_on_one_gpu():
-    """nccl group of world size 1: the sharded-rows code of _SGD_step (table log psi through the inference kernel, row
-    shard through the training kernels, accumulator and flat-gradient all-reduces) gives the single-process energies."""
+def test_flat_adam_follows_param_group_edits_after_load_state_dict():
+    """load_state_dict replaces the param_group dicts; the learning rate the step uses must be the one of the CURRENT
+    dict (the -c resume path, then experiments/_base.py's `g['lr'] = 5e-4` schedule and any LR scheduler)."""
+    import copy
+    from naqs_amd.flat_adam import FlatAdam
+    from test_nade import make_wf
+    from test_optimizer import ADAM
+    z = golden("nade_LiH.npz")
+    _, wf = make_wf("LiH", z, device="cuda")
+    flat = wf.flatten_parameters()
+    params = list(wf.model.parameters())
+    opt = FlatAdam([dict(ADAM[0], params=params), {'lr': 1e-2, 'params': []}], flat)
+
+    def step():
+        before = flat.clone()
+        for p in params:
+            p.grad = torch.ones_like(p)
+        opt.step()
+        return (flat - before).abs().max().item()
+
+    d0 = step()                                          # first Adam step with g = 1: |delta| = lr
+    assert abs(d0 - 1e-3) < 1e-6
+    sd = copy.deepcopy(opt.state_dict())
+    sd["param_groups"][0]["lr"] = 4e-3                   # a checkpoint written with another learning rate
+    opt.load_state_dict(sd)
+    assert abs(step() - 4e-3) < 1e-5                     # (constant gradient: m_hat / sqrt(v_hat) stays 1)
+    for g in opt.param_groups:
+        g['lr'] = 5e-4                                   # the default schedule's second half
+    assert abs(step() - 5e-4) < 1e-6
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.1)
+    step()
+    sched.step()
+    assert abs(step() - 5e-5) < 1e-7
+
+
+def _run_workers(tmp_path, backend, world, port):
+    """Start ``world`` fresh child processes of tests/dist_step_worker.py on cuda:0 and collect what they wrote."""
     import subprocess
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_probe.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "distributed branches == single-process path" in r.stdout
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / f"{backend}_{world}_{r}.pt") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_step_worker.py"), backend, str(r), str(world),
+                               str(port), outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            logs.append(pr.communicate(timeout=900)[0])
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            logs.append(pr.communicate()[0] + "\n[timeout]")
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(log[-2000:] for log in logs)
+    return [torch.load(o, weights_only=False) for o in outs]
+
+
+def test_distributed_step_on_one_gpu(tmp_path):
+    """The sharded step on the HIP path against the single-process answer (30 optimiser steps on H2O):
+    * nccl, world 1 — RCCL itself carries the accumulator and flat-gradient all-reduces;
+    * gloo, world 2 — two processes on the one GPU (RCCL refuses two ranks per device): the world > 1 branches of
+      ``_SGD_step`` really execute on the device — table log psi through the inference kernel between the training
+      forward and backward, row shards [0, M/2) and [M/2, M), both all-reduces, the shard-consistency proof."""
+    single = _run_workers(tmp_path, "none", 1, 29576)[0]
+    nccl1 = _run_workers(tmp_path, "nccl", 1, 29577)[0]
+    gloo2 = _run_workers(tmp_path, "gloo", 2, 29578)
+    e0 = np.array(single["energies"])
+    assert len(e0) == 30
+    assert np.allclose(nccl1["energies"], e0, rtol=0, atol=1e-6)
+    assert torch.equal(gloo2[0]["params"], gloo2[1]["params"]), "ranks diverged"
+    # two shards sum their float32 gradients in a different order than one process: same trajectory to ~1e-5 Ha
+    assert np.max(np.abs(np.array(gloo2[0]["energies"]) - e0)) < 5e-5, np.abs(np.array(gloo2[0]["energies"]) - e0).max()
+    assert torch.max(torch.abs(gloo2[0]["params"] - single["params"])).item() < 5e-4
 
 
 def test_fused_kernels_follow_parameter_changes(tmp_path):

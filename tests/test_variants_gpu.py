@@ -1,0 +1,164 @@
+"""The ansatz variants the reference's scripts run, on the MI355X, against the reference's own vectors
+(tests/golden/make_golden.py ``variants``; CPU counterpart: test_variants.py):
+
+* ``-no_amp_sym`` / ``-no_mask_psi`` / ``-full_mask_psi`` stay inside the fused HIP family — the kernels' ``sym = 0``
+  and masking branches run here (sampler, matrix-core log psi, training forward/backward);
+* the run.py default (``aggregate_phase=True``: one phase block per orbital pair) is outside it: the network runs as
+  PyTorch modules on the device — announced on stdout — with E_loc on the HIP kernels;
+* config 5: E_loc at M = 10 000 and the FULL-masked network on the two end geometries of the N2 sweep, and a short
+  training run of one geometry.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+FUSED = ["LiH_noampsym", "LiH_fullmask", "N2_noampsym", "N2_nomask", "N2_0.75_fullmask", "N2_2.25_fullmask"]
+EAGER = ["LiH_aggphase", "N2_aggphase"]
+
+
+def _wf(fix):
+    from test_nade import make_wf
+    mol = fix.rsplit("_", 1)[0]
+    z = golden(f"nade_{fix}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    return mol, z, hil, wf
+
+
+def _opt(mol, wf, tmp, **kw):
+    from naqs_amd import packing
+    from naqs_amd.optimizer import PartialSamplingOptimizer
+    from test_optimizer import ADAM
+    ham = packing.load_packed(os.path.join(GOLDEN, f"ham_{mol}.npz"))
+    na = nb = int(ham.n_alpha)
+    args = dict(n_samples=100000, n_samples_max=1e12, n_unq_samples_min=10, n_unq_samples_max=1e5, log_exact_energy=False,
+                wavefunction=wf, qubit_hamiltonian=ham, pre_compute_H=False, n_electrons=na + nb, n_alpha_electrons=na,
+                n_beta_electrons=nb, normalise_psi=True, grad_clip_factor=None, optimizer=torch.optim.Adam,
+                optimizer_args=[dict(a) for a in ADAM], save_loc=str(tmp), pauli_hamiltonian_dtype=np.float64, seed=5)
+    args.update(kw)
+    return PartialSamplingOptimizer(**args)
+
+
+@pytest.mark.parametrize("fix", FUSED)
+def test_fused_family_log_psi_matches_reference(fix):
+    """keys -> log psi through the HIP kernels (amplitudes + phase MLP on the matrix cores) vs the reference's
+    wavefunction.log_psi; un-physical-prefix handling and the masks are the variant's."""
+    mol, z, hil, wf = _wf(fix)
+    fused = wf.fused()
+    assert fused is not None, "these variants are inside the fused family"
+    for tag in ("eval", "samp"):
+        keys = torch.as_tensor(z[f"{tag}_keys"].astype(np.int64), device="cuda")
+        lp = fused.log_psi(keys).cpu().numpy()
+        assert np.max(np.abs(lp - z[f"{tag}_log_psi"])) < 5e-5, tag
+    # the torch modules on the device agree with the kernels
+    s = torch.tensor(z["eval_states"], device="cuda")
+    with torch.no_grad():
+        ref = wf.log_psi(s).cpu().numpy()
+    assert np.max(np.abs(ref - z["eval_log_psi"])) < 5e-5
+
+
+@pytest.mark.parametrize("fix", FUSED + EAGER)
+def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
+    mol, z, hil, wf = _wf(fix)
+    opt = _opt(mol, wf, tmp_path)
+    out = capsys.readouterr().out
+    if fix in EAGER:
+        assert wf.fused() is None
+        assert "fused HIP network kernels not available" in out and "aggregate_phase" in out      # loud, not silent
+    else:
+        from naqs_amd.flat_adam import FlatAdam
+        assert wf.fused() is not None and isinstance(opt.optimizer, FlatAdam)
+    states = torch.tensor(z["samp_states"], device="cuda")
+    counts = torch.tensor(z["samp_counts"], device="cuda")
+    keys = hil.state2idx(states).squeeze(-1)
+    lp = torch.tensor(z["samp_log_psi"], device="cuda")
+    psi = torch.stack([lp[:, 0].exp() * lp[:, 1].cos(), lp[:, 0].exp() * lp[:, 1].sin()], -1)
+    e = opt.calculate_local_energy(keys, psi=psi, ret_complex=True)            # HIP E_loc either way
+    want = z["sgd_eloc_c128"]
+    assert np.max(np.abs(e - want) / np.maximum(1, np.abs(want))) < 2e-5        # psi recomputed in float32 on device
+    E, var = opt._SGD_step(states, keys, None, sample_weights=counts.double() / counts.sum().double())
+    assert abs(E - float(z["sgd_E"])) < 2e-5 * max(1, abs(E))
+    assert abs(var - float(z["sgd_Var"])) < 1e-3 * max(1, abs(var))
+    for name, p in wf.model.named_parameters():
+        assert np.max(np.abs(p.detach().cpu().numpy() - z["sd_after:" + name])) < 2e-5, name
+
+
+@pytest.mark.parametrize("fix", ["LiH_aggphase", "N2_aggphase"])
+def test_aggregate_phase_log_psi_on_device(fix):
+    mol, z, hil, wf = _wf(fix)
+    s = torch.tensor(z["eval_states"], device="cuda")
+    with torch.no_grad():
+        lp = wf.log_psi(s).cpu().numpy()
+        cond = wf._evaluate_log_psi(s, gather_state=False).cpu().numpy()
+    ref = z["eval_cond"]
+    finite = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(cond), finite)
+    assert np.max(np.abs(cond[finite] - ref[finite])) < 2e-5 and np.max(np.abs(lp - z["eval_log_psi"])) < 5e-5
+    assert np.abs(ref[..., :-1, :, 1]).max() > 0          # every block contributes a phase, not only the last
+
+
+@pytest.mark.parametrize("mol", ["N2_0.75", "N2_2.25"])
+def test_eloc_on_sweep_geometries(mol):
+    """config 5, E_loc at the headline batch size on the two end geometries (K = 2 239 ... 2 951 terms)."""
+    from naqs_amd import hamiltonian, packing
+    z = golden(f"eloc_{mol}.npz")
+    ham = hamiltonian.DevicePauliHamiltonian(packing.load_packed(os.path.join(GOLDEN, f"ham_{mol}.npz")), device="cuda:0")
+    keys = hamiltonian.keys_to_device(z["c2_keys"], ham.device)
+    ref = z["c2_eloc_c128"]
+    for kind, arr in (("psi", z["c2_psi_f32"]), ("log_psi", z["c2_log_psi_f32"])):
+        e = ham.local_energy(keys, torch.as_tensor(arr, device=ham.device), kind=kind).cpu().numpy()
+        e = e[:, 0] + 1j * e[:, 1]
+        tol = 1e-10 if kind == "psi" else 2e-5          # log psi -> psi re-evaluated in f64 on the device vs the reference's f32 exp
+        assert np.max(np.abs(e - ref) / np.maximum(1, np.abs(ref))) < tol, kind
+    w = (z["c2_psi_f32"].astype(np.float64) ** 2).sum(-1)
+    psi = torch.as_tensor(z["c2_psi_f32"], device=ham.device)
+    e, sums = ham.local_energy(keys, psi, kind="psi", weights=torch.as_tensor(w, device=ham.device))
+    energy = (sums[0] / sums[3]).item()
+    assert abs(energy - (w * ref.real).sum() / w.sum()) < 1e-9
+
+
+def test_sampler_without_amp_symmetry_matches_psi_squared():
+    """naqs_net_sample with sym = 0 (4 raw outputs per block, no spin ordering of the inputs): chi-square against the
+    exact |psi|^2 of the same network over the whole LiH space."""
+    mol, z, hil, wf = _wf("LiH_noampsym")
+    fused = wf.fused()
+    n = 2_000_000
+    keys, counts, probs = fused.sample(n, seed=77, max_unique=100000)
+    k, c = keys.cpu().numpy(), counts.cpu().numpy()
+    assert np.all(np.diff(k) > 0) and hil.is_physical(k).all()
+    all_keys = np.sort(hil._all_keys())
+    with torch.no_grad():
+        lp = wf.log_psi(hil.idx2state(torch.as_tensor(all_keys, device="cuda"))).reshape(-1, 2)
+    p = np.exp(2.0 * lp[:, 0].double().cpu().numpy())                       # torch modules = independent of the kernels
+    pos = np.searchsorted(all_keys, k)
+    assert np.allclose(probs.cpu().numpy(), p[pos], rtol=2e-4, atol=1e-12)
+    total, p_phys = c.sum(), p.sum()
+    assert abs(total - n * p_phys) < 6 * np.sqrt(n * p_phys * (1 - p_phys)) + 1
+    obs = np.zeros(len(all_keys))
+    obs[pos] = c
+    expect = p / p_phys * total
+    m = expect >= 5
+    chi2 = ((obs[m] - expect[m]) ** 2 / expect[m]).sum()
+    assert stats.chi2.sf(chi2, m.sum()) > 1e-4, (chi2, m.sum())
+
+
+def test_sweep_geometry_short_training_run_full_mask(tmp_path):
+    """config 5 end to end on one GPU: N2 at 0.75 A with -full_mask_psi (batch_train_full_mask.sh:14), 300 steps of the
+    published schedule's first phase: variational (never below FCI), clearly improving, every draw kept."""
+    from naqs_amd.optimizer import LogKey
+    mol, z, hil, wf = _wf("N2_0.75_fullmask")
+    fci = float(golden("ham_N2_0.75.npz")["fci_energy"])
+    opt = _opt(mol, wf, tmp_path, n_samples=1000000, n_unq_samples_min=1000,
+               optimizer_args=[{'lr': 2e-3, 'betas': (0.9, 0.99), 'eps': 1e-15}, {'lr': 1e-2}])
+    states, counts, _ = opt.get_samples()
+    assert counts.sum().item() == opt.n_samples                  # FULL masking: no un-physical draw to discard
+    opt.run(n_epochs=300, save_freq=None, save_final=False, output_freq=100)
+    e = np.array([x[1] for x in opt.log[LogKey.E_LOC]])
+    assert np.mean(e[-10:]) < np.mean(e[:10]) - 1.0
+    assert np.mean(e[-10:]) > fci - 1e-3, (np.mean(e[-10:]), fci)
