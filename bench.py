@@ -2,23 +2,35 @@
 """bench.py — headline benchmark: unique samples/s through log-psi eval + E_loc on N2 (20 qubits),
 M = 10 000 unique samples per GPU (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or under torchrun
 
-One "step" = one pass of the hot path over one batch of M unique sampled bit-strings that is
-already resident in HBM: (log-psi evaluation of the batch ->) hash build -> matrix-free E_loc ->
-weighted energy accumulators.  The K timed steps are K independent batches; two are in flight at
-a time (`--pipeline`, two HIP streams) so that the E_loc / reduce kernels of one batch overlap the
-log-psi kernel of the next; the serial figures are measured in the same run (`serial`,
-`roofline.isolated`).  With N > 1 every rank owns an independent batch stream (weak scaling) and the
-per-step energy accumulators [K, 4] are summed over the ranks by one RCCL all-reduce at the end of
-the timed region — the only collective on the path.
-Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and
-`cpu_baseline`.
+One "step" = one pass of the hot path over one batch of M unique sampled bit-strings that is already resident
+in HBM: (log-psi evaluation of the batch ->) hash build -> matrix-free E_loc -> weighted energy accumulators.
+
+Modes
+  default        K independent batches per rank (4 distinct key sets, rotated), `--pipeline` of them in flight on as
+                 many HIP streams; with N > 1 every rank owns its own batch stream (weak scaling: the 14 400-state N2
+                 space cannot supply N x 10 000 unique samples for one table) and the per-step accumulators [K, 4]
+                 are summed over the ranks by one RCCL all-reduce at the end of the timed region.  After the timed
+                 region the same process also measures, and reports inside the same JSON line,
+                   * `serial`: the step one batch at a time (kernel durations with the GPU to themselves);
+                   * `config4_row_sharded`: BASELINE config 4 / north_star's split — ONE Li2O table of 50 000 keys,
+                     rows sharded over the ranks (below) — so that a 1/2/4/8-GPU sweep of the default command also
+                     yields the strong-scaling curve of the sharded table.
+  --shard rows   the sharded table as the primary measurement: every rank evaluates log psi for its contiguous row
+                 shard, ONE all-gather assembles the (log|psi|, phase) table (M x 8 B), every rank runs
+                 `naqs_eloc` for its rows against the whole table, ONE all-reduce per step sums the 4 energy
+                 accumulators.  Total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and `cpu_baseline`; everything
+in it is measured by this run except the fields tagged `"replayed": true` (hardware counters, which only a
+rocprofv3 --pmc pass can produce: they are read from the committed profiles/ file named beside them).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,8 +46,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 PROF_STRIDE = 10
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # f32-in/f32-acc MFMA dense peak (MI355X_MICROARCH.md: = the f32 vector rate)
+N_CU, SIMD_PER_CU, VALU_CYCLES_PER_WAVE_INST, MAX_CLOCK_HZ = 256, 4, 2, 2.4e9   # MI355X_MICROARCH.md (SIMD-32: 2 cycles)
+N_KEY_SETS = 4
+PMC_TRAFFIC = "profiles/r02_pmc_traffic.json"
+PMC_ISSUE = "profiles/r02_pmc_issue.json"
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# workload
+# ------------------------------------------------------------------------------------------------------------------
 def physical_keys(n_qubits, n_alpha, n_beta):
     from itertools import combinations
     al = [sum(1 << b for b in c) for c in combinations(range(0, n_qubits, 2), n_alpha)]
@@ -53,13 +72,16 @@ def make_batch(ham, M, seed):
         keys = np.sort(np.random.RandomState(1234 + seed).choice(space, M, replace=False))
     else:
         # config C4 (Li2O: 41 409 225 states): M distinct keys, alpha part = random n_alpha-subset of the even
-        # bits, beta part = random n_beta-subset of the odd bits
+        # bits, beta part = random n_beta-subset of the odd bits (vectorised: random scores, the smallest n win)
         rs0 = np.random.RandomState(1234 + seed)
-        ev, od, out = np.arange(0, ham.n_qubits, 2), np.arange(1, ham.n_qubits, 2), set()
-        while len(out) < M:
-            a, b_ = rs0.choice(ev, ham.n_alpha, replace=False), rs0.choice(od, ham.n_beta, replace=False)
-            out.add(int(sum(1 << int(q) for q in a) | sum(1 << int(q) for q in b_)))
-        keys = np.sort(np.array(list(out), np.uint64))
+        keys = np.zeros(0, np.uint64)
+        while len(keys) < M:
+            n = int((M - len(keys)) * 1.1) + 16
+            a = np.argsort(rs0.random_sample((n, n_orb)), axis=1)[:, :ham.n_alpha]
+            b = np.argsort(rs0.random_sample((n, n_orb)), axis=1)[:, :ham.n_beta]
+            k = (np.uint64(1) << (2 * a).astype(np.uint64)).sum(1) | (np.uint64(1) << (2 * b + 1).astype(np.uint64)).sum(1)
+            keys = np.unique(np.concatenate([keys, k.astype(np.uint64)]))
+        keys = np.sort(rs0.permutation(keys)[:M])
     rs = np.random.RandomState(4321 + seed)
     log_psi = np.stack([rs.normal(-0.5 * np.log(M), 2.0, M), rs.uniform(0, 2 * np.pi, M)], -1).astype(np.float32)
     counts = rs.poisson(5, M) + 1
@@ -72,12 +94,42 @@ def algorithmic_bytes(M, K, Kxy):
     return M * (40 + 24 * Kxy) + 16 * K + 12 * Kxy
 
 
-def cpu_baseline(ham_p, keys, log_psi, wf_args, budget_s=12.0):
+def logpsi_flops(n_qubits, M, amp_in_kernel=True):
+    """phase MLP 2*(K*N) flops per layer and sample (18->512->512->4 for N2) + the amplitude blocks
+    (pair n: 2n -> 64 -> 5) evaluated in the same launch."""
+    dims = [max(1, 2 * (n_qubits // 2 - 1)), 512, 512, 4]
+    f = 2.0 * M * sum(a * b for a, b in zip(dims, dims[1:]))
+    if amp_in_kernel:
+        f += 2.0 * M * sum(max(1, 2 * n) * 64 + 64 * 5 for n in range(n_qubits // 2))
+    return f
+
+
+def published_ansatz(ham_p):
+    # experiments/bash/naqs/batch_train.sh:14: amplitude blocks 1x64, one phase block 2x512
+    return dict(qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512], use_amp_spin_sym=True,
+                use_phase_spin_sym=False, aggregate_phase=False, n_alpha_electrons=ham_p.n_alpha,
+                n_beta_electrons=ham_p.n_beta)
+
+
+def shard_rows(M, rank, world):
+    """Equal padded shards (an all-gather needs equal contributions): rank r evaluates log psi for rows
+    [r*S, (r+1)*S) of the table padded to S*world rows and owns E_loc rows [r*S, min(M, (r+1)*S))."""
+    S = -(-M // world)
+    b = min(M, rank * S)
+    return S, b, min(M, b + S)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU leg
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(ham_p, keys, log_psi, wf_args, budget_s=16.0):
     """CPU leg, same two stages as the GPU step, on the host cores of this box, bounded sample:
       * E_loc: the oracle's staged restatement of the reference algorithm (update_H + get_H + SpMV
         with a cold Hamiltonian cache — equal work to the matrix-free GPU path), OpenMP;
       * log-psi eval: the same torch modules the reference would run on CPU (its nade.py is PyTorch),
-        float32, torch's default intra-op threads."""
+        float32, torch intra-op threads.
+    Timed twice: on all host threads and pinned to 8 threads (the box-independent figure BASELINE.md asks for;
+    the build container's 8-core numbers for the reference itself are in BASELINE.md / tests/golden/kat.json)."""
     import torch
     from naqs_amd.hilbert import Encoding, Hilbert
     from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
@@ -85,118 +137,320 @@ def cpu_baseline(ham_p, keys, log_psi, wf_args, budget_s=12.0):
     psi = np.exp(log_psi[:, 0].astype(np.float64)) * np.exp(1j * log_psi[:, 1].astype(np.float64))
     Ms = min(len(keys), 4000)          # M*Kyz / M*Kxy temporaries like the reference; bounded
     k, p = keys[:Ms], psi[:Ms]
-    threads = oracle.max_threads()
+    all_threads = int(oracle.max_threads())
+    torch_all = torch.get_num_threads()
     args = (ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, ham_p.xy, ham_p.yz, ham_p.coeff, k, p)
-    oracle.eloc_staged(*args)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.eloc_staged(*args)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s / 2 or reps >= 100:
-            break
-    t_eloc = dt / reps
     hil = Hilbert.get(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, encoding=Encoding.SIGNED)
     wf = NAQSComplex_NADE_orbitals(hil, device="cpu", **wf_args)
     states = hil.idx2state(torch.from_numpy(k.astype(np.int64)))
-    with torch.no_grad():
-        wf.log_psi(states)
-        reps2, t0 = 0, time.perf_counter()
+
+    def timed(fn, budget):
+        fn()
+        reps, t0 = 0, time.perf_counter()
         while True:
-            wf.log_psi(states)
-            reps2 += 1
-            dt2 = time.perf_counter() - t0
-            if dt2 > budget_s / 2 or reps2 >= 100:
-                break
-    t_lp = dt2 / reps2
-    return {"value": Ms / (t_eloc + t_lp), "unit": "unique samples/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {Ms} samples of the N2 batch: {reps} x E_loc (oracle staged restatement of "
-                      f"update_H+get_H+SpMV, cold cache, {threads} OpenMP threads, {t_eloc * 1e3:.1f} ms each) + "
-                      f"{reps2} x log-psi eval (torch CPU float32, {torch.get_num_threads()} threads, "
-                      f"{t_lp * 1e3:.1f} ms each)",
-            "eloc_only_samples_per_s": Ms / t_eloc, "logpsi_only_samples_per_s": Ms / t_lp}
+            fn()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= 100:
+                return dt / reps, reps
+
+    def leg(threads, torch_threads, budget):
+        oracle.set_threads(threads)
+        torch.set_num_threads(torch_threads)
+        t_e, r_e = timed(lambda: oracle.eloc_staged(*args), budget / 2)
+        with torch.no_grad():
+            t_l, r_l = timed(lambda: wf.log_psi(states), budget / 2)
+        return {"value": Ms / (t_e + t_l), "cores": int(threads), "eloc_ms": t_e * 1e3, "logpsi_ms": t_l * 1e3,
+                "eloc_reps": r_e, "logpsi_reps": r_l, "torch_threads": int(torch_threads),
+                "eloc_only_samples_per_s": Ms / t_e, "logpsi_only_samples_per_s": Ms / t_l}
+
+    try:
+        full = leg(all_threads, torch_all, budget_s * 0.6)
+        eight = leg(min(8, all_threads), min(8, torch_all), budget_s * 0.4)
+    finally:
+        oracle.set_threads(all_threads)
+        torch.set_num_threads(torch_all)
+    return {"value": full["value"], "unit": "unique samples/s", "cores": full["cores"], "kind": "port",
+            "sample": f"first {Ms} samples of the batch: {full['eloc_reps']} x E_loc (oracle staged restatement of "
+                      f"update_H+get_H+SpMV, cold cache, {full['cores']} OpenMP threads, {full['eloc_ms']:.1f} ms each) + "
+                      f"{full['logpsi_reps']} x log-psi eval (torch CPU float32, {full['torch_threads']} threads, "
+                      f"{full['logpsi_ms']:.1f} ms each)",
+            "eloc_only_samples_per_s": full["eloc_only_samples_per_s"],
+            "logpsi_only_samples_per_s": full["logpsi_only_samples_per_s"],
+            "eight_threads": {k_: eight[k_] for k_ in ("value", "cores", "eloc_ms", "logpsi_ms", "torch_threads")}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--molecule", default="N2")
-    ap.add_argument("--samples", type=int, default=10000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial-segment", action="store_true",
-                    help="after the timed region, run 200 more steps one batch at a time and report them under `serial`")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="independent batches in flight (HIP streams, one Hamiltonian/network handle pair each); 1 = serial")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with N > 1 and no launcher in the environment
+# ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Start one child process per GPU (rank r -> LOCAL_RANK r) and wait for them.  The parent never touches the GPU
+    (no HIP call before or after the children start — a process that has initialised the GPU must not exec or fork
+    GPU work).  Rank 0's stdout is passed through, so its JSON line stays the last line of ours; the other ranks'
+    output goes to stderr."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), NAQS_BENCH_CHILD="1")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    codes = []
+    deadline = time.time() + float(os.environ.get("NAQS_BENCH_LAUNCH_TIMEOUT", "3600"))
+    for pr in procs:
+        try:
+            codes.append(pr.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            codes.append(124)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        for pr in procs:           # one rank failed: the others would wait in a collective for ever
+            if pr.poll() is None:
+                pr.kill()
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    return max(codes, key=abs) if bad else 0
+
+
+def dry_run(args, world, rank):
+    """NAQS_BENCH_DRY_RUN=1 (tests/test_bench.py, no GPU): the ranks the launcher started form a gloo group and push
+    the sharded step's collectives through it with the real shapes — padded row shards all-gathered into the
+    (log|psi|, phase) table, 4 accumulators all-reduced per step — on closed-form stand-in values, so that shard
+    bounds, gather order and the reduction can be checked exactly.  Nothing is measured: "value" is null."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    M = args.samples
+    S, b, e = shard_rows(M, rank, world)
+    rows = torch.arange(rank * S, (rank + 1) * S, dtype=torch.float64)
+    mine = torch.stack([rows * 0.5, -rows], -1)                       # stand-in (log|psi|, phase) of my padded shard
+    table = torch.empty((S * world, 2), dtype=torch.float64)
+    if world > 1:
+        dist.all_gather_into_tensor(table, mine)
+    else:
+        table.copy_(mine)
+    want = torch.arange(S * world, dtype=torch.float64)
+    ok_table = bool(torch.equal(table[:, 0], want * 0.5) and torch.equal(table[:, 1], -want))
+    acc = torch.zeros((args.steps, 4), dtype=torch.float64)
+    r = torch.arange(b, e, dtype=torch.float64)
+    for i in range(args.steps):
+        acc[i] = torch.stack([r.sum() * (i + 1), (r * r).sum(), torch.tensor(float(e - b)), torch.tensor(1.0)])
+        if world > 1:
+            dist.all_reduce(acc[i])
+    full = torch.arange(M, dtype=torch.float64)
+    ok_acc = bool(acc[-1, 0] == full.sum() * args.steps and acc[-1, 1] == (full * full).sum()
+                  and acc[-1, 2] == M and acc[-1, 3] == world)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher + collectives wiring; nothing measured)", "value": None,
+                          "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ranks": world, "backend": "gloo", "shard_rows": [S, b, e], "table_ok": ok_table,
+                          "accumulators_ok": ok_acc, "shard": args.shard}), flush=True)
+    return 0 if (ok_table and ok_acc) else 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the row-sharded table (config 4 / north_star's split)
+# ------------------------------------------------------------------------------------------------------------------
+def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
+    """-> dict with ms_per_step, samples/s and the kernel durations of one sharded table of M keys."""
+    import torch
+    import torch.distributed as dist
+    from naqs_amd import hamiltonian, packing
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hilbert import Encoding, Hilbert
+    from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+    ham_p = packing.load_packed(os.path.join(ROOT, "tests", "golden", f"ham_{molecule}.npz"))
+    ham = hamiltonian.DevicePauliHamiltonian(ham_p, device=dev)
+    keys_np, log_psi_np, counts_np = make_batch(ham_p, M, seed=0)           # ONE table, the same on every rank
+    keys = hamiltonian.keys_to_device(keys_np, dev)
+    torch.manual_seed(1234)                                                   # replicated network
+    hil = Hilbert.get(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, encoding=Encoding.SIGNED)
+    wf_args = published_ansatz(ham_p)
+    wf = NAQSComplex_NADE_orbitals(hil, device=dev, **wf_args)
+    net = FusedLogPsi(wf)
+    S, b, e = shard_rows(M, rank, world)
+    pad = S * world - M
+    keys_pad = torch.cat([keys, keys[:pad]]) if pad else keys
+    my_keys = keys_pad[rank * S:(rank + 1) * S].contiguous()
+    lp_mine = torch.empty((S, 2), dtype=torch.float32, device=dev)
+    table = torch.empty((S * world, 2), dtype=torch.float32, device=dev)
+    weights = torch.as_tensor(counts_np / counts_np.sum(), dtype=torch.float64, device=dev)
+    w_mine = weights[b:e].contiguous()
+    eloc = torch.empty((max(e - b, 0), 2), dtype=torch.float64, device=dev)
+    acc = torch.zeros((warmup + steps, 4), dtype=torch.float64, device=dev)
+    ham.reserve(M)
+    pending = []
+
+    def step(i):
+        net.log_psi(my_keys, out=lp_mine)                                     # my rows of the table
+        if use_dist:
+            dist.all_gather_into_tensor(table, lp_mine)                       # the exchange step: M x 8 B in all
+            lp_table = table
+        else:
+            lp_table = lp_mine
+        ham.local_energy(keys, lp_table[:M], kind="log_psi", row_begin=b, n_rows=e - b, weights=w_mine, out=eloc,
+                         sums_out=acc[i])
+        if use_dist:
+            pending.append(dist.all_reduce(acc[i], async_op=True))            # 32 B; overlaps the next step's kernels
+
+    def fence():
+        for w_ in pending:
+            w_.wait()
+        pending.clear()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    stride = max(1, min(PROF_STRIDE, steps // 8))
+    ham.prof_enable(steps // stride + 1, stride)
+    net.prof_enable(steps // stride + 1, stride)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    e_ms, e_n = ham.prof_read(); ham.prof_enable(0)
+    p_ms, p_n = net.prof_read(); net.prof_enable(0)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if use_dist and world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    s = acc[warmup + steps - 1].cpu().numpy()
+    t_eloc, t_lp = e_ms / max(e_n, 1) * 1e-3, p_ms / max(p_n, 1) * 1e-3
+    res = {"workload": f"{molecule} STO-3G ({ham.n_qubits} qubits, K={ham.K}, Kxy={ham.Kxy}): ONE table of {M} unique "
+                       f"samples, rows sharded over {world} rank(s)",
+           "value": M * steps / dt, "unit": "unique samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "warmup": warmup, "scaling": "strong", "rows_per_rank": int(e - b), "logpsi_rows_per_rank": int(S),
+           "collectives_per_step": (f"1 all-gather of the (log|psi|, phase) table ({M * 8} B in all) + 1 all-reduce of 4 "
+                                    f"accumulators (32 B), RCCL, {dist.get_world_size()} rank(s)") if use_dist else "none (single process)",
+           "energy": float(s[0] / s[3]),
+           "eloc_kernel_us": t_eloc * 1e6, "logpsi_kernel_us": t_lp * 1e6}
+    b_alg = algorithmic_bytes(e - b, ham.K, ham.Kxy) if e > b else 0
+    res["eloc_algorithmic_GBps"] = b_alg / t_eloc / 1e9 if t_eloc > 0 else 0.0
+    issue = issue_roofline(f"{molecule}_{M}", t_eloc) if world == 1 else None
+    if issue:
+        res["eloc_issue"] = issue
+    ham.close()
+    net.close()
+    return res, (ham_p, keys_np, log_psi_np, wf_args)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# committed hardware-counter files (replayed: only a rocprofv3 --pmc pass can produce them)
+# ------------------------------------------------------------------------------------------------------------------
+def _load_json(rel):
+    try:
+        with open(os.path.join(ROOT, rel)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def issue_roofline(workload_key, t_kernel_s):
+    """VALU issue utilisation of eloc_kernel = wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed
+    --pmc pass, tools/collect_pmc.py) x 2 cycles each (a wave64 VALU instruction occupies its SIMD-32 for 2 cycles,
+    MI355X_MICROARCH.md) / (256 CUs x 4 SIMDs x kernel cycles).  Kernel cycles: the live duration of THIS run x the
+    clock the counter pass observed (GRBM_GUI_ACTIVE / duration; 2.4 GHz if absent)."""
+    pmc = _load_json(PMC_ISSUE)
+    if not pmc or workload_key not in pmc or "eloc_kernel" not in pmc[workload_key] or t_kernel_s <= 0:
+        return None
+    c = pmc[workload_key]["eloc_kernel"]
+    clock = c.get("effective_clock_hz") or MAX_CLOCK_HZ
+    slots = N_CU * SIMD_PER_CU * t_kernel_s * clock / VALU_CYCLES_PER_WAVE_INST
+    out = {"bound": "valu-issue", "valu_insts_per_launch": c["SQ_INSTS_VALU"], "issue_slots_per_launch": slots,
+           "frac": c["SQ_INSTS_VALU"] / slots, "clock_hz": clock, "replayed": True, "source": PMC_ISSUE,
+           "counters_per_launch": {k: v for k, v in c.items() if k.startswith(("SQ_", "GRBM_"))}}
+    if c.get("kernel_us"):
+        # the same fraction entirely from the counter pass (its own duration): the figure the committed file supports
+        out["frac_in_counter_pass"] = c["SQ_INSTS_VALU"] / (N_CU * SIMD_PER_CU * c["kernel_us"] * 1e-6 * clock /
+                                                            VALU_CYCLES_PER_WAVE_INST)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def worker(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NAQS_BENCH_DRY_RUN") == "1":
+        return dry_run(args, world, rank)
 
     import torch
     import torch.distributed as dist
     from naqs_amd import hamiltonian, packing
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("NAQS_BENCH_FORCE_DIST") == "1":
+    use_dist = world > 1 or os.environ.get("NAQS_BENCH_FORCE_DIST") == "1"      # (forced at world 1: exercises the path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    if args.shard == "rows":
+        return sharded_main(args, dev, world, rank, use_dist)
+
     ham_p = packing.load_packed(os.path.join(ROOT, "tests", "golden", f"ham_{args.molecule}.npz"))
     ham = hamiltonian.DevicePauliHamiltonian(ham_p, device=dev)
     M = args.samples
-    keys_np, log_psi_np, counts_np = make_batch(ham_p, M, seed=rank)   # log_psi_np: CPU-baseline psi only
-    keys = hamiltonian.keys_to_device(keys_np, dev)
+    # N_KEY_SETS distinct batches per rank, rotated step by step: consecutive steps never see the same keys, so hash
+    # table, psi table and key list are rebuilt from different data every step (nothing is L2-warm from the step before)
+    batches = [make_batch(ham_p, M, seed=rank * N_KEY_SETS + j) for j in range(N_KEY_SETS)]
+    keys_np, log_psi_np, counts_np = batches[0]                                   # (log_psi_np: CPU-baseline psi only)
+    key_sets = [hamiltonian.keys_to_device(b_[0], dev) for b_ in batches]
+    weight_sets = [torch.as_tensor(b_[2] / b_[2].sum(), dtype=torch.float64, device=dev) for b_ in batches]
     # ansatz of the published runs (experiments/bash/naqs/batch_train.sh:14): amplitude blocks 1x64,
     # one phase block 2x512, random init (no checkpoints without network) -> log psi of the batch
     from naqs_amd.hilbert import Encoding, Hilbert
     from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
     torch.manual_seed(1234 + rank)
     hil = Hilbert.get(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, encoding=Encoding.SIGNED)
-    wf_args = dict(qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512], use_amp_spin_sym=True,
-                   use_phase_spin_sym=False, aggregate_phase=False, n_alpha_electrons=ham_p.n_alpha,
-                   n_beta_electrons=ham_p.n_beta)
+    wf_args = published_ansatz(ham_p)
     wf = NAQSComplex_NADE_orbitals(hil, device=dev, **wf_args)
     from naqs_amd.fused import FusedLogPsi
     # Throughput of a STREAM of independent batches: `depth` of them are in flight, each on its own HIP stream with its
     # own handle pair (a handle owns per-call scratch: hash table, psi table), so the E_loc / reduce kernels of one batch
-    # run beside the log-psi kernel of the next (which leaves 47 of 256 CUs idle on its own).  --pipeline 1 = one batch
-    # at a time; its step time is measured too and reported as `serial_ms_per_step`.
+    # run beside the log-psi kernel of the next.  --pipeline 1 = one batch at a time (also measured: `serial`).
     depth = max(1, args.pipeline)
     hams = [ham] + [hamiltonian.DevicePauliHamiltonian(ham_p, device=dev) for _ in range(depth - 1)]
     nets = [FusedLogPsi(wf) for _ in range(depth)]       # libnaqs_hip.so: MFMA log-psi kernel
-    fused = nets[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream(dev)]
     log_psis = [torch.empty((M, 2), dtype=torch.float32, device=dev) for _ in range(depth)]
     elocs = [torch.empty((M, 2), dtype=torch.float64, device=dev) for _ in range(depth)]
-    log_psi = log_psis[0]
-    weights = torch.as_tensor(counts_np / counts_np.sum(), dtype=torch.float64, device=dev)
     for h_ in hams:
         h_.reserve(M)
     torch.cuda.synchronize()
-    # energy accumulators: two buffers, so that the RCCL all-reduce of step k (4 doubles, latency-bound on xGMI) runs on
-    # the collective stream under the kernels of step k+1 instead of in front of them
     # energy accumulators: one row of 4 doubles per step, written by the reduce kernel of that step; with N > 1 GPUs the
     # rows of the whole timed region are summed over the ranks by ONE RCCL all-reduce at its end (few, larger
     # collectives: a per-step 32-byte all-reduce is pure xGMI latency and only a training step needs <E> that early)
-    acc_all = torch.zeros((args.warmup + args.steps + 201, 4), dtype=torch.float64, device=dev)
-    use_dist = world > 1 or os.environ.get("NAQS_BENCH_FORCE_DIST") == "1"      # (forced at world 1: exercises the path)
+    n_serial = min(args.steps, 200)
+    acc_all = torch.zeros((args.warmup + args.steps + n_serial + 1, 4), dtype=torch.float64, device=dev)
     n_done = [0]
 
     def step(d_override=None):
-        row = acc_all[n_done[0]]
-        d = (n_done[0] % depth) if d_override is None else d_override
+        i = n_done[0]
+        row = acc_all[i]
+        d = (i % depth) if d_override is None else d_override
         with torch.cuda.stream(streams[d]):
             # one library call: phase kernel (amplitude conditionals + phase MLP on the matrix cores; builds the key hash
             # and psi in f64) -> eloc_kernel -> reduce_kernel
-            nets[d].log_psi_and_local_energy(hams[d], keys, weights=weights, log_psi_out=log_psis[d], eloc_out=elocs[d],
-                                             sums_out=row)
+            nets[d].log_psi_and_local_energy(hams[d], key_sets[i % N_KEY_SETS], weights=weight_sets[i % N_KEY_SETS],
+                                             log_psi_out=log_psis[d], eloc_out=elocs[d], sums_out=row)
         n_done[0] += 1
 
     def fence(first_row=None):
@@ -229,44 +483,54 @@ def main():
         h_.prof_enable(0)
         a, b = n_.prof_read(); mlp_ms += a; mlp_launches += b
         n_.prof_enable(0)
-    # the same K steps one batch at a time (single stream, first handle pair): latency of a batch, and the kernels'
-    # durations when each has the GPU to itself
+    # the same step one batch at a time (single stream, first handle pair), measured in this same run: latency of a
+    # batch, and the kernels' durations when each has the GPU to itself
     serial = None
-    if depth > 1 and world == 1 and args.serial_segment:
-        ks = min(args.steps, 200)
-        hams[0].prof_enable(ks // stride + 1, stride)
-        nets[0].prof_enable(ks // stride + 1, stride)
+    if depth > 1 and not args.no_serial_segment:
+        hams[0].prof_enable(n_serial // stride + 1, stride)
+        nets[0].prof_enable(n_serial // stride + 1, stride)
         t1 = time.perf_counter()
-        for _ in range(ks):
+        for _ in range(n_serial):
             step(0)
         fence()
         dts = time.perf_counter() - t1
         e_ms, e_n = hams[0].prof_read(); hams[0].prof_enable(0)
         p_ms, p_n = nets[0].prof_read(); nets[0].prof_enable(0)
-        serial = {"ms_per_step": dts / ks * 1e3, "steps": ks, "eloc_kernel_us": e_ms / max(e_n, 1) * 1e3,
-                  "logpsi_kernel_us": p_ms / max(p_n, 1) * 1e3}
+        serial = {"ms_per_step": dts / n_serial * 1e3, "steps": n_serial, "eloc_kernel_us": e_ms / max(e_n, 1) * 1e3,
+                  "logpsi_kernel_us": p_ms / max(p_n, 1) * 1e3, "measured": "this run, after the timed region"}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    s = acc_all[last_row].cpu().numpy()
+    for h_ in hams[1:]:
+        h_.close()
+    for n_ in nets[1:]:
+        n_.close()
 
+    # BASELINE config 4 in the same run (every rank takes part: it has collectives)
+    config4 = None
+    if not args.no_config4 and args.molecule == "N2":
+        try:
+            config4, _ = run_row_sharded(dev, world, rank, use_dist, "Li2O", 50000, steps=max(20, min(args.steps, 100)),
+                                         warmup=max(2, min(args.warmup, 10)))
+        except Exception as ex:                                          # the headline must survive a secondary failure
+            config4 = {"error": f"{type(ex).__name__}: {ex}"}
+
+    out = None
     if rank == 0:
-        s = acc_all[last_row].cpu().numpy()
         b_alg = algorithmic_bytes(M, ham.K, ham.Kxy)
         t_kernel = kern_ms / max(launches, 1) * 1e-3
         achieved = b_alg / t_kernel / 1e9 if t_kernel > 0 else 0.0
         eloc_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "eloc_kernel",
-                     "kernel_us": t_kernel * 1e6, "algorithmic_bytes_per_launch": b_alg}
-        # phase MLP: 2*(K*N) flops per layer and sample (18->512->512->4 for N2), f32 matrix cores
-        dims = [max(1, 2 * (ham.n_qubits // 2 - 1)), 512, 512, 4]
-        flops = 2.0 * M * sum(a * b for a, b in zip(dims, dims[1:]))
-        # ... and, unless NAQS_AMP_MODE=0 keeps them in their own kernel, the amplitude blocks (pair n: 2n -> 64 -> 5)
-        # evaluated in the same launch (2 * sum_n (max(1, 2n) * 64 + 64 * 5) flops per sample)
+                     "kernel_us": t_kernel * 1e6, "algorithmic_bytes_per_launch": b_alg,
+                     "note": "algorithmic rate (SURVEY 8d bytes / kernel time): 76 % of the candidates are rejected by two "
+                             "popcounts and the tables are L2-resident, so this is not a DRAM rate — `traffic` is the DRAM "
+                             "bytes, `issue` the bound that actually applies (VALU issue slots)"}
         amp_in_kernel = os.environ.get("NAQS_AMP_MODE", "1") == "1" and os.environ.get("NAQS_PHASE_MODE", "1") == "1"
-        if amp_in_kernel:
-            flops += 2.0 * M * sum(max(1, 2 * n) * 64 + 64 * 5 for n in range(ham.n_qubits // 2))
+        flops = logpsi_flops(ham.n_qubits, M, amp_in_kernel)
         t_mlp = mlp_ms / max(mlp_launches, 1) * 1e-3
         mlp_tf = flops / t_mlp / 1e12 if t_mlp > 0 else 0.0
         # The kernel evaluates the f32 network with every operand split into three bf16 planes (six exact cross
@@ -278,41 +542,36 @@ def main():
         mlp_roof = {"bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": mlp_tf / MFMA_F32_PEAK_TF, "traffic": None,
                     "kernel": ("phase_kernel_bf16x3 (" + ("amplitude conditionals + " if amp_in_kernel else "") +
-                               "phase MLP; f32 via 3-way bf16 split, v_mfma_f32_16x16x32_bf16)") if bf16_mode
+                               "phase MLP; f32 via 3-way bf16 split on the bf16 matrix cores)") if bf16_mode
                               else "phase_kernel (f32 MFMA 16x16x4)",
                     "kernel_us": t_mlp * 1e6, "algorithmic_flops_per_launch": flops}
         if bf16_mode:
             mlp_roof["executed"] = {"dtype": "bf16", "tflops": 6 * mlp_tf, "peak": MFMA_BF16_PEAK_TF,
                                     "frac": 6 * mlp_tf / MFMA_BF16_PEAK_TF}
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # HBM bytes per launch: hardware counters, from the committed rocprofv3 --pmc passes of this same command
         # (tools/collect_pmc.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 corrections applied there)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if args.molecule == "N2" and M == 10000:           # the PMC passes were taken on this workload
-                eloc_roof["traffic"] = pmc["eloc_kernel"]["hbm_bytes_per_launch"]
-                mlp_roof["traffic"] = pmc["phase_kernel"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        if serial is None and depth > 1 and args.molecule == "N2" and M == 10000:
-            # kernel durations of `bench.py --pipeline 1` on this workload, from the committed run (profiles/)
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_bench_n2_10k_serial.json")) as f:
-                    ser = json.load(f)
-                serial = {"ms_per_step": ser["ms_per_step"], "steps": ser["steps"], "source": "profiles/r01_bench_n2_10k_serial.json",
-                          "logpsi_kernel_us": ser["roofline"]["kernel_us"],
-                          "eloc_kernel_us": ser["roofline"]["other_kernels"][0]["kernel_us"]}
-            except (OSError, KeyError, ValueError, IndexError):
-                serial = None
+        pmc = _load_json(PMC_TRAFFIC)
+        if pmc and args.molecule == "N2" and M == 10000:               # the PMC passes were taken on this workload
+            for roof, name in ((eloc_roof, "eloc_kernel"), (mlp_roof, "phase_kernel")):
+                if name in pmc:
+                    roof["traffic"] = pmc[name]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = {"replayed": True, "file": PMC_TRAFFIC}
         if serial is not None:
             # the same kernels with the GPU to themselves (one batch at a time): what the kernel itself achieves; the
             # durations above are longer because the next batch's kernels share the CUs during the timed region
             if serial["logpsi_kernel_us"] > 0:
                 tf = flops / (serial["logpsi_kernel_us"] * 1e-6) / 1e12
                 mlp_roof["isolated"] = {"kernel_us": serial["logpsi_kernel_us"], "achieved": tf, "frac": tf / MFMA_F32_PEAK_TF}
+                if bf16_mode:
+                    mlp_roof["isolated"]["executed_frac"] = 6 * tf / MFMA_BF16_PEAK_TF
             if serial["eloc_kernel_us"] > 0:
                 gb = b_alg / (serial["eloc_kernel_us"] * 1e-6) / 1e9
                 eloc_roof["isolated"] = {"kernel_us": serial["eloc_kernel_us"], "achieved": gb, "frac": gb / HBM_PEAK_GBS}
+        t_issue = (serial["eloc_kernel_us"] * 1e-6) if serial and serial["eloc_kernel_us"] > 0 else t_kernel
+        issue = issue_roofline(f"{args.molecule}_{M}", t_issue)
+        if issue:
+            issue["kernel_us_used"] = t_issue * 1e6
+            eloc_roof["issue"] = issue
         dominant, other = (mlp_roof, eloc_roof) if t_mlp >= t_kernel else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]
@@ -332,17 +591,69 @@ def main():
                                     if world > 1 else ""),
                        "pipeline": (f"{depth} independent batches in flight on {depth} HIP streams (one handle pair each)"
                                     if depth > 1 else "one batch at a time"),
-                       "input": "unique sampled bit-strings (keys + int8 occupations) resident in HBM; random-init network",
+                       "batches": f"{N_KEY_SETS} distinct key sets per rank, rotated every step",
+                       "input": "unique sampled bit-strings (keys) resident in HBM; random-init network",
+                       "ranks": (f"{dist.get_world_size()} RCCL rank(s)" if use_dist else "single process, no process group"),
                        "energy": float(s[0] / s[3])},
             "roofline": roofline,
         }
         if serial is not None:
             out["serial"] = serial
+        if config4 is not None:
+            out["config4_row_sharded"] = config4
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np, wf_args)
-    else:
-        out = None
-    if dist.is_initialized():
+    finish(out)
+    return 0
+
+
+def sharded_main(args, dev, world, rank, use_dist):
+    """--shard rows: the sharded table is the measurement (BASELINE config 4 with --molecule Li2O --samples 50000)."""
+    import torch.distributed as dist
+    res, (ham_p, keys_np, log_psi_np, wf_args) = run_row_sharded(dev, world, rank, use_dist, args.molecule, args.samples,
+                                                                 args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        t_eloc, t_lp = res["eloc_kernel_us"] * 1e-6, res["logpsi_kernel_us"] * 1e-6
+        rows, S = res["rows_per_rank"], res["logpsi_rows_per_rank"]
+        from naqs_amd import packing  # noqa: F401
+        K, Kxy = ham_p.K, len(np.unique(ham_p.xy))
+        b_alg = algorithmic_bytes(rows, K, Kxy)
+        gb = b_alg / t_eloc / 1e9 if t_eloc > 0 else 0.0
+        eloc_roof = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "eloc_kernel", "kernel_us": t_eloc * 1e6,
+                     "algorithmic_bytes_per_launch": b_alg,
+                     "note": "algorithmic rate (SURVEY 8d bytes / kernel time), not a DRAM rate: most candidates are rejected "
+                             "in registers / by the LDS Bloom filter — see `issue` for the bound that applies"}
+        if "eloc_issue" in res:
+            eloc_roof["issue"] = res.pop("eloc_issue")
+        flops = logpsi_flops(ham_p.n_qubits, S)
+        tf = flops / t_lp / 1e12 if t_lp > 0 else 0.0
+        mlp_roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                    "traffic": None, "kernel": "phase_kernel_bf16x3", "kernel_us": t_lp * 1e6,
+                    "algorithmic_flops_per_launch": flops,
+                    "executed": {"dtype": "bf16", "tflops": 6 * tf, "peak": MFMA_BF16_PEAK_TF, "frac": 6 * tf / MFMA_BF16_PEAK_TF}}
+        dominant, other = (mlp_roof, eloc_roof) if t_lp >= t_eloc else (eloc_roof, mlp_roof)
+        roofline = dict(dominant)
+        roofline["other_kernels"] = [other]
+        out = {"metric": f"unique samples/sec through E_loc + log-psi eval ({args.molecule}, {ham_p.n_qubits} qubits), one "
+                         f"row-sharded table",
+               "value": res["value"], "unit": "unique samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32 network (bf16x3-split MFMA, f32-equivalent) / f64 E_loc", "data": "synthetic",
+               "config": {"workload": res["workload"], "collectives_per_step": res["collectives_per_step"],
+                          "ranks": (f"{dist.get_world_size()} RCCL rank(s)" if use_dist else "single process, no process group"),
+                          "rows_per_rank": rows, "energy": res["energy"]},
+               "roofline": roofline}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np, wf_args)
+    finish(out)
+    return 0
+
+
+def finish(out):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     if out is not None:
         # the JSON line must be the last line of stdout: RCCL writes its version banner through C stdio, which would
@@ -356,5 +667,39 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--molecule", default="N2")
+    ap.add_argument("--samples", type=int, default=10000)
+    ap.add_argument("--shard", choices=["batches", "rows"], default="batches",
+                    help="batches: independent batches per rank (weak scaling, default); rows: ONE table, rows sharded over "
+                         "the ranks, all-gather of log psi + all-reduce of the accumulators per step (strong scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial-segment", action="store_true",
+                    help="skip the one-batch-at-a-time segment that follows the timed region (`serial`, `roofline.isolated`)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="skip the secondary row-sharded Li2O 50 000 table that follows the timed region (`config4_row_sharded`)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="independent batches in flight (HIP streams, one Hamiltonian/network handle pair each); 1 = serial")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # the driver's convention `python bench.py --gpus N`: nobody started ranks for us -> start them ourselves,
+        # before anything in this process touches the GPU
+        return launch_ranks(args.gpus, argv)
+    if env_world is not None and int(env_world) != args.gpus and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; using {env_world}",
+              file=sys.stderr)
+    return worker(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -31,8 +31,99 @@ def test_bench_imports_and_workload_is_deterministic():
     assert bench.algorithmic_bytes(10000, 2239, 378) == 10000 * (40 + 24 * 378) + 16 * 2239 + 12 * 378 == 91160360
 
 
+def test_li2o_batch_and_row_shards():
+    """config 4's table: 50 000 distinct physical 30-qubit keys (7 alpha on even bits, 7 beta on odd bits), and the
+    padded row shards of the sharded mode tile it."""
+    bench = _bench()
+    from naqs_amd import packing
+    ham = packing.load_packed(os.path.join(ROOT, "tests", "golden", "ham_Li2O.npz"))
+    k, lp, c = bench.make_batch(ham, 50000, 0)
+    assert len(k) == 50000 and np.all(np.diff(k.astype(np.int64)) > 0) and np.array_equal(k, bench.make_batch(ham, 50000, 0)[0])
+    even, odd = sum(1 << q for q in range(0, 30, 2)), sum(1 << q for q in range(1, 30, 2))
+    pa = np.array([bin(int(x) & even).count("1") for x in k[:2000]])
+    pb = np.array([bin(int(x) & odd).count("1") for x in k[:2000]])
+    assert (pa == 7).all() and (pb == 7).all() and int(k.max()) < 2 ** 30
+    for M in (1, 7, 10000, 50000, 50001):
+        for world in (1, 2, 3, 8):
+            sh = [bench.shard_rows(M, r, world) for r in range(world)]
+            S = sh[0][0]
+            assert all(s_[0] == S for s_ in sh) and S * world >= M
+            assert sh[0][1] == 0 and sh[-1][2] == M and all(sh[i][2] == sh[i + 1][1] for i in range(world - 1))
+
+
+def _run_bench(argv, env_extra, timeout=300):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if k not in env_extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    return r, lines
+
+
+@pytest.mark.parametrize("n,samples", [(2, 10000), (3, 1000)])
+def test_gpus_flag_starts_its_own_ranks(n, samples):
+    """The driver calls `python bench.py --gpus N`: with no launcher in the environment bench.py must start N ranks
+    itself.  Dry run (gloo, no GPU): the N ranks push the sharded step's collectives through the group with the real
+    shapes — padded row shards all-gathered into the table, 4 accumulators all-reduced per step — on closed-form
+    values that are checked exactly; rank 0's JSON line is the last line of the parent's stdout."""
+    r, lines = _run_bench(["--gpus", str(n), "--steps", "4", "--warmup", "1", "--samples", str(samples), "--shard", "rows"],
+                          {"NAQS_BENCH_DRY_RUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["dry_run"] and d["value"] is None and d["n_gpus"] == d["ranks"] == n and d["backend"] == "gloo"
+    assert d["table_ok"] and d["accumulators_ok"] and d["shard"] == "rows"
+    assert sum(1 for l in lines if l.lstrip().startswith("{")) == 1        # only rank 0 reports
+
+
+def test_under_a_launcher_no_second_launch():
+    """torchrun convention: WORLD_SIZE/RANK in the environment -> this process IS a rank, nothing is spawned."""
+    r, lines = _run_bench(["--gpus", "1", "--steps", "2", "--samples", "64"],
+                          {"NAQS_BENCH_DRY_RUN": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(lines[-1])["ranks"] == 1
+
+
+def test_a_failing_rank_fails_the_launch():
+    r, lines = _run_bench(["--gpus", "2", "--steps", "2", "--samples", "64", "--molecule", "no-such-molecule"], {}, timeout=600)
+    assert r.returncode != 0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--pipeline", "1"]])
+def test_row_sharded_table_through_rccl_on_one_gpu():
+    """BASELINE config 4 as one rank: Li2O, ONE table of 50 000 keys, the sharded step with its collectives issued
+    through an RCCL group of size 1 (all-gather of the log-psi table, all-reduce of the accumulators)."""
+    r, lines = _run_bench(["--gpus", "1", "--shard", "rows", "--molecule", "Li2O", "--samples", "50000", "--steps", "20",
+                           "--warmup", "3", "--no-cpu-baseline"], {"NAQS_BENCH_FORCE_DIST": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert REQUIRED <= set(d) and d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 1e6
+    assert "1 RCCL rank(s)" in d["config"]["ranks"] and d["config"]["rows_per_rank"] == 50000
+    assert np.isfinite(d["config"]["energy"]) and "all-gather" in d["config"]["collectives_per_step"]
+
+
+@pytest.mark.gpu
+def test_default_line_is_measured_in_this_run():
+    """serial figures and the config-4 table are measured by the same process, nothing is replayed from a file except
+    the hardware-counter fields, which say so."""
+    r, lines = _run_bench(["--gpus", "1", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], {}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["serial"]["measured"].startswith("this run") and "source" not in d["serial"]
+    assert d["serial"]["ms_per_step"] > 0 and d["roofline"]["isolated"]["kernel_us"] > 0
+    c4 = d["config4_row_sharded"]
+    assert "error" not in c4 and c4["scaling"] == "strong" and c4["value"] > 1e6 and "Li2O" in c4["workload"]
+    for roof in [d["roofline"]] + d["roofline"]["other_kernels"]:
+        if roof.get("traffic") is not None:
+            assert roof["traffic_source"]["replayed"] is True
+        if "issue" in roof:
+            assert roof["issue"]["replayed"] is True and 0 < roof["issue"]["frac"] <= 1.0
+    assert "4 distinct key sets" in d["config"]["batches"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--no-config4"], ["--pipeline", "1", "--no-config4"]])
 def test_bench_prints_one_json_line_last(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

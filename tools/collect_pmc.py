@@ -1,41 +1,66 @@
 #!/usr/bin/env python3
-"""Post-process rocprofv3 PMC passes into profiles/<tag>_pmc_traffic.json.
+"""Post-process rocprofv3 PMC passes into the counter summaries bench.py reads.
 
-Collect on the GPU box (separate passes, as MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE do
-not fit one pass; never combined with sys/hip traces):
+Collect on the GPU box (separate passes, as MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE do not fit
+one pass; never combined with sys/hip traces; the program itself directly after `--`):
 
-    cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline
+    cd /tmp && export TMPDIR=/tmp        # R = the repo
+    B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --pipeline 1"
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- $B
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o bench -- $B
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES \
+              GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_issue_n2 -o bench -- $B
+    (the same issue pass with `--shard rows --molecule Li2O --samples 50000` -> pmc_issue_li2o)
 
-then `python tools/collect_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json`.
+then
+    python tools/collect_pmc.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_traffic.json
+    python tools/collect_pmc.py issue gpurun_out/pmc_issue_n2 N2_10000 profiles/r02_pmc_issue.json
+    python tools/collect_pmc.py issue gpurun_out/pmc_issue_li2o Li2O_50000 profiles/r02_pmc_issue.json
 
-Units/corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports
-exactly half of the bytes of a wide (16 B/lane) coalesced stream -> doubled for the streaming kernel
-(phase_kernel: 16-byte weight loads); other access widths are uncalibrated and reported as counted.
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide (16 B/lane) coalesced stream -> doubled for the streaming kernel (phase_kernel:
+16-byte weight loads); other access widths are uncalibrated and reported as counted.  SQ_* instruction counters
+are wave-level instruction counts summed over the chip; GRBM_GUI_ACTIVE / kernel duration = the clock the pass ran at.
 """
 import collections
 import csv
+import glob
 import json
+import os
 import sys
+
+SHORT = ("phase_kernel", "eloc_kernel", "amp_kernel", "prep_kernel", "reduce_kernel")
+
+
+def short_name(name):
+    for s in SHORT:
+        if s in name:
+            return s
+    return None
+
+
+def rows_of(path):
+    files = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no *counter_collection.csv under {path}")
+    for fn in files:
+        with open(fn) as f:
+            yield from csv.DictReader(f)
 
 
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
-    with open(path + "/bench_counter_collection.csv") as f:
-        for r in csv.DictReader(f):
-            if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for r in rows_of(path):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items() if len(v) >= 10}
 
 
-def main(fetch_dir, write_dir, out):
+def traffic(fetch_dir, write_dir, out):
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     res = {}
     for name in sorted(set(fetch) | set(write)):
-        short = "phase_kernel" if "phase_kernel" in name else "eloc_kernel" if "eloc_kernel" in name else \
-            "amp_kernel" if "amp_kernel" in name else "prep_kernel" if "prep_kernel" in name else \
-            "reduce_kernel" if "reduce_kernel" in name else None
+        short = short_name(name)
         if short is None:
             continue
         f_kib, w_kib = fetch.get(name, 0.0), write.get(name, 0.0)
@@ -47,5 +72,40 @@ def main(fetch_dir, write_dir, out):
     print(json.dumps(res, indent=1))
 
 
+def issue(path, workload_key, out):
+    """Per launch of each kernel: mean of every counter over the dispatches, the dispatch duration, and the clock."""
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(dict)
+    for r in rows_of(path):
+        short = short_name(r["Kernel_Name"])
+        if short is None:
+            continue
+        vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[short][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3      # us
+    res = {}
+    for short, counters in vals.items():
+        d = sorted(dur[short].values())
+        entry = {k: sum(v) / len(v) for k, v in counters.items()}
+        entry["launches"] = len(d)
+        entry["kernel_us"] = sum(d) / len(d)
+        if "GRBM_GUI_ACTIVE" in entry and entry["kernel_us"] > 0:
+            entry["effective_clock_hz"] = entry["GRBM_GUI_ACTIVE"] / (entry["kernel_us"] * 1e-6)
+        res[short] = entry
+    try:
+        with open(out) as f:
+            allres = json.load(f)
+    except (OSError, ValueError):
+        allres = {}
+    allres[workload_key] = res
+    with open(out, "w") as f:
+        json.dump(allres, f, indent=1, sort_keys=True)
+    print(json.dumps({workload_key: res}, indent=1))
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    if sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:5])
+    elif sys.argv[1] == "issue":
+        issue(*sys.argv[2:5])
+    else:
+        raise SystemExit(__doc__)
