@@ -721,6 +721,7 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
             __builtin_amdgcn_sched_barrier(0);
             amp_mfma_item<CT>(d, f1, n, ab, lane, hs, outs);
         }
+        if (clk != nullptr && blockIdx.x == 0 && lane == 0 && q - q0 < 4) clk[wave * 16 + 11 + (q - q0)] = clock64();
     }
     if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 8] = clock64();
     __syncthreads();
@@ -733,6 +734,7 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
         const int occ = (int)((ab >> n) & 1u) + 2 * (int)((ab >> (16 + n)) & 1u);
         s_lan[n][r] = naqs::amp_finish(d, n, o, ab & mask, (ab >> 16) & mask, occ);
     }
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 15] = clock64();
     __syncthreads();
 }
 
@@ -1218,7 +1220,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         (void)hipFree(clk_dev);
         for (int wv = 0; wv < 8; ++wv) {
             std::fprintf(stderr, "[naqs clocks] wave %d:", wv);
-            for (int k = 1; k < 11; ++k) std::fprintf(stderr, " %lld", h[wv * 16 + k] ? h[wv * 16 + k] - h[wv * 16] : 0ll);
+            for (int k = 1; k < 16; ++k) std::fprintf(stderr, " %lld", h[wv * 16 + k] ? h[wv * 16 + k] - h[wv * 16] : 0ll);
             std::fprintf(stderr, "\n");
         }
     }

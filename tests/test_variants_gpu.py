@@ -86,7 +86,14 @@ def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
     assert abs(E - float(z["sgd_E"])) < 2e-5 * max(1, abs(E))
     assert abs(var - float(z["sgd_Var"])) < 1e-3 * max(1, abs(var))
     for name, p in wf.model.named_parameters():
-        assert np.max(np.abs(p.detach().cpu().numpy() - z["sd_after:" + name])) < 2e-5, name
+        d = np.abs(p.detach().cpu().numpy() - z["sd_after:" + name])
+        # the first Adam step moves every parameter by lr * sign(g) (eps = 1e-15): where the reference's gradient is
+        # itself rounding noise (|g| < 1e-4 of the tensor's gradient scale) the sign — hence a 2 lr difference — is not
+        # determined; everywhere else the parameters agree to 2e-5
+        g = np.abs(z["grad:" + name])
+        noise = g <= 1e-4 * max(g.max(), 1e-30)
+        assert d[~noise].max(initial=0.0) < 2e-5, name
+        assert d[noise].max(initial=0.0) < 2.1e-3 and noise.mean() < 2e-3, (name, noise.mean())
 
 
 @pytest.mark.parametrize("fix", ["LiH_aggphase", "N2_aggphase"])

@@ -1,0 +1,42 @@
+"""The optimiser's own training loop (PartialSamplingOptimizer.run) on one GPU, timed; run it under
+`rocprofv3 --kernel-trace --stats` for the per-kernel launch list of a VMC step.
+usage: python tools/train_loop_profile.py [molecule npz] [n_samples] [steps] [warmup]"""
+import os, sys, time, io, contextlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "naqs-for-quantum-chemistry_amd")]
+import numpy as np, torch
+from naqs_amd.hilbert import Encoding, Hilbert
+from naqs_amd.nade import NadeMasking
+from naqs_amd.optimizer import PartialSamplingOptimizer
+from naqs_amd.system import load_molecule, set_global_seed
+
+from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+mol_f = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/ham_N2.npz")
+n_samples = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1000000
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+warmup = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+dev = torch.device("cuda", 0)
+with contextlib.redirect_stdout(io.StringIO()):
+    set_global_seed(1)
+    mol, qh = load_molecule(mol_f)
+na, nb = mol.get_n_alpha_electrons(), mol.get_n_beta_electrons()
+hil = Hilbert.get(N=mol.n_qubits, N_alpha=na, N_beta=nb, encoding=Encoding.SIGNED)
+wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, amp_hidden_size=[64],
+                               phase_hidden_size=[512, 512], use_amp_spin_sym=True, use_phase_spin_sym=False,
+                               aggregate_phase=False, n_alpha_electrons=na, n_beta_electrons=nb, device=dev)
+opt = PartialSamplingOptimizer(n_samples=n_samples, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5,
+                               wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False, n_electrons=mol.n_electrons,
+                               n_alpha_electrons=na, n_beta_electrons=nb, optimizer=torch.optim.Adam,
+                               optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'eps': 1e-15}, {'lr': 1e-2}],
+                               save_loc="/tmp/train_loop_profile", seed=1, grad_clip_factor=None, log_exact_energy=False,
+                               pauli_hamiltonian_dtype=np.float64, normalise_psi=True)
+with contextlib.redirect_stdout(io.StringIO()):
+    opt.run(warmup, output_freq=10 ** 9)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+with contextlib.redirect_stdout(io.StringIO()):
+    opt.run(steps, output_freq=10 ** 9)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+from naqs_amd.optimizer import LogKey
+n_unq = opt.log[LogKey.N_UNIQUE_SAMP][-1][1]
+print(f"{os.path.basename(mol_f)}: {steps} steps, {dt / steps * 1e3:.3f} ms/step, {n_unq} unique samples in the last step, "
+      f"<E_loc> = {opt.log[LogKey.E_LOC][-1][1]:.6f}")
