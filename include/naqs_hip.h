@@ -241,6 +241,12 @@ int naqs_net_prof_stride(naqs_net_t *net, int stride);
 int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
                     int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream);
 
+/* naqs_net_sample that also writes the samples' weights counts / sum(counts) (float64 [max_unique]; the `weights`
+ * of PartialSamplingOptimizer.run, src/optimizer/energy.py:993) from the same final launch — the integer total is
+ * exact, so the weights do not depend on a summation order. */
+int naqs_net_sample_weighted(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                             int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream);
+
 /* ================================================================================================
  * Training-time amplitude network: forward and backward of log|psi| in two launches each.
  * The reference back-propagates 2 Re sum_i w_i log psi_i (E_loc_i - <E>)^* through PyTorch autograd
@@ -288,6 +294,11 @@ int naqs_net_phase_inputs(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, 
  * the reference: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>)).  eloc_dev [M][2] float64, w_dev [M] float64. */
 int naqs_vmc_loss_grad(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
                        void *stream);
+
+/* naqs_vmc_loss_grad that also writes ev_dev[2] = { <E> = sums[0]/sums[3], Var = sums[2]/sums[3] - <E>^2 } (float64), the
+ * two numbers _SGD_step returns (energy.py:372-375), from the same launch. */
+int naqs_vmc_loss_grad_ev(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
+                          double *ev_dev, void *stream);
 
 /* Host evaluation of the sampler's generators, for known-answer and statistical tests (no device needed):
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */

@@ -260,8 +260,13 @@ __global__ __launch_bounds__(256) void phase_inputs_kernel(const NetDims d, cons
 // arithmetic (energy.py:328-329 with complex.py:49-58): g = (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>))
 __global__ __launch_bounds__(256) void vmc_grad_kernel(const int64_t M, const double2 *__restrict__ eloc,
                                                        const double *__restrict__ w, const double *__restrict__ sums,
-                                                       float2 *__restrict__ g) {
+                                                       float2 *__restrict__ g, double *__restrict__ ev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ev != nullptr && i == 0) {                     // <E> and Var of energy.py:372-375 from the same accumulators
+        const double e_mean = sums[0] / sums[3];
+        ev[0] = e_mean;
+        ev[1] = sums[2] / sums[3] - e_mean * e_mean;
+    }
     if (i >= M) return;
     const float m_re = (float)sums[0], m_im = (float)sums[1];
     const double2 e = eloc[i];
@@ -318,14 +323,27 @@ NAQS_API int naqs_net_phase_inputs(naqs_net_t *net, int64_t M, const uint64_t *k
     return NAQS_OK;
 }
 
-NAQS_API int naqs_vmc_loss_grad(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
-                                void *stream) {
+static int vmc_loss_grad_impl(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
+                              double *ev_dev, void *stream) {
     if (M < 0 || (M > 0 && (!eloc_dev || !w_dev || !sums_dev || !g_dev))) return NAQS_ERR_INVALID;
-    if (M == 0) return NAQS_OK;
-    hipLaunchKernelGGL(vmc_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M,
-                       reinterpret_cast<const double2 *>(eloc_dev), w_dev, sums_dev, reinterpret_cast<float2 *>(g_dev));
+    if (M == 0 && ev_dev == nullptr) return NAQS_OK;
+    if (!sums_dev) return NAQS_ERR_INVALID;
+    hipLaunchKernelGGL(vmc_grad_kernel, dim3((unsigned)std::max<int64_t>(1, (M + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), M, reinterpret_cast<const double2 *>(eloc_dev), w_dev, sums_dev,
+                       reinterpret_cast<float2 *>(g_dev), ev_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
+}
+
+NAQS_API int naqs_vmc_loss_grad(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
+                                void *stream) {
+    return vmc_loss_grad_impl(M, eloc_dev, w_dev, sums_dev, g_dev, nullptr, stream);
+}
+
+NAQS_API int naqs_vmc_loss_grad_ev(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
+                                   double *ev_dev, void *stream) {
+    if (!ev_dev) return NAQS_ERR_INVALID;
+    return vmc_loss_grad_impl(M, eloc_dev, w_dev, sums_dev, g_dev, ev_dev, stream);
 }
 
 NAQS_API int naqs_net_amp_param_count(const naqs_net_t *net, int64_t *count) {

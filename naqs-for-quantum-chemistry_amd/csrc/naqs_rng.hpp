@@ -58,6 +58,21 @@ struct RngStream {
     }
 };
 
+// 1 / x for the generator's inner loops.  On the device a float64 division is a ~100-cycle dependent chain
+// (div_scale, rcp, five fmas, div_fmas, div_fixup) and these loops are latency-bound — one wave's draws are the critical
+// path of a whole tree level — so the reciprocal comes from v_rcp_f64 refined by two Newton steps (full double
+// accuracy for the well-scaled arguments that occur here: k + 1 >= 1, 1 - p >= 1/2, b >= 1.15, ...).
+NAQS_HD double rcp_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
 // log(k!) - [ (k + 1/2) log(k + 1) - (k + 1) + log(2 pi)/2 ]  (Stirling series remainder)
 NAQS_HD double stirling_tail(double k) {
     if (k < 10.0) {
@@ -74,13 +89,13 @@ NAQS_HD double stirling_tail(double k) {
             default: return 0.008330563433362871;
         }
     }
-    const double k1 = k + 1.0, s = k1 * k1;
-    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / s) / s) / k1;
+    const double r = rcp_fast(k + 1.0), r2 = r * r;      // (1/12 - (1/360 - 1/1260 / s) / s) / (k + 1), s = (k + 1)^2
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0) * r2) * r2) * r;
 }
 
 // Binomial(n, p), 0 < p <= 1/2, n p < 10: invert the CDF upwards from 0
 NAQS_HD double binomial_inversion(double n, double p, RngStream &g) {
-    const double s = p / (1.0 - p);
+    const double s = p * rcp_fast(1.0 - p);
     double u, v;
     g.pair(u, v);
     double f = exp(n * log1p(-p));          // P(0) = q^n >= e^-15 here
@@ -88,7 +103,7 @@ NAQS_HD double binomial_inversion(double n, double p, RngStream &g) {
     for (int it = 0; it < 400 && u > f && k < n; ++it) {
         u -= f;
         k += 1.0;
-        f *= s * (n - k + 1.0) / k;
+        f *= s * (n - k + 1.0) * rcp_fast(k);
     }
     return k;
 }
@@ -99,22 +114,30 @@ NAQS_HD double binomial_btrs(double n, double p, RngStream &g) {
     const double b = 1.15 + 2.53 * spq;
     const double a = -0.0873 + 0.0248 * b + 0.01 * p;
     const double c = n * p + 0.5;
-    const double vr = 0.92 - 4.2 / b;
-    const double alpha = (2.83 + 5.1 / b) * spq;
-    const double r = p / q;
+    const double rb = rcp_fast(b);
+    const double vr = 0.92 - 4.2 * rb;
     const double m = floor((n + 1.0) * p);
-    const double h_m = (m + 0.5) * log((m + 1.0) / (r * (n - m + 1.0))) + stirling_tail(m) + stirling_tail(n - m);
+    // constants of the exact acceptance test: only needed when a proposal falls outside the squeeze (~1 in 7), so they
+    // are formed on first use — a log, two Stirling tails and a division that most draws never pay for
+    bool have_slow = false;
+    double alpha = 0.0, r = 0.0, h_m = 0.0;
     for (int it = 0; it < 1000; ++it) {
         double u, v;
         g.pair(u, v);
         u -= 0.5;
         const double us = 0.5 - fabs(u);
-        const double k = floor((2.0 * a / us + b) * u + c);
+        const double k = floor((2.0 * a * rcp_fast(us) + b) * u + c);
         if (us >= 0.07 && v <= vr) return k;                      // inside the squeeze: accept immediately
         if (k < 0.0 || k > n) continue;
-        const double lv = log(v * alpha / (a / (us * us) + b));
-        const double ub = h_m + (n + 1.0) * log1p((k - m) / (n - k + 1.0)) +
-                          (k + 0.5) * log(r * (n - k + 1.0) / (k + 1.0)) - stirling_tail(k) - stirling_tail(n - k);
+        if (!have_slow) {
+            have_slow = true;
+            alpha = (2.83 + 5.1 * rb) * spq;
+            r = p * rcp_fast(q);
+            h_m = (m + 0.5) * log((m + 1.0) * rcp_fast(r * (n - m + 1.0))) + stirling_tail(m) + stirling_tail(n - m);
+        }
+        const double lv = log(v * alpha * rcp_fast(a * rcp_fast(us * us) + b));
+        const double ub = h_m + (n + 1.0) * log1p((k - m) * rcp_fast(n - k + 1.0)) +
+                          (k + 0.5) * log(r * (n - k + 1.0) * rcp_fast(k + 1.0)) - stirling_tail(k) - stirling_tail(n - k);
         if (lv <= ub) return k;
     }
     return m;                                                     // unreachable in practice (acceptance ~0.87 per pair)

@@ -315,20 +315,38 @@ __global__ __launch_bounds__(SB) void sample_scatter_kernel(const NetDims d, con
     }
 }
 
-__global__ void sample_finish_kernel(SampleBufs b, int P, int64_t *__restrict__ info) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int64_t overflow = b.U[MAXP + 1];
-        info[0] = overflow ? 0 : b.U[P];
+// M and the overflow flag for the host; optionally the samples' weights counts / sum(counts) (energy.py:993) — the
+// integer total is exact whatever the summation order, so the weights are deterministic
+constexpr int FIN_THREADS = 1024;
+__global__ __launch_bounds__(FIN_THREADS) void sample_finish_kernel(SampleBufs b, int P, int64_t *__restrict__ info,
+                                                                     const int64_t *__restrict__ counts,
+                                                                     double *__restrict__ weights) {
+    __shared__ int64_t s_part[FIN_THREADS / WAVE];
+    const int64_t overflow = b.U[MAXP + 1];
+    const int64_t M = overflow ? 0 : b.U[P];
+    if (threadIdx.x == 0) {
+        info[0] = M;
         info[1] = overflow;
     }
+    if (weights == nullptr) return;
+    int64_t part = 0;
+    for (int64_t i = threadIdx.x; i < M; i += FIN_THREADS) part += counts[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    int64_t total = 0;
+    for (int i = 0; i < FIN_THREADS / WAVE; ++i) total += s_part[i];
+    const double tot = (double)total;
+    for (int64_t i = threadIdx.x; i < M; i += FIN_THREADS) weights[i] = (double)counts[i] / tot;
 }
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
-                             int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream) {
+static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                           int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream) {
     if (!net || n_samples < 0 || max_unique <= 0 || !keys_dev || !counts_dev || !info_dev) return NAQS_ERR_INVALID;
     if (!net->have_amp_weights) return NAQS_ERR_INVALID;
     if (n_samples > (1ll << 44) || max_unique >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
@@ -396,9 +414,22 @@ NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, 
         HIP_TRY(hipGetLastError());
         bound = bound > cap ? bound : bound * 4;
     }
-    hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, s, b, d.P, info_dev);
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
+                       weights_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
+}
+
+NAQS_API int naqs_net_sample(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                             int64_t *counts_dev, float *probs_dev, int64_t *info_dev, void *stream) {
+    return net_sample_impl(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, nullptr, info_dev, stream);
+}
+
+NAQS_API int naqs_net_sample_weighted(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                                      int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev,
+                                      void *stream) {
+    if (!weights_dev) return NAQS_ERR_INVALID;
+    return net_sample_impl(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, info_dev, stream);
 }
 
 NAQS_API int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out) {

@@ -49,6 +49,7 @@ SIGNATURES = {
     "naqs_net_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_net_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "naqs_net_sample": (ctypes.c_int, [c_vp, c_i64, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_net_sample_weighted": (ctypes.c_int, [c_vp, c_i64, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_amp_param_count": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "naqs_net_set_amp_weights": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "naqs_net_logamp": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -60,6 +61,7 @@ SIGNATURES = {
                                       ctypes.c_double, ctypes.c_double, c_i64, c_vp]),
     "naqs_net_phase_inputs": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_loss_grad": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_vmc_loss_grad_ev": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_rng_binomial_host": (ctypes.c_int, [c_i64, ctypes.c_double, ctypes.c_uint64, c_i64, c_vp]),
     "naqs_rng_philox_host": (ctypes.c_int, [c_vp, c_vp, c_vp]),
 }

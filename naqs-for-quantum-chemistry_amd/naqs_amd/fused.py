@@ -175,10 +175,18 @@ class FusedLogPsi:
         _lib.check(st, "naqs_net_train_forward_eloc")
         return log_psi, (keys, None, None), eloc, sums
 
-    def vmc_loss_grad(self, e_loc, weights, sums):
-        """g [M, 2] float32 = d loss / d (log|psi|, phase) of the VMC loss (``naqs_vmc_loss_grad``)."""
+    def vmc_loss_grad(self, e_loc, weights, sums, with_energy=False):
+        """g [M, 2] float32 = d loss / d (log|psi|, phase) of the VMC loss (``naqs_vmc_loss_grad``); with
+        ``with_energy`` also the device pair (<E>, Var) of energy.py:372-375 from the same launch
+        (``naqs_vmc_loss_grad_ev``) -> (g, ev float64 [2])."""
         M = e_loc.shape[0]
         g = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+        if with_energy:
+            ev = torch.empty(2, dtype=torch.float64, device=self.device)
+            st = self._lib.naqs_vmc_loss_grad_ev(M, e_loc.data_ptr(), weights.data_ptr(), sums.data_ptr(), g.data_ptr(),
+                                                 ev.data_ptr(), _stream_ptr(self.device))
+            _lib.check(st, "naqs_vmc_loss_grad_ev")
+            return g, ev
         st = self._lib.naqs_vmc_loss_grad(M, e_loc.data_ptr(), weights.data_ptr(), sums.data_ptr(), g.data_ptr(),
                                           _stream_ptr(self.device))
         _lib.check(st, "naqs_vmc_loss_grad")
@@ -270,26 +278,36 @@ class FusedLogPsi:
         _lib.check(st, "naqs_logpsi_eloc")
         return (log_psi_out, eloc_out, sums_out) if weights is not None else (log_psi_out, eloc_out)
 
-    def sample(self, n_samples, seed, max_unique):
+    def sample(self, n_samples, seed, max_unique, with_weights=False):
         """Draw ``n_samples`` from |psi|^2 on the device (``naqs_net_sample``): -> (keys int64 [M] in qubit order,
-        counts int64 [M], probs float32 [M]), M unique bit-strings in (prefix, outcome) order.  Raises
-        ``MaxBatchSizeExceededError`` when more than ``max_unique`` prefixes are alive at some level
-        (nade.py:710-712).  One host synchronisation (to learn M)."""
+        counts int64 [M], probs float32 [M]), M unique bit-strings in (prefix, outcome) order; ``with_weights`` appends
+        the float64 weights counts / sum(counts) written by the sampler's last launch (``naqs_net_sample_weighted``).
+        Raises ``MaxBatchSizeExceededError`` when more than ``max_unique`` prefixes are alive at some level
+        (nade.py:710-712).  One host synchronisation (to learn M); the results are views of buffers allocated for
+        this call (no copies)."""
         from .nade import MaxBatchSizeExceededError
         cap = int(max_unique)
-        if self._samp is None or self._samp[0].shape[0] < cap:
-            self._samp = (torch.empty(cap, dtype=torch.int64, device=self.device),
-                          torch.empty(cap, dtype=torch.int64, device=self.device),
-                          torch.empty(cap, dtype=torch.float32, device=self.device),
-                          torch.empty(2, dtype=torch.int64, device=self.device))
-        keys, counts, probs, info = self._samp
-        st = self._lib.naqs_net_sample(self._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, keys.data_ptr(),
-                                       counts.data_ptr(), probs.data_ptr(), info.data_ptr(), _stream_ptr(self.device))
+        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+        counts = torch.empty(cap, dtype=torch.int64, device=self.device)
+        probs = torch.empty(cap, dtype=torch.float32, device=self.device)
+        if self._samp is None:
+            self._samp = torch.empty(2, dtype=torch.int64, device=self.device)
+        info = self._samp
+        if with_weights:
+            weights = torch.empty(cap, dtype=torch.float64, device=self.device)
+            st = self._lib.naqs_net_sample_weighted(self._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, keys.data_ptr(),
+                                                    counts.data_ptr(), probs.data_ptr(), weights.data_ptr(), info.data_ptr(),
+                                                    _stream_ptr(self.device))
+        else:
+            st = self._lib.naqs_net_sample(self._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, keys.data_ptr(),
+                                           counts.data_ptr(), probs.data_ptr(), info.data_ptr(), _stream_ptr(self.device))
         _lib.check(st, "naqs_net_sample")
         m, overflow = info.tolist()
         if overflow:
             raise MaxBatchSizeExceededError
-        return keys[:m].clone(), counts[:m].clone(), probs[:m].clone()
+        if with_weights:
+            return keys[:m], counts[:m], probs[:m], weights[:m]
+        return keys[:m], counts[:m], probs[:m]
 
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")

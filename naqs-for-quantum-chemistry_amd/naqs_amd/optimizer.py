@@ -360,15 +360,16 @@ class OptimizerBase:
             sums = ext[:4]
             shard_ok = (world * ext[5] == ext[4] * ext[4]) & (world * ext[7] == ext[6] * ext[6])
             self._shard_mismatch = (~shard_ok if self._shard_mismatch is None else self._shard_mismatch | ~shard_ok)
-        e_mean = torch.stack([sums[0], sums[1]])                        # (sum w E_loc), like energy.py:328 (w not renormalised)
-
         self.optimizer.zero_grad()
+        ev = None
         if saved is not None:
-            # d loss / d log psi of vmc_loss, written out: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>))
-            g = fused.vmc_loss_grad(e_loc, w[b:e_].contiguous(), sums)
+            # d loss / d log psi of vmc_loss, written out: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>)); the same launch
+            # leaves (<E>, Var) of energy.py:372-375 on the device
+            g, ev = fused.vmc_loss_grad(e_loc, w[b:e_].contiguous(), sums, with_energy=True)
             self._loss_terms, self._last_loss = (g, lp_mine), None
             fused.backward_saved(saved, g)
         else:
+            e_mean = torch.stack([sums[0], sums[1]])                    # (sum w E_loc), like energy.py:328 (w not renormalised)
             loss = vmc_loss(lp_mine, e_loc.to(lp_mine.dtype), w[b:e_].to(lp_mine.dtype), e_mean.to(lp_mine.dtype))
             if self.normalize_grads:
                 loss = loss / loss.detach().abs()
@@ -396,14 +397,16 @@ class OptimizerBase:
             self.scheduler.step()
 
         with torch.no_grad():                                           # energy.py:367-377
-            energy = sums[0] / sums[3]
-            variance = sums[2] / sums[3] - energy * energy
+            if ev is None:
+                energy = sums[0] / sums[3]
+                ev = torch.stack([energy, sums[2] / sums[3] - energy * energy])
             if shard_ok is not None:        # ranks that sampled different tables must not report a plausible energy
-                energy = torch.where(shard_ok, energy, torch.full_like(energy, float("nan")))
+                ev = torch.where(shard_ok, ev, torch.full_like(ev, float("nan")))
         if lazy:        # device scalars: the caller reads them later, so the host can queue the next step meanwhile
-            return torch.stack([energy, variance])
+            return ev
         self._check_shards()
-        return float(energy.item()), float(variance.item())
+        energy, variance = ev.tolist()
+        return float(energy), float(variance)
 
     # ---- checkpoints / logs: same keys as the reference (energy.py:400-538) ----
     def _fmt(self, fname):
@@ -488,14 +491,20 @@ class PartialSamplingOptimizer(OptimizerBase):
         if n_epochs:
             raise NotImplementedError("pre_flatten with n_epochs > 0 (unused: n_pretrain=0, experiments/run.py:14)")
 
-    def get_samples(self, last_action=0):
+    def get_samples(self, last_action=0, lazy=False):
         """Adaptive sample count (energy.py:936-971): x10 while too few unique samples, /10 when too many
-        or when the unique-prefix tree exceeds ``n_unq_samples_max``."""
+        or when the unique-prefix tree exceeds ``n_unq_samples_max``.  -> (states, counts, probs); the keys and the
+        weights counts / sum(counts) of the same draw are left in ``self._sample_keys`` / ``self._sample_weights``.
+        ``lazy`` (the training loop): states come back as ``LazyStates`` (built from the keys only if looked at)."""
         action = 0
+        if self.use_fused:
+            # one full re-pack of the parameters now (sampler, forward and backward all read it) instead of an
+            # amplitude-only one here and a full one before the forward pass
+            self.wavefunction.fused(need_phase=True)
         try:
-            states, counts, probs, self._sample_keys = self.wavefunction.sample(
+            states, counts, probs, self._sample_keys, self._sample_weights = self.wavefunction.sample(
                 self.n_samples, ret_log_psi=False, max_batch_size=self.n_unq_samples_max, generator=self.generator,
-                ret_keys=True)
+                ret_keys=True, lazy_states=lazy, ret_weights=True)
             n_unq, completed = len(states), True
         except MaxBatchSizeExceededError:
             print("MaxBatchSizeExceededError")
@@ -512,7 +521,7 @@ class PartialSamplingOptimizer(OptimizerBase):
                 print(f"\t...{n_unq} unique samples generated --> decreasing batch size to "
                       f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
         if action != 0:
-            return self.get_samples(action)
+            return self.get_samples(action, lazy=lazy)
         return states, counts, probs
 
     def solve_H(self, n_samps=None, ret_n_samps=True):
@@ -557,8 +566,8 @@ class PartialSamplingOptimizer(OptimizerBase):
             self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=False)
         for _ in range(n_epochs):
             t0 = time.time()
-            states, counts, probs = self.get_samples()
-            weights = counts.double() / counts.sum().double()                         # energy.py:993
+            states, counts, probs = self.get_samples(lazy=True)
+            weights = self._sample_weights                                            # counts / sum(counts), energy.py:993
             keys = self._sample_keys                                                  # = hilbert.state2idx(states)
             # <E>, Var stay on the device until they are printed or saved: reading them here would drain the queue
             # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU

@@ -19,6 +19,40 @@ from .nade import (InputEncoding, MaxBatchSizeExceededError, NadeMasking, Orbita
                    SoftmaxLogProbAmps)
 
 
+class LazyStates:
+    """The occupation strings of a batch of sampled keys, materialised on demand.  The training loop only needs the keys
+    (the fused kernels read occupations straight from the key bits); building the int8 [M, N] tensor the reference's
+    ``sample`` returns costs half a dozen launches per step, so it is deferred until somebody looks at it."""
+
+    def __init__(self, hilbert, keys):
+        self._hilbert, self._keys, self._states = hilbert, keys, None
+
+    def __len__(self):
+        return int(self._keys.shape[0])
+
+    @property
+    def shape(self):
+        return (len(self), self._hilbert.N)
+
+    def tensor(self):
+        if self._states is None:
+            self._states = self._hilbert.idx2state(self._keys)
+        return self._states
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return self._hilbert.idx2state(self._keys[idx])
+        return self.tensor()[idx]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):         # torch.*(lazy) sees the tensor
+        args = tuple(a.tensor() if isinstance(a, LazyStates) else a for a in args)
+        return func(*args, **(kwargs or {}))
+
+    def __getattr__(self, name):                                             # .to(), .numpy(), .dim() ...
+        return getattr(self.tensor(), name)
+
+
 class NAQSComplex_NADE_orbitals:
     _cplx_dtype = np.complex64
 
@@ -223,11 +257,13 @@ class NAQSComplex_NADE_orbitals:
         self._param_epoch += 1
 
     def sample(self, num_samples=1, ret_probs=True, ret_log_psi=True, ret_norm_reg=False, eval_mode=False,
-               max_batch_size=None, generator=None, use_fused=None, ret_keys=False):
+               max_batch_size=None, generator=None, use_fused=None, ret_keys=False, lazy_states=False, ret_weights=False):
         """wavefunction.py:488-521.  On a HIP device the draw is ``naqs_net_sample`` (one library call for the
         whole tree); ``use_fused=False`` selects the PyTorch formulation of the same sampler
         (``OrbitalNADE._forward_sample``, ``torch.binomial`` on the device), which is also what runs for
-        architectures outside the fused family.  ``ret_keys`` appends the int64 keys of the states."""
+        architectures outside the fused family.  ``ret_keys`` appends the int64 keys of the states, ``ret_weights`` the
+        float64 weights counts / sum(counts) (energy.py:993; from the sampler's own last launch on the fused path);
+        ``lazy_states`` returns the states as a ``LazyStates`` that builds the int8 tensor only when looked at."""
         if ret_norm_reg:
             raise NotImplementedError("ret_norm_reg")
         fused = self.fused(need_phase=False) if use_fused in (None, True) else None
@@ -250,8 +286,11 @@ class NAQSComplex_NADE_orbitals:
                 if self.model.masking is not NadeMasking.NONE and self.model.use_restricted_hilbert:
                     bound = min(bound, self.hilbert.size)
                 cap = int(min(bound, 2 ** 22))
-            keys, counts, probs = fused.sample(int(num_samples), seed, cap)
-            states = self.hilbert.idx2state(keys)
+            if ret_weights:
+                keys, counts, probs, weights = fused.sample(int(num_samples), seed, cap, with_weights=True)
+            else:
+                keys, counts, probs = fused.sample(int(num_samples), seed, cap)
+            states = LazyStates(self.hilbert, keys) if lazy_states else self.hilbert.idx2state(keys)
         else:
             was_training = self.model.training
             self.model.eval() if eval_mode else self.model.train()
@@ -272,6 +311,8 @@ class NAQSComplex_NADE_orbitals:
             out.append(lp.reshape(-1, 2))
         if ret_keys:
             out.append(keys if keys is not None else self.hilbert.state2idx(states).squeeze(-1).to(torch.int64))
+        if ret_weights:
+            out.append(weights if keys is not None else counts.double() / counts.sum().double())
         return out
 
     # ---- parameters (wavefunction.py:416-451)

@@ -20,7 +20,8 @@ then
 Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of a wide (16 B/lane) coalesced stream -> doubled for the streaming kernel (phase_kernel:
 16-byte weight loads); other access widths are uncalibrated and reported as counted.  SQ_* instruction counters
-are wave-level instruction counts summed over the chip; GRBM_GUI_ACTIVE / kernel duration = the clock the pass ran at.
+are wave-level instruction counts summed over the chip; SQ_BUSY_CYCLES / 32 shader engines = the kernel's duration in
+shader cycles (and, over its duration in microseconds, the clock the pass ran at).
 """
 import collections
 import csv
@@ -29,6 +30,7 @@ import json
 import os
 import sys
 
+N_SHADER_ENGINES = 32          # MI355X_MICROARCH.md, chip-level parameters
 SHORT = ("phase_kernel", "eloc_kernel", "amp_kernel", "prep_kernel", "reduce_kernel")
 
 
@@ -88,8 +90,14 @@ def issue(path, workload_key, out):
         entry = {k: sum(v) / len(v) for k, v in counters.items()}
         entry["launches"] = len(d)
         entry["kernel_us"] = sum(d) / len(d)
-        if "GRBM_GUI_ACTIVE" in entry and entry["kernel_us"] > 0:
-            entry["effective_clock_hz"] = entry["GRBM_GUI_ACTIVE"] / (entry["kernel_us"] * 1e-6)
+        if "SQ_BUSY_CYCLES" in entry and entry["kernel_us"] > 0:
+            # SQ_BUSY_CYCLES arrives summed over the chip's 32 shader engines (a one-workgroup kernel, busy on one of
+            # them, reports duration x clock once; a full-chip kernel 32 times): per-engine busy cycles = the kernel's
+            # duration in shader cycles.  (GRBM_GUI_ACTIVE also covers the dispatch overhead around the kernel's
+            # timestamps and is kept only as counted.)
+            entry["kernel_cycles"] = entry["SQ_BUSY_CYCLES"] / N_SHADER_ENGINES
+            if entry["launches"] and entry.get("SQ_WAVES", 0) >= 256:
+                entry["effective_clock_hz"] = entry["kernel_cycles"] / (entry["kernel_us"] * 1e-6)
         res[short] = entry
     try:
         with open(out) as f:
