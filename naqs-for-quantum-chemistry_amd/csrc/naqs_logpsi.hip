@@ -376,24 +376,31 @@ __device__ __forceinline__ void split3t_pair(float lo, float hi, uint32_t &w1, u
     w3 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), SEL);
 }
 
-template <int RB, int NC>
+// A1: the activations have a single non-zero plane (layer 0: the +-1 / 0 inputs are exact in bf16) -> three terms
+template <int RB, int NC, bool A1 = false>
 __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
                                                  const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
                                                  f32x4 (&acc)[RB][CBT]) {
     // a_ptr: this lane's row/k-group inside plane 0 of the activation tile; w_ptr: this lane's 8 weights of
     // column block 0, chunk 0, plane 0.  Chunks are 32 wide (one MFMA K).  (Register double buffering of the weight
     // fragments was tried: 96 VGPRs of fragments on top of the accumulators spill — 89 VGPRs to scratch, +20 us; the
-    // second wave of the SIMD is what hides the L2 latency here.)
+    // second wave of the SIMD is what hides the L2 latency here.  Also tried, round 2: fetching the fragments as two
+    // half-chunks so that each load has half a chunk of MFMAs to land in, with the next chunk's activation fragments
+    // prefetched from LDS — no faster (layer 1: 51.5k vs 49.7k cycles) and 58 VGPRs spilled around the loop: the loop
+    // already runs at ~88 % of what v_mfma_f32_16x16x32_bf16 sustains (2 waves x 72 MFMAs x ~19 cycles per chunk).)
+    constexpr int AP = A1 ? 1 : 3;
     for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
-        bf16x8 a[3][RB], b[3][NC];
+        bf16x8 a[AP][RB], b[3][NC];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 b[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + ((size_t)c * Kh_pad + k0) * 16);
+            if (p < AP) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                a[p][rb] = *reinterpret_cast<const bf16x8 *>(a_ptr + p * plane_stride + rb * 16 * ldh + k0);
+                for (int rb = 0; rb < RB; ++rb)
+                    a[p][rb] = *reinterpret_cast<const bf16x8 *>(a_ptr + p * plane_stride + rb * 16 * ldh + k0);
+            }
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -401,12 +408,18 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
             for (int c = 0; c < NC; ++c) {
                 f32x4 v = acc[rb][c];
                 // smallest terms first
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b[1][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][rb], b[0][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[2][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b[0][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[1][c], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[0][c], v, 0, 0, 0);
+                if (A1) {
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[2][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[1][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[0][c], v, 0, 0, 0);
+                } else {
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1 % AP][rb], b[1][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 % AP][rb], b[0][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[2][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1 % AP][rb], b[0][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[1][c], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[0][c], v, 0, 0, 0);
+                }
                 acc[rb][c] = v;
             }
     }
@@ -416,8 +429,9 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
 template <int RB, bool SAVE>
 __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int ldh, int Kh_pad, int N_pad,
                                             const ushort_t *__restrict__ W, const float *__restrict__ bias, bool last,
-                                            int wave, int lane, float *__restrict__ save = nullptr, int save_ld = 0,
-                                            int64_t row0 = 0, int64_t M = 0, long long *clk = nullptr) {
+                                            int wave, int lane, float *__restrict__ save, int save_ld,
+                                            int64_t row0, int64_t M, long long *clk,
+                                            bool in_plane0_only) {
     // save != nullptr (training forward): the post-ReLU activations of this hidden layer also go to HBM
     // ([M][save_ld] float32) for the backward pass
     constexpr int BM = RB * 16;
@@ -484,7 +498,13 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
 #pragma unroll
     for (int c = 0; c < CBT; ++c) bvs[c] = c < my_cb ? bias[tile_col(cb0 + c, m, N_pad)] : 0.0f;
     const ushort_t *w_ptr = W + (size_t)cb0 * Kh_pad * 16 + lane * 8;
-    if (my_cb == CBT) mlp_accumulate_h<RB, CBT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    if (my_cb == CBT) {
+        // (layer 0's fragments were also requested ahead, from the prologue, so that their first-touch latency would be
+        // off the critical path: the 48 registers they hold across the conditionals spill — layer 0 got 1.8k cycles
+        // shorter and the kernel 3.9k longer, A/B on one box)
+        if (in_plane0_only) mlp_accumulate_h<RB, CBT, true>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+        else mlp_accumulate_h<RB, CBT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    }
     else if (my_cb >= 4) mlp_accumulate_h<RB, (CBT > 4 ? 4 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 3) mlp_accumulate_h<RB, (CBT > 3 ? 3 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 2) mlp_accumulate_h<RB, (CBT > 2 ? 2 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
@@ -701,10 +721,6 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
             }
         }
         s_ab[tid] = a | (b << 16);
-        if (feed.tab != nullptr && i < M) {           // fused log-psi + E_loc call: narrow the key, build the hash table
-            if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, i, key);
-            else naqs::feed_key<uint64_t>(feed, i, key);
-        }
     }
     __syncthreads();
     if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 1] = clock64();
@@ -724,6 +740,15 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
         if (clk != nullptr && blockIdx.x == 0 && lane == 0 && q - q0 < 4) clk[wave * 16 + 11 + (q - q0)] = clock64();
     }
     if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 8] = clock64();
+    // fused log-psi + E_loc call: narrow the key and insert it into the E_loc hash table.  Done here, by the threads of
+    // the waves that got the fewest items (tid < BM: waves 0..), and not next to the key gather above: the insert is an
+    // atomicCAS round trip to L2 that nothing in this kernel waits for, and in front of the first barrier it delayed
+    // every wave's first item
+    if (tid < BM && feed.tab != nullptr && row0 + tid < M) {
+        const uint64_t key = keys[row0 + tid];
+        if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, row0 + tid, key);
+        else naqs::feed_key<uint64_t>(feed, row0 + tid, key);
+    }
     __syncthreads();
     for (int e = tid; e < P * BM; e += PH_THREADS) {
         const int n = e / BM, r = e - n * BM;
@@ -752,7 +777,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     __shared__ uint32_t s_ab[RB * 16];                 // model-order occupation strings of the tile's samples
     __shared__ float s_lan[MAXP][RB * 16];             // conditional log-amplitudes, pair-major
     constexpr int BM = RB * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int P = d.P, ldh = d.ldh;
 
@@ -773,35 +798,44 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     }
     NAQS_MARK(3);
 
-    // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero)
-    const int K0 = d.Kh_pad[0];
-    for (int e = tid; e < BM * K0; e += PH_THREADS) {
-        const int r = e / K0, k = e - r * K0;
+    // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero); one thread builds 8 consecutive inputs of a row
+    // and stores them as one 16-byte LDS write per plane (ldh and Kh_pad are multiples of 8)
+    const int K0 = d.Kh_pad[0], G0 = K0 >> 3;
+    for (int e = tid; e < BM * G0; e += PH_THREADS) {
+        const int r = e / G0, k8 = (e - r * G0) << 3;
         const int64_t i = row0 + r;
-        ushort_t v = 0;
-        if (i < M && k < 2 * (P - 1)) {
-            bool set;
-            if (wamp != nullptr) {                                              // occupation strings already gathered in LDS
-                const uint32_t ab = s_ab[r];
-                set = k < P - 1 ? ((ab >> k) & 1u) : ((ab >> (16 + k - (P - 1))) & 1u);
-            } else {
+        uint32_t pk[4] = {0u, 0u, 0u, 0u};
+        if (i < M && k8 < 2 * (P - 1)) {
+            uint32_t ab;
+            if (wamp != nullptr) ab = s_ab[r];                                  // occupation strings already gathered in LDS
+            else {
                 const uint64_t key = keys[i];
-                const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
-                set = (key >> q) & 1ull;
+                uint32_t a_ = 0, b_ = 0;
+                for (int k = 0; k < P; ++k) { a_ |= (uint32_t)((key >> d.qa[k]) & 1ull) << k; b_ |= (uint32_t)((key >> d.qb[k]) & 1ull) << k; }
+                ab = a_ | (b_ << 16);
             }
-            v = set ? (ushort_t)0x3F80 : (ushort_t)0xBF80;                      // +1.0 / -1.0
-            if (SAVE && save.x != nullptr) save.x[i * save.x_ld + k] = set ? 1.0f : -1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k8 + j;
+                if (k < 2 * (P - 1)) {
+                    const bool set = k < P - 1 ? ((ab >> k) & 1u) : ((ab >> (16 + k - (P - 1))) & 1u);
+                    pk[j >> 1] |= (set ? 0x3F80u : 0xBF80u) << (16 * (j & 1));  // +1.0 / -1.0
+                    if (SAVE && save.x != nullptr) save.x[i * save.x_ld + k] = set ? 1.0f : -1.0f;
+                }
+            }
         }
-        planes[r * ldh + k] = v;
-        planes[BM * ldh + r * ldh + k] = 0;
-        planes[2 * BM * ldh + r * ldh + k] = 0;
+        ushort_t *dst = planes + r * ldh + k8;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4 *>(dst + BM * ldh) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(dst + 2 * BM * ldh) = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
 
     NAQS_MARK(4);
     for (int l = 0; l < d.n_lin; ++l) {
         mlp_layer_h<RB, SAVE>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
-                        l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M, l == 0 ? save.clk : nullptr);
+                        l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M, l == 0 ? save.clk : nullptr,
+                        /*in_plane0_only=*/l == 0);
         NAQS_MARK(5 + l);
     }
 
