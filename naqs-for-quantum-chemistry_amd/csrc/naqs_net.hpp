@@ -159,6 +159,7 @@ struct naqs_net {
     int64_t cap_M = 0;
     void *d_samp = nullptr;                 // tree-sampler scratch (naqs_sample.hip), sized for samp_cap unique prefixes
     int64_t samp_cap = 0;
+    uint32_t samp_seq = 0;                  // sampling calls so far: tags the per-workgroup scan words of the fused level kernel
     int cu_count = 256;
     bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
     bool packed_f32 = false;                // the f32-MFMA weight tiles are current (only packed when phase_kernel will run)

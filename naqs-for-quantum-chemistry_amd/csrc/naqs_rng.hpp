@@ -108,39 +108,61 @@ NAQS_HD double binomial_inversion(double n, double p, RngStream &g) {
     return k;
 }
 
-// Binomial(n, p), 0 < p <= 1/2, n p >= 10 (BTRS)
-NAQS_HD double binomial_btrs(double n, double p, RngStream &g) {
-    const double q = 1.0 - p, spq = sqrt(n * p * q);
-    const double b = 1.15 + 2.53 * spq;
-    const double a = -0.0873 + 0.0248 * b + 0.01 * p;
-    const double c = n * p + 0.5;
-    const double rb = rcp_fast(b);
-    const double vr = 0.92 - 4.2 * rb;
-    const double m = floor((n + 1.0) * p);
+// Binomial(n, p), 0 < p <= 1/2, n p >= 10 (BTRS), split into set-up and ONE attempt so that the sequential host/
+// single-lane form below and the sampler's quad-parallel form (several attempts of one draw evaluated by neighbouring
+// lanes, the first accepted one in attempt order wins: naqs_sample.hip) run the same arithmetic.
+struct Btrs {
+    double n, p, spq, b, a, c, rb, vr, m;
     // constants of the exact acceptance test: only needed when a proposal falls outside the squeeze (~1 in 7), so they
     // are formed on first use — a log, two Stirling tails and a division that most draws never pay for
-    bool have_slow = false;
-    double alpha = 0.0, r = 0.0, h_m = 0.0;
-    for (int it = 0; it < 1000; ++it) {
-        double u, v;
-        g.pair(u, v);
-        u -= 0.5;
-        const double us = 0.5 - fabs(u);
-        const double k = floor((2.0 * a * rcp_fast(us) + b) * u + c);
-        if (us >= 0.07 && v <= vr) return k;                      // inside the squeeze: accept immediately
-        if (k < 0.0 || k > n) continue;
-        if (!have_slow) {
-            have_slow = true;
-            alpha = (2.83 + 5.1 * rb) * spq;
-            r = p * rcp_fast(q);
-            h_m = (m + 0.5) * log((m + 1.0) * rcp_fast(r * (n - m + 1.0))) + stirling_tail(m) + stirling_tail(n - m);
-        }
-        const double lv = log(v * alpha * rcp_fast(a * rcp_fast(us * us) + b));
-        const double ub = h_m + (n + 1.0) * log1p((k - m) * rcp_fast(n - k + 1.0)) +
-                          (k + 0.5) * log(r * (n - k + 1.0) * rcp_fast(k + 1.0)) - stirling_tail(k) - stirling_tail(n - k);
-        if (lv <= ub) return k;
+    bool have_slow;
+    double alpha, r, h_m;
+};
+
+NAQS_HD void btrs_setup(Btrs &t, double n, double p) {
+    const double q = 1.0 - p;
+    t.n = n; t.p = p;
+    t.spq = sqrt(n * p * q);
+    t.b = 1.15 + 2.53 * t.spq;
+    t.a = -0.0873 + 0.0248 * t.b + 0.01 * p;
+    t.c = n * p + 0.5;
+    t.rb = rcp_fast(t.b);
+    t.vr = 0.92 - 4.2 * t.rb;
+    t.m = floor((n + 1.0) * p);
+    t.have_slow = false;
+    t.alpha = t.r = t.h_m = 0.0;
+}
+
+// one proposal from the uniform pair (u, v): true and the variate in k when it is accepted
+NAQS_HD bool btrs_attempt(Btrs &t, double u, double v, double &k) {
+    u -= 0.5;
+    const double us = 0.5 - fabs(u);
+    k = floor((2.0 * t.a * rcp_fast(us) + t.b) * u + t.c);
+    if (us >= 0.07 && v <= t.vr) return true;                     // inside the squeeze: accept immediately
+    if (k < 0.0 || k > t.n) return false;
+    if (!t.have_slow) {
+        t.have_slow = true;
+        t.alpha = (2.83 + 5.1 * t.rb) * t.spq;
+        t.r = t.p * rcp_fast(1.0 - t.p);
+        t.h_m = (t.m + 0.5) * log((t.m + 1.0) * rcp_fast(t.r * (t.n - t.m + 1.0))) + stirling_tail(t.m) + stirling_tail(t.n - t.m);
     }
-    return m;                                                     // unreachable in practice (acceptance ~0.87 per pair)
+    const double lv = log(v * t.alpha * rcp_fast(t.a * rcp_fast(us * us) + t.b));
+    const double ub = t.h_m + (t.n + 1.0) * log1p((k - t.m) * rcp_fast(t.n - k + 1.0)) +
+                      (k + 0.5) * log(t.r * (t.n - k + 1.0) * rcp_fast(k + 1.0)) - stirling_tail(k) - stirling_tail(t.n - k);
+    return lv <= ub;
+}
+
+constexpr int BTRS_MAX_ATTEMPTS = 1000;                           // unreachable in practice (acceptance ~0.87 per pair)
+
+NAQS_HD double binomial_btrs(double n, double p, RngStream &g) {
+    Btrs t;
+    btrs_setup(t, n, p);
+    for (int it = 0; it < BTRS_MAX_ATTEMPTS; ++it) {
+        double u, v, k;
+        g.pair(u, v);
+        if (btrs_attempt(t, u, v, k)) return k;
+    }
+    return t.m;
 }
 
 NAQS_HD int64_t binomial(int64_t n, double p, RngStream &g) {

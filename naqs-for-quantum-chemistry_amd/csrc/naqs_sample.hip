@@ -48,6 +48,7 @@ struct SampleBufs {
     int64_t *child_cnt;                     // [cap][4]
     float *child_prob;                      // [cap][4]
     uint32_t *wg_total;                     // survivors per workgroup of the current level
+    unsigned long long *wg_state;           // fused level kernel: (tag << 32 | survivors) per workgroup, never cleared
     int64_t *U;
 };
 
@@ -68,8 +69,54 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// One prefix, one quad of lanes (q = lane & 3): the hidden units of block n are split four ways, then lanes 0/1 draw the
-// two independent second-level binomials of the multinomial split in parallel.  Weights of pair n are in s_w (staged and
+// Binomial(n, p) drawn by a group of G consecutive lanes (G = 4: a quad, G = 2: half of one).  The lanes of a group pass
+// the same arguments and all return the same variate — the one naqs::binomial() returns for the stream (k0, k1, c0, c1).
+// What the group buys is latency: a tree level lasts as long as its slowest wave, and a wave's BTRS rejection loop as
+// long as its unluckiest lane (~3 rounds of 16-32 concurrent draws, each round through the log-heavy exact test).
+// Here lane j of the group evaluates attempt round * G + j of the SAME draw and the first accepted attempt in attempt
+// order wins, so a draw needs a second round with probability 0.13^G instead of 0.13.  Must be called by all 64 lanes
+// (wave-uniform control flow: it votes and shuffles); lanes with nothing to draw pass need = false.
+template <int G>
+__device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, const double p, const uint32_t k0,
+                                                  const uint32_t k1, const uint32_t c0, const uint32_t c1) {
+    const int lane = threadIdx.x & 63, j = lane & (G - 1), base = lane & ~(G - 1);
+    int64_t fixed = 0;
+    if (need && (n <= 0 || !(p > 0.0))) need = false;
+    if (need && p >= 1.0) { fixed = n; need = false; }
+    const bool flip = p > 0.5;
+    const double pp = flip ? 1.0 - p : p, nd = (double)n;
+    const bool inv = need && nd * pp < 10.0, bt = need && !inv;
+    double k = 0.0;
+    if (inv) {                                                  // short sequential search: every lane of the group runs it
+        naqs::RngStream g{k0, k1, c0, c1, 0u, 0u};
+        k = naqs::binomial_inversion(nd, pp, g);
+    }
+    naqs::Btrs t;
+    if (bt) naqs::btrs_setup(t, nd, pp);
+    bool pending = bt;
+    for (int round = 0; round < naqs::BTRS_MAX_ATTEMPTS / G && __ballot(pending) != 0ull; ++round) {
+        bool acc = false;
+        double kk = 0.0;
+        if (pending) {
+            naqs::RngStream g{k0, k1, c0, c1, 0u, (uint32_t)(round * G + j)};
+            double u, v;
+            g.pair(u, v);
+            acc = naqs::btrs_attempt(t, u, v, kk);
+        }
+        const unsigned long long votes = __ballot(acc);
+        const uint32_t mine = (uint32_t)(votes >> base) & ((1u << G) - 1u);
+        const double kw = __shfl(kk, base + (mine ? __builtin_ctz(mine) : 0), 64);
+        if (pending && mine) { k = kw; pending = false; }
+    }
+    if (pending) k = t.m;                                       // unreachable in practice
+    if (!need) return fixed;
+    int64_t ki = (int64_t)k;
+    ki = ki < 0 ? 0 : (ki > n ? n : ki);
+    return flip ? n - ki : ki;
+}
+
+// One prefix, one quad of lanes (q = lane & 3): the hidden units of block n are split four ways, then the quad draws the
+// first-level binomial of the multinomial split together and its two halves the two independent second-level ones.  Weights of pair n are in s_w (staged and
 // synchronised by the caller).  On return lane q == 0 holds the children counts (un-physical ones zeroed, nade.py:695)
 // and the float32 conditional probabilities p[c] = exp(log-amp)^2 (nade.py:673).
 __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
@@ -108,21 +155,18 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
     // nade.py:31-35, two dependent rounds instead of three; the float64 renormalisation of :682-683 cancels in the
     // ratios): first {2,3} against {0,1}, then 1 within {0,1} and 3 within {2,3}
     const double p01 = (double)p[0] + (double)p[1], p23 = (double)p[2] + (double)p[3], tot = p01 + p23;
-    int64_t n23 = 0;
-    if (q == 0 && tot > 0.0) {
-        naqs::RngStream g{k0, k1, ab, (uint32_t)n | (1u << 8), 0u, 0u};
-        n23 = naqs::binomial(cnt, fmin(1.0, p23 / tot), g);
-    }
-    n23 = __shfl(n23, (int)(threadIdx.x & 63) & ~3, 64);
+    // first split by the whole quad (four attempts per round), then lanes {0,1} draw outcome 1 within {0,1} and lanes
+    // {2,3} outcome 3 within {2,3} (two attempts per round each); every lane of a group ends up with the group's variate
+    const int64_t n23 = binomial_group<4>(tot > 0.0, cnt, fmin(1.0, p23 / tot), k0, k1, ab, (uint32_t)n | (1u << 8));
     const int64_t n01 = tot > 0.0 ? cnt - n23 : 0;
-    int64_t hi = 0;                              // lane 0: outcome 1 out of {0,1}; lane 1: outcome 3 out of {2,3}
-    if (q < 2) {
-        const int64_t m = q == 0 ? n01 : n23;
-        const double den = q == 0 ? p01 : p23, num = q == 0 ? (double)p[1] : (double)p[3];
-        naqs::RngStream g{k0, k1, ab, (uint32_t)n | ((uint32_t)(2 + q) << 8), 0u, 0u};
-        hi = den > 0.0 ? naqs::binomial(m, fmin(1.0, num / den), g) : 0;
-    }
-    const int64_t n3 = __shfl(hi, ((int)(threadIdx.x & 63) & ~3) + 1, 64);
+    const int sub = q >> 1;
+    const int64_t m_sub = sub == 0 ? n01 : n23;
+    const double den = sub == 0 ? p01 : p23, num = sub == 0 ? (double)p[1] : (double)p[3];
+    const int64_t hi_sub = binomial_group<2>(den > 0.0, m_sub, fmin(1.0, num / den), k0, k1, ab,
+                                             (uint32_t)n | ((uint32_t)(2 + sub) << 8));
+    const int quad0 = (int)(threadIdx.x & 63) & ~3;
+    const int64_t hi = __shfl(hi_sub, quad0, 64);
+    const int64_t n3 = __shfl(hi_sub, quad0 + 2, 64);
     out[0] = n01 - hi; out[1] = hi; out[2] = n23 - n3; out[3] = n3;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -176,54 +220,164 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
     }
 }
 
-// The first HEAD_LEVELS levels of the tree in ONE launch: level n has at most 4^n <= 64 prefixes there, so a single
-// workgroup (a quad of lanes per prefix) expands, compacts in LDS and moves on — these levels are pure latency
-// (~30 us each as separate expand + scatter launches whatever their size).  Leaves the level-HEAD_LEVELS prefixes
-// (<= 256) in the global ping-pong arrays where the per-level kernels continue.
-constexpr int HEAD_LEVELS = 4;
-__global__ __launch_bounds__(SB) void sample_head_kernel(const NetDims d, const float *__restrict__ w, const SampleBufs b,
-                                                         const int64_t n_samples, const uint32_t k0, const uint32_t k1) {
+// One tree level in ONE launch (expand + compaction): as sample_expand_kernel, then instead of leaving the children
+// counts for sample_scatter_kernel the workgroup finds its place in the next level itself.  Its survivors count goes
+// out as one 8-byte word (tag << 32 | count, a relaxed agent-scope store: flag and value travel in the same naturally
+// aligned granule, so no fence is needed) and the sum over the preceding workgroups comes from polling their words
+// (relaxed agent-scope loads, which bypass this CU's L1) — "decoupled look-back" over the aggregates.  The tag is
+// (sampling call, level), so the words are never cleared.  Forward progress: a workgroup only waits for workgroups
+// with LOWER indices, which the dispatcher starts no later than itself.  Children are written straight to the other
+// half of the ping-pong arrays (or, on the last level, to the caller's outputs) in (prefix, outcome) order: the same
+// positions sample_scatter_kernel assigns, bit-identical results.
+__global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const float *__restrict__ w, const int n,
+                                                          const SampleBufs b, const int cur, const uint32_t k0,
+                                                          const uint32_t k1, const uint32_t tag, const int64_t cap,
+                                                          const int last, uint64_t *__restrict__ keys_out,
+                                                          int64_t *__restrict__ counts_out, float *__restrict__ probs_out) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
-    __shared__ uint32_t s_ab[2][EXP_PARENTS];
-    __shared__ int64_t s_cnt[2][EXP_PARENTS];
-    __shared__ float s_prob[2][EXP_PARENTS];
-    __shared__ int s_surv[EXP_PARENTS], s_pos[EXP_PARENTS + 1];
-    const int tid = threadIdx.x, u = tid >> 2, q = tid & 3;
+    __shared__ uint32_t s_wave[SB / WAVE];
+    __shared__ long long s_base;
+    const int64_t U = b.U[n];
+    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
+    const int64_t nwg = (U + EXP_PARENTS - 1) / EXP_PARENTS;
+    stage_pair_weights(d, w, n, s_w, SB);
+    const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
+    const bool active = u < U;
+    const uint32_t ab = active ? b.ab[cur][u] : 0u;
+    const int64_t cnt = active ? b.cnt[cur][u] : 0;
+    const float pr = active ? b.prob[cur][u] : 0.0f;
+    __syncthreads();
+    int64_t out[4];
+    float p[4];
+    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool owner = active && (threadIdx.x & 3) == 0;
+    uint32_t mine = 0;
+    if (owner)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mine += out[c] > 0 ? 1u : 0u;
+    // inclusive scan of `mine` over the workgroup (only quad owners contribute)
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SB / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&b.wg_state[blockIdx.x], ((unsigned long long)tag << 32) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        // look back: lanes poll the words of the preceding workgroups, 64 at a time
+        long long part = 0;
+        for (int64_t j0 = 0; j0 < (int64_t)blockIdx.x; j0 += WAVE) {
+            const int64_t j = j0 + lane;
+            if (j < (int64_t)blockIdx.x) {
+                unsigned long long v;
+                do {
+                    v = __hip_atomic_load(&b.wg_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 32) != tag) __builtin_amdgcn_s_sleep(1);
+                } while ((uint32_t)(v >> 32) != tag);
+                part += (long long)(uint32_t)v;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+        if (lane == 0) s_base = part;
+    }
+    __syncthreads();
+    const int64_t base = s_base;
+    int64_t pos = base + before + (incl - mine);
+    if (owner && mine) {
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (out[c] > 0) {
+                if (pos < cap) {
+                    const uint32_t child = ab | ((uint32_t)(c & 1) << n) | ((uint32_t)(c >> 1) << (16 + n));
+                    const float prc = pr * p[c];
+                    if (last) {
+                        uint64_t key = 0;
+                        for (int k = 0; k < d.P; ++k) {
+                            key |= (uint64_t)((child >> k) & 1u) << d.qa[k];
+                            key |= (uint64_t)((child >> (16 + k)) & 1u) << d.qb[k];
+                        }
+                        keys_out[pos] = key;
+                        counts_out[pos] = out[c];
+                        if (probs_out) probs_out[pos] = prc;
+                    } else {
+                        b.ab[nxt][pos] = child;
+                        b.cnt[nxt][pos] = out[c];
+                        b.prob[nxt][pos] = prc;
+                    }
+                }
+                ++pos;
+            }
+        }
+    }
+    if ((int64_t)blockIdx.x == nwg - 1 && threadIdx.x == 0) {
+        const int64_t all = base + total;
+        b.U[n + 1] = all < cap ? all : cap;
+        if (all > cap) b.U[MAXP + 1] = 1;
+    }
+}
+
+// The first HL levels of the tree in ONE launch: level n has at most 4^n <= HT / 4 prefixes there, so a single
+// workgroup of HT threads (a quad of lanes per prefix) expands, compacts in LDS and moves on — these levels are pure
+// latency (~30 us each as separate expand + scatter launches whatever their size).  Leaves the level-HL prefixes
+// (<= HT) in the global ping-pong arrays where the per-level kernels continue.  HT = 1024 keeps five levels in the
+// launch, HT = 256 four (small max_unique).
+template <int HT, int HL>
+__global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const float *__restrict__ w, const SampleBufs b,
+                                                         const int64_t n_samples, const uint32_t k0, const uint32_t k1) {
+    constexpr int HP = HT / 4;                             // prefixes the workgroup can hold
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    __shared__ uint32_t s_ab[2][HP];
+    __shared__ int64_t s_cnt[2][HP];
+    __shared__ float s_prob[2][HP];
+    __shared__ uint32_t s_wave[HT / WAVE];
+    const int tid = threadIdx.x, u = tid >> 2, q = tid & 3, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         for (int i = 0; i < MAXP + 2; ++i) b.U[i] = 0;
         b.U[0] = 1;
         s_ab[0][0] = 0u; s_cnt[0][0] = n_samples; s_prob[0][0] = 1.0f;
     }
     int U = 1;
-    for (int n = 0; n < HEAD_LEVELS; ++n) {
+    for (int n = 0; n < HL; ++n) {
         const int cur = n & 1, nxt = cur ^ 1;
         __syncthreads();                                   // previous level's LDS writes / everyone done with s_w
-        stage_pair_weights(d, w, n, s_w, SB);
+        stage_pair_weights(d, w, n, s_w, HT);
         const bool active = u < U;
         const uint32_t ab = active ? s_ab[cur][u] : 0u;
         const int64_t cnt = active ? s_cnt[cur][u] : 0;
+        const float pr = active ? s_prob[cur][u] : 0.0f;
         __syncthreads();
         int64_t out[4];
         float p[4];
         expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
-        if (q == 0) {
-            int sv = 0;
-            if (active)
-                for (int c = 0; c < 4; ++c) sv += out[c] > 0 ? 1 : 0;
-            s_surv[u] = sv;
+        uint32_t mine = 0;                                 // survivors of this quad's prefix, held by its first lane
+        if (active && q == 0)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine += out[c] > 0 ? 1u : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
         }
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        if (tid == 0) {                                    // <= 64 entries: a serial scan is a few hundred cycles
-            int run = 0;
-            for (int i = 0; i < EXP_PARENTS; ++i) { s_pos[i] = run; run += s_surv[i]; }
-            s_pos[EXP_PARENTS] = run;
-        }
-        __syncthreads();
-        const int total = s_pos[EXP_PARENTS];
-        const bool to_global = n + 1 == HEAD_LEVELS;       // the last head level feeds the per-level kernels
-        if (active && q == 0) {
-            int pos = s_pos[u];
-            const float pr = s_prob[cur][u];
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < HT / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
+        const bool to_global = n + 1 == HL;                // the last head level feeds the per-level kernels
+        if (mine) {
+            int pos = (int)(before + (incl - mine));
+#pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (out[c] > 0) {
                     const uint32_t child = ab | ((uint32_t)(c & 1) << n) | ((uint32_t)(c >> 1) << (16 + n));
@@ -236,7 +390,7 @@ __global__ __launch_bounds__(SB) void sample_head_kernel(const NetDims d, const 
                 }
             }
         }
-        U = total;
+        U = (int)total;
         if (tid == 0) b.U[n + 1] = total;
     }
 }
@@ -367,13 +521,16 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const size_t o_cc = off; off = align_up(off + (size_t)cap * 4 * sizeof(int64_t));
     const size_t o_cp = off; off = align_up(off + (size_t)cap * 4 * sizeof(float));
     const size_t o_wg = off; off = align_up(off + (size_t)nwg_cap * sizeof(uint32_t));
+    const size_t o_ws = off; off = align_up(off + (size_t)nwg_cap * sizeof(unsigned long long));
     const size_t o_U = off; off = align_up(off + (size_t)U_SLOTS * sizeof(int64_t));
     if (cap > net->samp_cap) {
         HIP_TRY(hipDeviceSynchronize());
         if (net->d_samp) (void)hipFree(net->d_samp);
         net->d_samp = nullptr; net->samp_cap = 0;
         HIP_TRY(hipMalloc(&net->d_samp, off));
+        HIP_TRY(hipMemset(static_cast<char *>(net->d_samp) + o_ws, 0, (size_t)nwg_cap * sizeof(unsigned long long)));   // tag 0 = never written
         net->samp_cap = cap;
+        net->samp_seq = 0;
     }
     char *base = static_cast<char *>(net->d_samp);
     SampleBufs b;
@@ -385,33 +542,57 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     b.child_cnt = reinterpret_cast<int64_t *>(base + o_cc);
     b.child_prob = reinterpret_cast<float *>(base + o_cp);
     b.wg_total = reinterpret_cast<uint32_t *>(base + o_wg);
+    b.wg_state = reinterpret_cast<unsigned long long *>(base + o_ws);
     b.U = reinterpret_cast<int64_t *>(base + o_U);
 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     int64_t bound = 1;                                     // worst-case prefixes entering level n: min(4^n, cap)
     int n_first = 0;
-    if (d.P > HEAD_LEVELS && cap >= 4 * EXP_PARENTS && naqs::env_int("NAQS_SAMPLE_HEAD", 1) == 1) {
-        const int nin = 2 * (HEAD_LEVELS - 1);
+    // 0: per-level launches only, 1 (default): 4 levels / 256 threads, 2: 5 levels / 1024 threads — measured slower
+    // (94 us against 38 + 18 for the fifth level on its own: sixteen latency-bound waves on one CU)
+    const int head = naqs::env_int("NAQS_SAMPLE_HEAD", 1);
+    if (head >= 1 && ((head >= 2 && d.P > 5 && cap >= 1024) || (d.P > 4 && cap >= 256))) {
+        const bool big = head >= 2 && d.P > 5 && cap >= 1024;
+        const int hl = big ? 5 : 4;
+        const int nin = 2 * (hl - 1);
         const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-        hipLaunchKernelGGL(sample_head_kernel, dim3(1), dim3(SB), lds, s, d, net->d_w, b, n_samples, k0, k1);
+        if (big) hipLaunchKernelGGL((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1);
+        else hipLaunchKernelGGL((sample_head_kernel<256, 4>), dim3(1), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1);
         HIP_TRY(hipGetLastError());
-        n_first = HEAD_LEVELS;
-        for (int n = 0; n < HEAD_LEVELS; ++n) bound *= 4;
+        n_first = hl;
+        for (int n = 0; n < hl; ++n) bound *= 4;
     } else {
         hipLaunchKernelGGL(sample_init_kernel, dim3(1), dim3(64), 0, s, b, n_samples);
         HIP_TRY(hipGetLastError());
     }
+    // one launch per level (expand + compaction with a look-back scan across workgroups) unless NAQS_SAMPLE_FUSED=0 or
+    // the level could need more workgroups than are resident at once (the look-back waits on lower-indexed workgroups)
+    const bool fused_levels = naqs::env_int("NAQS_SAMPLE_FUSED", 1) == 1;
+    const int64_t resident_wg = (int64_t)net->cu_count * 8;
+    if (net->samp_seq >= 0x00FFFFFFu) {                    // the 24-bit call tag is about to repeat: forget every old word
+        HIP_TRY(hipMemsetAsync(b.wg_state, 0, (size_t)nwg_cap * sizeof(unsigned long long), s));
+        net->samp_seq = 0;
+    }
+    ++net->samp_seq;
     for (int n = n_first; n < d.P; ++n) {
         const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const int nin = n == 0 ? 1 : 2 * n;
         const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
         const unsigned grid_e = (unsigned)((std::min(bound, cap) + EXP_PARENTS - 1) / EXP_PARENTS);
-        hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, n & 1, cap, n == d.P - 1 ? 1 : 0,
-                           keys_dev, counts_dev, probs_dev);
-        HIP_TRY(hipGetLastError());
+        const int last = n == d.P - 1 ? 1 : 0;
+        if (fused_levels && (int64_t)grid_e <= resident_wg) {
+            const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
+            hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
+                               keys_dev, counts_dev, probs_dev);
+            HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, n & 1, cap, last, keys_dev, counts_dev,
+                               probs_dev);
+            HIP_TRY(hipGetLastError());
+        }
         bound = bound > cap ? bound : bound * 4;
     }
     hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,

@@ -147,11 +147,30 @@ def test_thirty_qubit_network_sample_logpsi_and_gradients():
 
 
 @pytest.mark.parametrize("mol", ["H2O", "N2"])
-def test_fused_head_levels_change_nothing(mol, monkeypatch):
-    """The first four levels in one launch (sample_head_kernel) vs one expand + scatter launch per level: identical output."""
+def test_launch_fusions_change_nothing(mol, monkeypatch):
+    """Every way of cutting the tree into launches draws the same samples: the first levels in one single-workgroup launch
+    (sample_head_kernel: five levels / 1024 threads, four / 256, or none), and a level as ONE launch (expand + compaction
+    with a look-back scan across workgroups, sample_level_kernel) or as an expand and a scatter launch."""
     hil, wf, fused = _setup(mol)
+    outs = []
+    for head, fuse in (("2", "1"), ("1", "1"), ("0", "1"), ("2", "0"), ("0", "0")):
+        monkeypatch.setenv("NAQS_SAMPLE_HEAD", head)
+        monkeypatch.setenv("NAQS_SAMPLE_FUSED", fuse)
+        outs.append(fused.sample(10 ** 8, seed=77, max_unique=100000))
+    assert len(outs[0][0]) > 100
+    for o in outs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(outs[0], o))
     monkeypatch.setenv("NAQS_SAMPLE_HEAD", "1")
-    a = fused.sample(10 ** 8, seed=77, max_unique=100000)
-    monkeypatch.setenv("NAQS_SAMPLE_HEAD", "0")
-    b = fused.sample(10 ** 8, seed=77, max_unique=100000)
-    assert all(torch.equal(x, y) for x, y in zip(a, b)) and len(a[0]) > 100
+    monkeypatch.setenv("NAQS_SAMPLE_FUSED", "1")
+    from naqs_amd.nade import MaxBatchSizeExceededError
+    with pytest.raises(MaxBatchSizeExceededError):          # (live prefixes of a level may outnumber the final samples, never the reverse)
+        fused.sample(10 ** 8, seed=77, max_unique=len(outs[0][0]) - 1)
+
+
+def test_sampler_weights_are_counts_over_total():
+    hil, wf, fused = _setup("N2")
+    keys, counts, probs, weights = fused.sample(10 ** 7, seed=5, max_unique=100000, with_weights=True)
+    k2, c2, p2 = fused.sample(10 ** 7, seed=5, max_unique=100000)
+    assert torch.equal(keys, k2) and torch.equal(counts, c2) and torch.equal(probs, p2)
+    want = counts.double() / counts.sum().double()
+    assert weights.dtype == torch.float64 and torch.equal(weights, want) and abs(weights.sum().item() - 1) < 1e-12
