@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 2
+#define NAQS_ABI_VERSION 3
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -177,8 +177,9 @@ int naqs_prof_stride(naqs_ham_t *h, int stride);
  * Fused log-psi evaluation of the orbital NADE (inference; gradients stay with PyTorch autograd).
  * Replaces wavefunction.log_psi(states) (src/naqs/wavefunction.py:167-183) ->
  * _forward_predict (src/naqs/network/nade.py:738-770) for the published architecture family:
- * one amplitude MLP per orbital pair (one hidden layer), a single phase MLP on the last pair
- * (aggregate_phase = False), SoftmaxLogProbAmps amplitudes, no phase symmetry.
+ * one amplitude MLP per orbital pair (one hidden layer), and either a single phase MLP on the last pair
+ * (aggregate_phase = False: -single_phase, the published runs) or one single-hidden-layer phase block per pair whose
+ * outputs are summed (aggregate_phase = True: the reference's default); SoftmaxLogProbAmps amplitudes, no phase symmetry.
  * ============================================================================================== */
 typedef struct naqs_net naqs_net_t;
 
@@ -194,6 +195,10 @@ typedef struct naqs_net_config {
     int32_t n_phase_hidden;           /* hidden layers of the phase block (>= 1) */
     int32_t phase_hidden[NAQS_NET_MAX_PHASE_LAYERS];   /* their widths */
     int32_t qubit2model[2 * NAQS_NET_MAX_PAIRS];       /* model position -> qubit (wavefunction.py:56-83, :369-383) */
+    int32_t aggregate_phase;          /* 0: one phase MLP on the last pair (the published runs, -single_phase);
+                                       * 1: one phase block per orbital pair, phases summed — the reference's default
+                                       *    (experiments/run.py:31, nade.py:556-569): every block is
+                                       *    Linear(max(1, 2n), phase_hidden[0]) + ReLU + Linear(phase_hidden[0], 4); n_phase_hidden must be 1 */
 } naqs_net_config_t;
 
 int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_t **out);

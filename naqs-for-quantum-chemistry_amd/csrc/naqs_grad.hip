@@ -52,14 +52,18 @@ __global__ __launch_bounds__(256) void logamp_sum_kernel(int P, int64_t M, const
 // always 1), dW2[c][j] = sum_s dout[s][c] h[s][j] — and run on the f32 matrix cores (v_mfma_f32_16x16x4_f32): wave w
 // owns hidden units 16w..16w+15, its accumulators live across all tiles of the workgroup.  (The first version walked the
 // tiles with scalar LDS reads and VALU selects: 83 k cycles per tile for this stage; the MFMA form is ~20x fewer LDS reads.)
-template <int NB>
+// GB: samples per tile = threads per workgroup (256, or 128 when the two [Ha][GB + 1] tiles of a wider block would not
+// fit the LDS); TPW: 16-unit hidden tiles per wave (Ha <= 16 * TPW * GB / 64).
+// raw: phase blocks of an aggregate-phase network (d describes them: 4 outputs, no symmetry) — the differentiated
+// quantity is the raw output of the realised outcome, d out[c] = g_i [c == occ], no conditional in between.
+template <int NB, int GB, int TPW>
 __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float *__restrict__ w, const int64_t M,
                                                   const uint64_t *__restrict__ keys, const float *__restrict__ g,
-                                                  float *__restrict__ out, float *smem) {
+                                                  float *__restrict__ out, float *smem, const int raw) {
     constexpr int NIN = NB == 0 ? 1 : 2 * NB;
     constexpr int S = (NIN + 1 + 5 + 3) & ~3;
     constexpr int RT = (NIN + 1 + 15) / 16;               // 16-row tiles of the input axis (inputs + the bias input)
-    constexpr int GB = GB_MAX, LD = GB + 1;
+    constexpr int LD = GB + 1, NW = GB / WAVE;
     const int Ha = d.Ha, nout = d.n_out_amp;
     const int w_floats = (Ha * S + 8 + 3) & ~3;
     float *s_w = smem;
@@ -67,7 +71,7 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
     float *s_h = s_dpre + Ha * LD;
     float *s_do = s_h + Ha * LD;                          // [5][GB]
     uint32_t *s_x = reinterpret_cast<uint32_t *>(s_do + 5 * GB);
-    __shared__ float s_b2[GB_MAX / WAVE][5];
+    __shared__ float s_b2[NW][5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
     {
         const f32x4 *from = reinterpret_cast<const f32x4 *>(w + d.amp_off[NB]);
@@ -75,11 +79,14 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
         for (int e = tid; e < (Ha * S + 8) / 4; e += GB) to[e] = from[e];
     }
     const float *b2 = s_w + Ha * S;
-    const int ct = wave;                                   // this wave's 16 hidden units (Ha <= 64)
-    const bool own = ct * 16 < Ha;
-    f32x4 acc1[RT], acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this wave's hidden tiles: ct = wave + u * NW, u < TPW (16 units each)
+    f32x4 acc1[TPW][RT], acc2[TPW];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc1[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < TPW; ++u) {
+        acc2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[u][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     float accb2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
@@ -125,16 +132,21 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
             for (int c = 0; c < 5; ++c)
                 if (c < nout) o[c] = fmaf(rv[NIN + 1 + c], h, o[c]);
         }
-        float la[4];
-        bool ok[4];
-        naqs::amp_conditional(d, NB, o, abits, bbits, la, ok);
-        // d la[occ] / d a4[c] = [c == occ] - softmax(2 a4)[c] on the allowed outcomes
         float da4[4];
-        const bool live = valid && (occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3])));
+        if (raw) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float sm = ok[c] ? expf(2.0f * la[c]) : 0.0f;
-            da4[c] = live && ok[c] ? gi * ((c == occ ? 1.0f : 0.0f) - sm) : 0.0f;
+            for (int c = 0; c < 4; ++c) da4[c] = valid && c == occ ? gi : 0.0f;
+        } else {
+            float la[4];
+            bool ok[4];
+            naqs::amp_conditional(d, NB, o, abits, bbits, la, ok);
+            // d la[occ] / d a4[c] = [c == occ] - softmax(2 a4)[c] on the allowed outcomes
+            const bool live = valid && (occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3])));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sm = ok[c] ? expf(2.0f * la[c]) : 0.0f;
+                da4[c] = live && ok[c] ? gi * ((c == occ ? 1.0f : 0.0f) - sm) : 0.0f;
+            }
         }
         float dout[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         if (d.sym) {                                       // transpose of amp_symmetrise
@@ -163,41 +175,49 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
         }
         __syncthreads();
         // sums over the tile's samples on the matrix cores
-        if (own) {
-            const float *bd = s_dpre + (ct * 16 + m) * LD + kq, *bh = s_h + (ct * 16 + m) * LD + kq;
-            const float *ad = s_do + m * GB + kq;
-#pragma unroll 4
-            for (int s0 = 0; s0 < GB; s0 += 4) {
-                const uint32_t xb = s_x[s0 + kq];
-                const float vd = bd[s0], vh = bh[s0];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const int k = rt * 16 + m;
-                    const float a = k <= NIN ? (((xb >> k) & 1u) ? 1.0f : -1.0f) : 0.0f;
-                    acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vd, acc1[rt], 0, 0, 0);
+        for (int u = 0; u < TPW; ++u) {
+            const int ct = wave + u * NW;
+            if (ct * 16 < Ha) {                            // wave-uniform
+                const float *bd = s_dpre + (ct * 16 + m) * LD + kq, *bh = s_h + (ct * 16 + m) * LD + kq;
+                const float *ad = s_do + m * GB + kq;
+#pragma unroll 4
+                for (int s0 = 0; s0 < GB; s0 += 4) {
+                    const uint32_t xb = s_x[s0 + kq];
+                    const float vd = bd[s0], vh = bh[s0];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int k = rt * 16 + m;
+                        const float a = k <= NIN ? (((xb >> k) & 1u) ? 1.0f : -1.0f) : 0.0f;
+                        acc1[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vd, acc1[u][rt], 0, 0, 0);
+                    }
+                    const float a2 = m < 5 ? ad[s0] : 0.0f;
+                    acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, vh, acc2[u], 0, 0, 0);
                 }
-                const float a2 = m < 5 ? ad[s0] : 0.0f;
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, vh, acc2, 0, 0, 0);
             }
         }
         __syncthreads();
     }
 
     // partial sums of this workgroup in state_dict order: W1 [Ha][NIN], b1 [Ha], W2 [nout][Ha], b2 [nout]
-    if (own) {
-        const int j = ct * 16 + m;                          // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + r
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+    for (int u = 0; u < TPW; ++u) {
+        const int ct = wave + u * NW;
+        if (ct * 16 < Ha) {
+            const int j = ct * 16 + m;                      // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + r
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = rt * 16 + 4 * kq + r;
+                    if (k < NIN) out[j * NIN + k] = NB == 0 ? 0.0f : acc1[u][rt][r];
+                    else if (k == NIN) out[Ha * NIN + j] = acc1[u][rt][r];
+                }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = rt * 16 + 4 * kq + r;
-                if (k < NIN) out[j * NIN + k] = NB == 0 ? 0.0f : acc1[rt][r];
-                else if (k == NIN) out[Ha * NIN + j] = acc1[rt][r];
+                const int c = 4 * kq + r;
+                if (c < nout) out[Ha * NIN + Ha + c * Ha + j] = acc2[u][r];
             }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 4 * kq + r;
-            if (c < nout) out[Ha * NIN + Ha + c * Ha + j] = acc2[r];
         }
     }
     // db2[c] = sum over this workgroup's samples of d-out[c]: wave sums, then the four waves in fixed order
@@ -211,20 +231,21 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
     __syncthreads();
     if (tid < nout) {
         float v = 0.0f;
-        for (int q = 0; q < GB / WAVE; ++q) v += s_b2[q][tid];
+        for (int q = 0; q < NW; ++q) v += s_b2[q][tid];
         out[Ha * NIN + Ha + nout * Ha + tid] = v;
     }
 }
 
-__global__ __launch_bounds__(GB_MAX) void amp_backward_kernel(const NetDims d, const float *__restrict__ w, const int64_t M,
-                                                              const uint64_t *__restrict__ keys, const float *__restrict__ g,
-                                                              float *__restrict__ partial, const int64_t partial_stride,
-                                                              const AmpSrc src) {
+template <int GB, int TPW>
+__global__ __launch_bounds__(GB) void amp_backward_kernel(const NetDims d, const float *__restrict__ w, const int64_t M,
+                                                          const uint64_t *__restrict__ keys, const float *__restrict__ g,
+                                                          float *__restrict__ partial, const int64_t partial_stride,
+                                                          const AmpSrc src, const int raw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = blockIdx.y;
     float *out = partial + (int64_t)blockIdx.x * partial_stride + src.off[n];
     switch (n) {
-#define CASE(NB) case NB: amp_backward_pair<NB>(d, w, M, keys, g, out, smem); break;
+#define CASE(NB) case NB: amp_backward_pair<NB, GB, TPW>(d, w, M, keys, g, out, smem, raw); break;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
         CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
 #undef CASE
@@ -368,41 +389,54 @@ NAQS_API int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     return NAQS_OK;
 }
 
-NAQS_API int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
-                                   float *grad_dev, void *stream) {
-    if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
-    if (!net->have_amp_weights) return NAQS_ERR_INVALID;
-    const NetDims &d = net->dims;
-    const int GB = GB_MAX;                                 // one workgroup = 4 waves = one tile of 256 samples at a time
-    if (d.Ha > 64 || (d.Ha & 15)) return NAQS_ERR_UNSUPPORTED;                  // a wave owns 16 hidden units: Ha in {16, 32, 48, 64}
-    DeviceGuard guard;
-    int st = guard.init(net->device);
-    if (st != NAQS_OK) return st;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// gradient of sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks: f = log|psi|; raw: the phase blocks
+// of an aggregate-phase network, f = phase): partial sums per workgroup, then a fixed-order reduction
+int naqs::net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const int64_t *src_off, int64_t n_block_params,
+                              int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s) {
+    if (d.Ha > 128 || (d.Ha & 15)) return NAQS_ERR_UNSUPPORTED;                 // a wave owns 16-unit hidden tiles
     if (M == 0) {
-        HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)net->amp_params * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)n_block_params * sizeof(float), s));
         return NAQS_OK;
     }
+    const bool wide = d.Ha > 64;                           // two [Ha][GB + 1] LDS tiles: 256 samples per tile up to 64 units, 128 beyond
+    const int GB = wide ? 128 : GB_MAX;
     const int n_wg = (int)std::min<int64_t>(MAX_TILE_WGS, (M + GB - 1) / GB);
-    const int64_t stride = (net->amp_params + 3) & ~3ll;
+    const int64_t stride = (std::max(net->amp_params, net->ph_params) + 3) & ~3ll;
     if (!net->d_gpart) {
         HIP_TRY(hipMalloc((void **)&net->d_gpart, (size_t)MAX_TILE_WGS * stride * sizeof(float)));
     }
     const int nin_max = 2 * (d.P - 1);
     const int S_max = (nin_max + 1 + 5 + 3) & ~3;
     const size_t lds = ((size_t)((d.Ha * S_max + 8 + 3) & ~3) + 2 * (size_t)d.Ha * (GB + 1) + 5 * GB + GB) * sizeof(float);
-    if (lds > 160 * 1024) return NAQS_ERR_UNSUPPORTED;
+    if (lds > 156 * 1024) return NAQS_ERR_UNSUPPORTED;
     if (!net->grad_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int lds_max = 156 * 1024;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward_kernel<GB_MAX, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         net->grad_attr_set = true;
     }
     AmpSrc src;
-    for (int n = 0; n < MAXP; ++n) src.off[n] = net->amp_src_off[n];
-    hipLaunchKernelGGL(amp_backward_kernel, dim3((unsigned)n_wg, (unsigned)d.P), dim3(GB), lds, s, d, net->d_w, M, keys_dev, g_dev,
-                       net->d_gpart, stride, src);
+    for (int n = 0; n < MAXP; ++n) src.off[n] = src_off[n] - src_off[0];         // relative to this set's first parameter
+    if (wide)
+        hipLaunchKernelGGL((amp_backward_kernel<128, 4>), dim3((unsigned)n_wg, (unsigned)d.P), dim3(128), lds, s, d, w, M, keys_dev,
+                           g_dev, net->d_gpart, stride, src, raw);
+    else
+        hipLaunchKernelGGL((amp_backward_kernel<GB_MAX, 1>), dim3((unsigned)n_wg, (unsigned)d.P), dim3(GB_MAX), lds, s, d, w, M,
+                           keys_dev, g_dev, net->d_gpart, stride, src, raw);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(amp_reduce_kernel, dim3((unsigned)((net->amp_params + 255) / 256)), dim3(256), 0, s, net->amp_params, n_wg,
+    hipLaunchKernelGGL(amp_reduce_kernel, dim3((unsigned)((n_block_params + 255) / 256)), dim3(256), 0, s, n_block_params, n_wg,
                        stride, net->d_gpart, grad_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
+}
+
+NAQS_API int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
+                                   float *grad_dev, void *stream) {
+    if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
+    if (!net->have_amp_weights) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    return naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_dev, grad_dev, 0,
+                                     reinterpret_cast<hipStream_t>(stream));
 }

@@ -65,7 +65,10 @@ constexpr int AMP_SPLIT = NAQS_AMP_SPLIT;   // waves splitting the hidden units 
 // over more waves was measured 2x faster than giving each wave all of them.)
 __global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w,
                                                                            int64_t M, const uint64_t *__restrict__ keys,
-                                                                           float *__restrict__ scratch, const ElocFeed feed) {
+                                                                           float *__restrict__ scratch, const ElocFeed feed,
+                                                                           const int raw) {
+    // raw: the blocks are phase blocks (aggregate_phase; d describes them: 4 outputs, no symmetry): the output of the
+    // realised outcome goes to scratch as it is (nade.py:556-569) instead of through the conditional
     __shared__ float s_part[AMP_TILES][AMP_SPLIT][5][WAVE];
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // this pair's packed rows + b2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,8 +124,22 @@ __global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const
             for (int u = 0; u < AMP_SPLIT; ++u) v += s_part[tile][u][c][lane];      // fixed order
             t[c] = v;
         }
-        scratch[(int64_t)n * M + i] = amp_finish(d, n, t, abits, bbits, occ);
+        scratch[(int64_t)n * M + i] = raw ? (occ == 0 ? t[0] : (occ == 1 ? t[1] : (occ == 2 ? t[2] : t[3])))
+                                          : amp_finish(d, n, t, abits, bbits, occ);
     }
+}
+
+// aggregate_phase epilogue: (log|psi|, phase) = (sum_n conditional log-amplitudes, sum_n phases), pair 0 first (the
+// order of the fused kernel's amplitude sum); on the fused log-psi + E_loc entry also psi in float64
+__global__ __launch_bounds__(256) void agg_finish_kernel(const int P, const int64_t M, const float *__restrict__ s_amp,
+                                                         const float *__restrict__ s_ph, float2 *__restrict__ out,
+                                                         const ElocFeed feed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float la = 0.0f, ph = 0.0f;
+    for (int n = 0; n < P; ++n) { la += s_amp[(int64_t)n * M + i]; ph += s_ph[(int64_t)n * M + i]; }
+    out[i] = make_float2(la, ph);
+    if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -972,6 +989,8 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     if (P < 2) return NAQS_ERR_UNSUPPORTED;
     if (cfg->amp_hidden <= 0 || cfg->n_phase_hidden < 1 || cfg->n_phase_hidden > NAQS_NET_MAX_PHASE_LAYERS)
         return NAQS_ERR_INVALID;
+    const bool aggregate = cfg->aggregate_phase != 0;
+    if (aggregate && (cfg->n_phase_hidden != 1 || cfg->phase_hidden[0] <= 0)) return NAQS_ERR_UNSUPPORTED;
     if (cfg->masking < 0 || cfg->masking > 2) return NAQS_ERR_INVALID;
     if ((cfg->n_alpha < 0) != (cfg->n_beta < 0)) return NAQS_ERR_INVALID;
     std::vector<bool> seen((size_t)N, false);
@@ -1007,6 +1026,39 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         poff += (int64_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
     }
     net->amp_params = off;
+    net->aggregate = aggregate;
+    if (aggregate) {
+        // phase blocks as a second amplitude-shaped network: same inputs, Hp hidden units, 4 raw outputs, no symmetry
+        NetDims &q = net->dph;
+        q = d;
+        q.Ha = cfg->phase_hidden[0];
+        q.sym = 0;
+        q.n_out_amp = 4;
+        int64_t poff2 = 0;
+        for (int n = 0; n < P; ++n) {
+            net->ph_src_off[n] = off;
+            q.amp_off[n] = (int32_t)poff2;
+            const int nin = n == 0 ? 1 : 2 * n;
+            off += (int64_t)q.Ha * nin + q.Ha + 4ll * q.Ha + 4;
+            poff2 += (int64_t)q.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
+        }
+        net->ph_params = off - net->amp_params;
+        net->n_params = off;
+        net->w_floats = poff;
+        d.n_lin = 0;
+        d.ld = d.ldh = 0;
+        DeviceGuard guard0;
+        int st0 = guard0.init(device);
+        if (st0 == NAQS_OK) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cu_count = prop.multiProcessorCount;
+            if (hipMalloc((void **)&net->d_w, (size_t)poff * sizeof(float)) != hipSuccess) st0 = NAQS_ERR_NOMEM;
+            if (st0 == NAQS_OK && hipMalloc((void **)&net->d_wph, (size_t)poff2 * sizeof(float)) != hipSuccess) st0 = NAQS_ERR_NOMEM;
+        }
+        if (st0 != NAQS_OK) { naqs_net_destroy(net); return st0; }
+        *out = net;
+        return NAQS_OK;
+    }
     // phase block: 2(P-1) -> hidden... -> 4
     int K = std::max(1, 2 * (P - 1));
     d.n_lin = cfg->n_phase_hidden + 1;
@@ -1085,6 +1137,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     (void)guard.init(net->device);
     (void)net->prof.enable(0);
     if (net->d_w) (void)hipFree(net->d_w);
+    if (net->d_wph) (void)hipFree(net->d_wph);
     if (net->d_wh) (void)hipFree(net->d_wh);
     if (net->d_wamp) (void)hipFree(net->d_wamp);
     if (net->d_scratch) (void)hipFree(net->d_scratch);
@@ -1102,14 +1155,16 @@ NAQS_API int naqs_net_param_count(const naqs_net_t *net, int64_t *count) {
     return NAQS_OK;
 }
 
-static int pack_amp_blocks(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
-    const NetDims &d = net->dims;
+static int pack_blocks(const NetDims &d, const int64_t *src_off, float *dst, const float *flat_dev, hipStream_t s) {
     AmpSrcOff so;
-    for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
+    for (int n = 0; n < MAXP; ++n) so.off[n] = src_off[n];
     const int total_max = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;
-    hipLaunchKernelGGL(pack_amp_kernel, dim3((total_max + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_w);
+    hipLaunchKernelGGL(pack_amp_kernel, dim3((total_max + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, dst);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
+}
+static int pack_amp_blocks(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
+    return pack_blocks(net->dims, net->amp_src_off, net->d_w, flat_dev, s);
 }
 
 NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
@@ -1135,6 +1190,12 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     net->have_weights = net->have_amp_weights = net->have_wb = false;
     st = pack_amp_blocks(net, flat_dev, s);
     if (st != NAQS_OK) return st;
+    if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack
+        st = pack_blocks(net->dph, net->ph_src_off, net->d_wph, flat_dev, s);
+        if (st != NAQS_OK) return st;
+        net->have_weights = net->have_amp_weights = net->have_wb = true;
+        return NAQS_OK;
+    }
     {
         PhasePackJobs jobs{};
         int biggest = 0;
@@ -1166,6 +1227,16 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     return NAQS_OK;
 }
 
+static int launch_amp_kernel(const NetDims &d, const float *w, int64_t M, const uint64_t *keys_dev, float *scratch,
+                             const ElocFeed &feed, int raw, hipStream_t s) {
+    const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+    if (amp_lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, w, M,
+                       keys_dev, scratch, feed, raw);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
 int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed) {
     const NetDims &d = net->dims;
     if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
@@ -1174,13 +1245,27 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
         if (net->d_scratch) (void)hipFree(net->d_scratch);
         net->d_scratch = nullptr; net->cap_M = 0;
         const int64_t cap = std::max<int64_t>(1024, M + M / 4);
-        HIP_TRY(hipMalloc((void **)&net->d_scratch, (size_t)cap * d.P * sizeof(float)));
+        // [P][cap] conditional log-amplitudes (+ [P][cap] phases of the per-pair phase blocks)
+        HIP_TRY(hipMalloc((void **)&net->d_scratch, (size_t)cap * d.P * (net->aggregate ? 2 : 1) * sizeof(float)));
         net->cap_M = cap;
     }
     const ElocFeed none{};
-    const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, net->d_w, M,
-                       keys_dev, net->d_scratch, feed ? *feed : none);
+    return launch_amp_kernel(d, net->d_w, M, keys_dev, net->d_scratch, feed ? *feed : none, 0, s);
+}
+
+// aggregate_phase: amplitude blocks, phase blocks (raw), then the sums
+static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, hipStream_t s, const ElocFeed &feed) {
+    int st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
+    if (st != NAQS_OK) return st;
+    float *s_ph = net->d_scratch + (size_t)net->dims.P * net->cap_M;
+    const ElocFeed none{};
+    const bool prof = net->prof.armed();
+    if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
+    st = launch_amp_kernel(net->dph, net->d_wph, M, keys_dev, s_ph, none, 1, s);
+    if (st != NAQS_OK) return st;
+    if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
+    hipLaunchKernelGGL(agg_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch, s_ph,
+                       reinterpret_cast<float2 *>(logpsi_dev), feed);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -1196,6 +1281,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (net->aggregate) return agg_logpsi(net, M, keys_dev, logpsi_dev, s, feed);
     const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA
     const size_t lds_h16 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
     const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;

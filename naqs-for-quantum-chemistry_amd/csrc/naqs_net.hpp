@@ -150,6 +150,13 @@ struct naqs_net {
     int64_t amp_src_off[naqs::MAXP] = {};         // per pair: offset in the flat source
     std::vector<int64_t> phase_src_off;     // per phase linear layer: offset in the flat source
     std::vector<int> phase_K, phase_N;
+    // aggregate_phase: one phase block per pair, described as a second "amplitude-shaped" network (4 raw outputs, no
+    // symmetry, the realised outcome's output is the pair's phase): the amplitude kernels run on it in raw mode
+    bool aggregate = false;
+    naqs::NetDims dph{};
+    int64_t ph_src_off[naqs::MAXP] = {};          // per pair: offset of its phase block in the flat source
+    int64_t ph_params = 0;
+    float *d_wph = nullptr;                 // packed phase blocks (layout of the amplitude rows)
     float *d_w = nullptr;                   // [amp params | packed phase layers]
     unsigned short *d_wh = nullptr;         // phase layers as 3 bf16 planes (phase_kernel_bf16x3)
     int64_t wh_elems = 0;
@@ -188,6 +195,10 @@ int net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *l
                     const ElocFeed &feed, const PhaseSave &save);
 // naqs_phase_grad.hip: row-major padded copies of the phase weights for the backward GEMMs
 int net_pack_backward_weights(naqs_net *net, const float *flat_dev, hipStream_t s);
+// naqs_grad.hip: d/d theta sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks, or the phase blocks of an
+// aggregate-phase network with raw = 1); grad_dev receives n_block_params floats in state_dict order
+int net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const int64_t *src_off, int64_t n_block_params,
+                        int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s);
 // naqs_logpsi.hip: grow the [P][M] scratch and launch amp_kernel (feed == nullptr: no E_loc hand-over)
 int net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed = nullptr);
 }  // namespace naqs

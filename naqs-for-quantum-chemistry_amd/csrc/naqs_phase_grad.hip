@@ -53,6 +53,13 @@ __global__ __launch_bounds__(256) void top_delta_kernel(const NetDims d, const i
     delta[e] = c == occ ? g[i].y : 0.0f;
 }
 
+// both columns of g [M][2] as contiguous vectors (aggregate-phase backward: one per set of blocks)
+__global__ __launch_bounds__(256) void split_g2_kernel(const int64_t M, const float2 *__restrict__ g, float *__restrict__ g_amp,
+                                                       float *__restrict__ g_ph) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < M) { const float2 v = g[i]; g_amp[i] = v.x; g_ph[i] = v.y; }
+}
+
 __global__ __launch_bounds__(256) void split_g_kernel(const int64_t M, const float2 *__restrict__ g, float *__restrict__ g_amp) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < M) g_amp[i] = g[i].x;
@@ -294,6 +301,10 @@ NAQS_API int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
+    if (net->aggregate) {                                   // the per-pair blocks are recomputed by the backward pass: nothing to keep
+        naqs::ElocFeed none{};
+        return naqs::net_logpsi_impl(net, M, keys_dev, logpsi_dev, stream, none, naqs::PhaseSave{});
+    }
     st = ensure_train_scratch(net, M);
     if (st != NAQS_OK) return st;
     const TrainLayout L = train_layout(net, net->train_cap);
@@ -324,16 +335,18 @@ NAQS_API int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64
         if (out4_dev) HIP_TRY(hipMemsetAsync(out4_dev, 0, 4 * sizeof(double), s));
         return NAQS_OK;
     }
-    st = ensure_train_scratch(net, M);
-    if (st != NAQS_OK) return st;
-    const TrainLayout L = train_layout(net, net->train_cap);
-    char *base = static_cast<char *>(net->d_train);
     naqs::PhaseSave save;
-    save.x = reinterpret_cast<float *>(base + L.x);
-    save.x_ld = L.x_ld;
-    for (int l = 0; l + 1 < net->dims.n_lin; ++l) {
-        save.act[l] = reinterpret_cast<float *>(base + L.act[l]);
-        save.act_ld[l] = L.act_ld[l];
+    if (!net->aggregate) {
+        st = ensure_train_scratch(net, M);
+        if (st != NAQS_OK) return st;
+        const TrainLayout L = train_layout(net, net->train_cap);
+        char *base = static_cast<char *>(net->d_train);
+        save.x = reinterpret_cast<float *>(base + L.x);
+        save.x_ld = L.x_ld;
+        for (int l = 0; l + 1 < net->dims.n_lin; ++l) {
+            save.act[l] = reinterpret_cast<float *>(base + L.act[l]);
+            save.act_ld[l] = L.act_ld[l];
+        }
     }
     naqs::ElocFeed feed{};
     st = naqs::eloc_begin(ham, M, s, &feed);
@@ -347,7 +360,7 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
                                      float *grad_dev, void *stream) {
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
     if (!net->have_weights || !net->have_wb) return NAQS_ERR_INVALID;
-    if (M > net->train_cap || !net->d_train) return NAQS_ERR_INVALID;        // naqs_net_train_forward of the same batch comes first
+    if (!net->aggregate && (M > net->train_cap || !net->d_train)) return NAQS_ERR_INVALID;   // naqs_net_train_forward of the same batch comes first
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
@@ -355,6 +368,19 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     if (M == 0) {
         HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)net->n_params * sizeof(float), s));
         return NAQS_OK;
+    }
+    if (net->aggregate) {
+        // both sets of per-pair blocks through the same backward kernel: amplitude blocks on g[:, 0], phase blocks (raw
+        // outputs, no conditional) on g[:, 1]; the forward scratch ([2 P][cap] floats, free by now) holds the two columns
+        if (M > net->cap_M || !net->d_scratch) return NAQS_ERR_INVALID;
+        float *g_amp = net->d_scratch, *g_ph = net->d_scratch + M;
+        hipLaunchKernelGGL(split_g2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, reinterpret_cast<const float2 *>(g_dev),
+                           g_amp, g_ph);
+        HIP_TRY(hipGetLastError());
+        st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, s);
+        if (st != NAQS_OK) return st;
+        return naqs::net_blocks_backward(net, net->dph, net->d_wph, net->ph_src_off, net->ph_params, M, keys_dev, g_ph,
+                                         grad_dev + net->amp_params, 1, s);
     }
     const NetDims &d = net->dims;
     const TrainLayout L = train_layout(net, net->train_cap);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(os.path.dirname(_HERE), "lib")
 
 NAQS_OK = 0
-ABI_VERSION = 2          # NAQS_ABI_VERSION of include/naqs_hip.h
+ABI_VERSION = 3          # NAQS_ABI_VERSION of include/naqs_hip.h
 PSI_F32, PSI_F64, LOGPSI_F32, LOGPSI_F64 = 0, 1, 2, 3
 
 c_i64, c_u64p, c_f64p, c_vp = ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
@@ -74,7 +74,7 @@ class NetConfig(ctypes.Structure):
     _fields_ = [("n_qubits", ctypes.c_int32), ("n_alpha", ctypes.c_int32), ("n_beta", ctypes.c_int32),
                 ("masking", ctypes.c_int32), ("use_amp_spin_sym", ctypes.c_int32), ("amp_hidden", ctypes.c_int32),
                 ("n_phase_hidden", ctypes.c_int32), ("phase_hidden", ctypes.c_int32 * NET_MAX_PHASE_LAYERS),
-                ("qubit2model", ctypes.c_int32 * (2 * NET_MAX_PAIRS))]
+                ("qubit2model", ctypes.c_int32 * (2 * NET_MAX_PAIRS)), ("aggregate_phase", ctypes.c_int32)]
 
 
 class NaqsError(RuntimeError):

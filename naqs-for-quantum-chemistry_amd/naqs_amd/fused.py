@@ -1,10 +1,13 @@
 """Fused HIP evaluation of log psi for a batch of keys (``naqs_net_*`` entry points).
 
 The product path of the metric's "log-psi eval": two kernels instead of ~200 eager launches.
-Supported architecture family = what the reference's published runs use (batch_train.sh:14):
-one hidden layer per amplitude block, a single phase block (``aggregate_phase=False``), no phase
-symmetry, <= 16 orbital pairs, phase layers <= 512 wide.  Anything else raises
-``NotImplementedError`` — callers then stay on the PyTorch modules (same numbers, more launches).
+Supported architecture families:
+  * what the reference's published runs use (batch_train.sh:14): one hidden layer per amplitude block (a multiple of 16,
+    <= 128 units), a single phase block (``aggregate_phase=False``) of 1..8 hidden layers <= 512 wide;
+  * the reference's default ansatz (experiments/run.py:11-31): the same amplitude blocks and one phase block per orbital
+    pair (``aggregate_phase=True``), each with one hidden layer (multiple of 16, <= 128 units);
+no phase symmetry, <= 16 orbital pairs.  Anything else raises ``NotImplementedError`` — callers then stay on the
+PyTorch modules (same numbers, more launches), and ``wavefunction.fused()`` says so on stdout.
 """
 import ctypes
 import os
@@ -57,15 +60,23 @@ class FusedLogPsi:
         wf, m = wavefunction, wavefunction.model
         if m.device.type != "cuda":
             raise _lib.NaqsError("FusedLogPsi needs the network on a HIP device (no CPU fallback)")
-        if m.aggregate_phase or len(m.phase_layers) != 1:
-            raise NotImplementedError("fused log-psi: aggregate_phase=True")
+        self.aggregate = bool(m.aggregate_phase)
+        if len(m.phase_layers) != (m.P if self.aggregate else 1):
+            raise NotImplementedError("fused log-psi: unexpected number of phase blocks")
         if len(m.amp_layers[0].linears()) != 2:
             raise NotImplementedError("fused log-psi: amplitude blocks need exactly one hidden layer")
+        ha = m.amp_layers[0].linears()[0].out_features
+        if ha % 16 or ha > 128:
+            raise NotImplementedError(f"fused log-psi: amplitude hidden width {ha} (a multiple of 16, <= 128, is supported)")
         if m.P > _lib.NET_MAX_PAIRS or m.P < 2:
             raise NotImplementedError("fused log-psi: 2..16 orbital pairs")
         phase_lin = m.phase_layers[0].linears()
         hidden = [lin.out_features for lin in phase_lin[:-1]]
-        if not 1 <= len(hidden) <= _lib.NET_MAX_PHASE_LAYERS or max(hidden) > 512:
+        if self.aggregate:
+            if len(hidden) != 1 or hidden[0] % 16 or hidden[0] > 128:
+                raise NotImplementedError("fused log-psi: aggregate_phase=True with other than one phase hidden layer per "
+                                          f"block of a multiple of 16, <= 128 units (got {hidden})")
+        elif not 1 <= len(hidden) <= _lib.NET_MAX_PHASE_LAYERS or max(hidden) > 512:
             raise NotImplementedError("fused log-psi: 1..8 phase hidden layers of width <= 512")
         self._lib = _lib.load_library()
         self.wf = wf
@@ -82,6 +93,7 @@ class FusedLogPsi:
             cfg.phase_hidden[i] = h
         for i, q in enumerate(wf.qubit2model_permutation):
             cfg.qubit2model[i] = int(q)
+        cfg.aggregate_phase = int(self.aggregate)
         self._h = ctypes.c_void_p(None)
         st = self._lib.naqs_net_create(ctypes.byref(cfg), self.device.index or 0, ctypes.byref(self._h))
         _lib.check(st, "naqs_net_create")
@@ -91,6 +103,8 @@ class FusedLogPsi:
         self._samp = None
         self._grad_flat, self._grad_views = None, None
         self.train_mode = os.environ.get("NAQS_TRAIN_MODE", "hip")     # "hip" | "blas" (phase MLP through torch/rocBLAS)
+        if self.aggregate:
+            self.train_mode = "hip"                                     # (the per-pair phase blocks have no BLAS formulation here)
         assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
         _lib.check(self._lib.naqs_net_amp_param_count(self._h, ctypes.byref(n)), "naqs_net_amp_param_count")
         self.n_amp_params = n.value
@@ -122,6 +136,9 @@ class FusedLogPsi:
         pair, the phase MLP (three Linear layers) through PyTorch/rocBLAS.  Same function of the parameters as
         ``wavefunction.log_psi(states)``."""
         m = self.wf.model
+        if self.aggregate:
+            raise NotImplementedError("log_psi_train (autograd.Function form) for aggregate_phase networks: use "
+                                      "forward_saved / backward_saved")
         keys = keys.contiguous()
         log_amp = _LogAmp.apply(self, keys, *self._amp_params)
         x = ((keys.unsqueeze(-1) >> self._phase_shifts) & 1).to(torch.float32).mul_(2.0).sub_(1.0)

@@ -323,7 +323,7 @@ class OptimizerBase:
             elif fused is not None and regularisation_loss is None and not self.normalize_grads:
                 # HIP amplitude forward/backward + explicit chain rule of the phase MLP: no autograd graph at all
                 lp_mine, saved = fused.forward_saved(keys[b:e_])
-            elif fused is not None:         # same kernels behind a torch.autograd.Function
+            elif fused is not None and not fused.aggregate:     # same kernels behind a torch.autograd.Function
                 lp_mine = fused.log_psi_train(keys[b:e_])
             else:
                 lp_mine = self.wavefunction.log_psi(states[b:e_]).reshape(-1, 2)

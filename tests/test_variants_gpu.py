@@ -3,8 +3,10 @@
 
 * ``-no_amp_sym`` / ``-no_mask_psi`` / ``-full_mask_psi`` stay inside the fused HIP family — the kernels' ``sym = 0``
   and masking branches run here (sampler, matrix-core log psi, training forward/backward);
-* the run.py default (``aggregate_phase=True``: one phase block per orbital pair) is outside it: the network runs as
-  PyTorch modules on the device — announced on stdout — with E_loc on the HIP kernels;
+* the run.py default (``aggregate_phase=True``: one phase block per orbital pair, 128 hidden units) is a second fused
+  family: the per-pair phase blocks run through the amplitude kernels in raw mode (forward, training backward with
+  128-unit blocks);  an ansatz outside both families falls back to the PyTorch modules — announced on stdout — with
+  E_loc on the HIP kernels;
 * config 5: E_loc at M = 10 000 and the FULL-masked network on the two end geometries of the N2 sweep, and a short
   training run of one geometry.
 """
@@ -19,8 +21,9 @@ from conftest import GOLDEN, golden
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-FUSED = ["LiH_noampsym", "LiH_fullmask", "N2_noampsym", "N2_nomask", "N2_0.75_fullmask", "N2_2.25_fullmask"]
-EAGER = ["LiH_aggphase", "N2_aggphase"]
+FUSED = ["LiH_noampsym", "LiH_fullmask", "N2_noampsym", "N2_nomask", "N2_0.75_fullmask", "N2_2.25_fullmask",
+         "LiH_aggphase", "N2_aggphase"]
+EAGER = []
 
 
 def _wf(fix):
@@ -67,13 +70,9 @@ def test_fused_family_log_psi_matches_reference(fix):
 def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
     mol, z, hil, wf = _wf(fix)
     opt = _opt(mol, wf, tmp_path)
-    out = capsys.readouterr().out
-    if fix in EAGER:
-        assert wf.fused() is None
-        assert "fused HIP network kernels not available" in out and "aggregate_phase" in out      # loud, not silent
-    else:
-        from naqs_amd.flat_adam import FlatAdam
-        assert wf.fused() is not None and isinstance(opt.optimizer, FlatAdam)
+    from naqs_amd.flat_adam import FlatAdam
+    assert wf.fused() is not None and isinstance(opt.optimizer, FlatAdam)
+    assert wf.fused().aggregate == fix.endswith("aggphase")
     states = torch.tensor(z["samp_states"], device="cuda")
     counts = torch.tensor(z["samp_counts"], device="cuda")
     keys = hil.state2idx(states).squeeze(-1)
@@ -100,6 +99,7 @@ def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
 
 @pytest.mark.parametrize("fix", ["LiH_aggphase", "N2_aggphase"])
 def test_aggregate_phase_log_psi_on_device(fix):
+    """The PyTorch modules on the device (conditionals of every block) and the HIP kernels' gradients against autograd."""
     mol, z, hil, wf = _wf(fix)
     s = torch.tensor(z["eval_states"], device="cuda")
     with torch.no_grad():
@@ -110,6 +110,45 @@ def test_aggregate_phase_log_psi_on_device(fix):
     assert np.array_equal(np.isfinite(cond), finite)
     assert np.max(np.abs(cond[finite] - ref[finite])) < 2e-5 and np.max(np.abs(lp - z["eval_log_psi"])) < 5e-5
     assert np.abs(ref[..., :-1, :, 1]).max() > 0          # every block contributes a phase, not only the last
+    # d/d theta sum_i (g0_i log|psi_i| + g1_i phase_i): naqs_net_train_backward (amplitude blocks + raw phase blocks, 128
+    # hidden units -> the 128-sample-tile variant of the backward kernel) vs autograd through the modules
+    fused = wf.fused()
+    keys = torch.as_tensor(z["samp_keys"].astype(np.int64), device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g = torch.randn((len(keys), 2), device="cuda", generator=gen)
+    lp_k, saved = fused.forward_saved(keys)
+    for p in wf.model.parameters():
+        p.grad = None
+    fused.backward_saved(saved, g)
+    mine = {n: p.grad.clone() for n, p in wf.model.named_parameters()}
+    for p in wf.model.parameters():
+        p.grad = None
+    lp_t = wf.log_psi(hil.idx2state(keys)).reshape(-1, 2)
+    assert torch.max(torch.abs(lp_t.detach() - lp_k)).item() < 5e-5
+    (g * lp_t).sum().backward()
+    for n, p in wf.model.named_parameters():
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((mine[n] - p.grad).abs().max()) < 2e-4 * scale + 1e-9, n
+
+
+def test_ansatz_outside_the_fused_families_falls_back_loudly(capsys):
+    """Two phase hidden layers per block with aggregate_phase=True is in neither family: PyTorch modules on the device,
+    announced on stdout (not silent), E_loc still on the HIP kernels."""
+    from naqs_amd.hilbert import Encoding, Hilbert
+    from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+    hil = Hilbert.get(12, 2, 2, encoding=Encoding.SIGNED)
+    wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[32, 32],
+                                   use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=True,
+                                   n_alpha_electrons=2, n_beta_electrons=2, device="cuda")
+    assert wf.fused() is None
+    out = capsys.readouterr().out
+    assert "fused HIP network kernels not available" in out and "aggregate_phase" in out
+    states, counts, probs, lp = wf.sample(10000)                                   # the PyTorch sampler on the device
+    assert lp.shape == (len(states), 2) and counts.sum().item() <= 10000
+    wf2 = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, amp_hidden_size=[200], phase_hidden_size=[512, 512],
+                                    use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=False,
+                                    n_alpha_electrons=2, n_beta_electrons=2, device="cuda")
+    assert wf2.fused() is None and "amplitude hidden width 200" in capsys.readouterr().out
 
 
 @pytest.mark.parametrize("mol", ["N2_0.75", "N2_2.25"])
@@ -171,3 +210,60 @@ def test_sweep_geometry_short_training_run_full_mask(tmp_path):
     e = np.array([x[1] for x in opt.log[LogKey.E_LOC]])
     assert np.mean(e[-10:]) < np.mean(e[:10]) - 1.0
     assert np.mean(e[-10:]) > fci - 1e-3, (np.mean(e[-10:]), fci)
+
+
+def test_default_ansatz_cli_run_on_device(tmp_path, capsys):
+    """`python -m experiments.run -m molecules/LiH` with the reference's own defaults for the ansatz (run.py:11-31:
+    aggregate phase, 128 hidden units, amplitude symmetry) end to end on the HIP path: sampler, fused forward with the
+    per-pair phase blocks, E_loc, HIP backward of both sets of blocks, FlatAdam, checkpoints, summary."""
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    from experiments import _base
+    from naqs_amd.flat_adam import FlatAdam
+    out = str(tmp_path / "run")
+    lih = os.path.join(GOLDEN, "molecules", "LiH")
+    made = {}
+    real = _base.PartialSamplingOptimizer
+
+    class Spy(real):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made["opt"] = self
+
+    _base.PartialSamplingOptimizer = Spy
+    try:
+        res = _base.run(n_hid=128, n_samps=1e6, n_unq_samps_min=10, n_unq_samps_max=1e5,
+                        argv=["-m", lih, "-o", out, "-n_train", "200", "-output_freq", "100", "-s", "111"])
+    finally:
+        _base.PartialSamplingOptimizer = real
+    txt = capsys.readouterr().out
+    assert "fused HIP network kernels not available" not in txt          # the default ansatz is a fused family
+    opt = made["opt"]
+    assert opt.wavefunction.model.aggregate_phase and opt.wavefunction.fused().aggregate
+    assert isinstance(opt.optimizer, FlatAdam)
+    r = res[0]
+    assert r["final"] < -7.0 and r["final"] > r["fci"] - 1e-3             # 200 steps from random init (-2 Ha): variational, most of the way
+    assert r["eig"] >= r["fci"] - 1e-8
+    assert os.path.exists(os.path.join(out, "summary.txt")) and os.path.exists(os.path.join(out, "energy_optimizer.pth"))
+
+
+def test_sampler_with_wide_blocks_matches_psi_squared():
+    """128 hidden units per amplitude block (the reference's default -n_hid): the tree sampler's quads take 32 units each."""
+    mol, z, hil, wf = _wf("LiH_aggphase")
+    fused = wf.fused()
+    n = 2_000_000
+    keys, counts, probs = fused.sample(n, seed=9, max_unique=100000)
+    k, c = keys.cpu().numpy(), counts.cpu().numpy()
+    all_keys = np.sort(hil._all_keys())
+    with torch.no_grad():
+        lp = wf.log_psi(hil.idx2state(torch.as_tensor(all_keys, device="cuda"))).reshape(-1, 2)
+    p = np.exp(2.0 * lp[:, 0].double().cpu().numpy())
+    pos = np.searchsorted(all_keys, k)
+    assert np.allclose(probs.cpu().numpy(), p[pos], rtol=2e-4, atol=1e-12)
+    obs = np.zeros(len(all_keys))
+    obs[pos] = c
+    expect = p / p.sum() * c.sum()
+    m = expect >= 5
+    chi2 = ((obs[m] - expect[m]) ** 2 / expect[m]).sum()
+    assert stats.chi2.sf(chi2, m.sum()) > 1e-4, (chi2, m.sum())
