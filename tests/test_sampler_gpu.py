@@ -29,7 +29,7 @@ def _exact(hil, fused):
     return keys.cpu().numpy(), np.exp(2.0 * lp[:, 0].double().cpu().numpy())
 
 
-@pytest.mark.parametrize("mol,n", [("LiH", 2_000_000), ("H2O", 5_000_000)])
+@pytest.mark.parametrize("mol,n", [("LiH", 2_000_000), ("H2O", 5_000_000), ("N2", 50_000_000)])
 def test_distribution_matches_psi_squared(mol, n):
     hil, wf, fused = _setup(mol)
     keys, counts, probs = fused.sample(n, seed=20240607, max_unique=100000)
