@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two builds of the library on the same box: NAQS_HIP_LIB selects the .so
-for lib in naqs-for-quantum-chemistry_amd/lib/libnaqs_hip_nopre.so naqs-for-quantum-chemistry_amd/lib/libnaqs_hip.so naqs-for-quantum-chemistry_amd/lib/libnaqs_hip_nopre.so naqs-for-quantum-chemistry_amd/lib/libnaqs_hip.so; do
+for lib in naqs-for-quantum-chemistry_amd/lib/libnaqs_hip_A.so naqs-for-quantum-chemistry_amd/lib/libnaqs_hip.so naqs-for-quantum-chemistry_amd/lib/libnaqs_hip_A.so naqs-for-quantum-chemistry_amd/lib/libnaqs_hip.so; do
   echo "== $lib"
   NAQS_HIP_LIB=$PWD/$lib NAQS_DEBUG_CLOCKS=1 python tools/clock_probe.py 2>&1 | grep "wave 0\|wave 7" | tail -2
   NAQS_HIP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-config4 --steps 400 2>/dev/null | python -c "
