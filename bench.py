@@ -347,7 +347,8 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
            "value": M * steps / dt, "unit": "unique samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "warmup": warmup, "scaling": "strong", "rows_per_rank": int(e - b), "logpsi_rows_per_rank": int(S),
            "collectives_per_step": (f"1 all-gather of the (log|psi|, phase) table ({M * 8} B in all) + 1 all-reduce of 4 "
-                                    f"accumulators (32 B), RCCL, {dist.get_world_size()} rank(s)") if use_dist else "none (single process)",
+                                    f"accumulators (32 B), {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}, "
+                                    f"{dist.get_world_size()} rank(s)") if use_dist else "none (single process)",
            "energy": float(s[0] / s[3]),
            "eloc_kernel_us": t_eloc * 1e6, "logpsi_kernel_us": t_lp * 1e6}
     b_alg = algorithmic_bytes(e - b, ham.K, ham.Kxy) if e > b else 0
@@ -411,13 +412,19 @@ def worker(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # test hook (tests/test_bench.py on the one-GPU box): NAQS_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+    # NAQS_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two ranks per device) — the world > 1 code of both
+    # modes then runs on real kernels; the JSON names the backend, such a line is not a multi-GPU measurement
+    if os.environ.get("NAQS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("NAQS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("NAQS_BENCH_FORCE_DIST") == "1"      # (forced at world 1: exercises the path)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.shard == "rows":
         return sharded_main(args, dev, world, rank, use_dist)
@@ -620,7 +627,8 @@ def worker(args):
                                     if depth > 1 else "one batch at a time"),
                        "batches": f"{N_KEY_SETS} distinct key sets per rank, rotated every step",
                        "input": "unique sampled bit-strings (keys) resident in HBM; random-init network",
-                       "ranks": (f"{dist.get_world_size()} RCCL rank(s)" if use_dist else "single process, no process group"),
+                       "ranks": (f"{dist.get_world_size()} {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} rank(s)"
+                                 if use_dist else "single process, no process group"),
                        "energy": float(s[0] / s[3])},
             "roofline": roofline,
         }
@@ -669,7 +677,8 @@ def sharded_main(args, dev, world, rank, use_dist):
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32 network (bf16x3-split MFMA, f32-equivalent) / f64 E_loc", "data": "synthetic",
                "config": {"workload": res["workload"], "collectives_per_step": res["collectives_per_step"],
-                          "ranks": (f"{dist.get_world_size()} RCCL rank(s)" if use_dist else "single process, no process group"),
+                          "ranks": (f"{dist.get_world_size()} {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} rank(s)"
+                                    if use_dist else "single process, no process group"),
                           "rows_per_rank": rows, "energy": res["energy"]},
                "roofline": roofline}
         if not args.no_cpu_baseline and world == 1:

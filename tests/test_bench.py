@@ -104,6 +104,35 @@ def test_row_sharded_table_through_rccl_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_two_ranks_on_one_gpu_shard_one_table_to_the_same_energy():
+    """The world > 1 code of `--shard rows` on real kernels: two ranks (both on the box's one GPU, collectives over gloo —
+    RCCL refuses two ranks per device) evaluate log psi for half of the table each, all-gather it, produce E_loc for
+    their row shards and all-reduce the accumulators: the weighted energy of the table must be the single-rank one."""
+    argv = ["--shard", "rows", "--molecule", "Li2O", "--samples", "20001", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    one, l1 = _run_bench(["--gpus", "1"] + argv, {}, timeout=900)
+    two, l2 = _run_bench(["--gpus", "2"] + argv, {"NAQS_BENCH_ONE_DEVICE": "1", "NAQS_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert one.returncode == 0 and two.returncode == 0, one.stderr[-1500:] + two.stderr[-1500:]
+    d1, d2 = json.loads(l1[-1]), json.loads(l2[-1])
+    assert d2["n_gpus"] == 2 and "2 gloo rank(s)" in d2["config"]["ranks"] and d2["config"]["rows_per_rank"] == 10001
+    e1, e2 = d1["config"]["energy"], d2["config"]["energy"]
+    assert np.isfinite(e1) and abs(e1 - e2) < 1e-9 * abs(e1), (e1, e2)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_weak_mode_runs():
+    """The default (independent batches per rank) mode with two ranks: one all-reduce of the accumulators at the end of
+    the timed region, then the row-sharded config-4 table across both ranks, one JSON line from rank 0."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "4", "--no-cpu-baseline"],
+                          {"NAQS_BENCH_ONE_DEVICE": "1", "NAQS_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e6 and "cpu_baseline" not in d
+    c4 = d["config4_row_sharded"]
+    assert "error" not in c4 and c4["rows_per_rank"] == 25000 and "all-gather" in c4["collectives_per_step"]
+    assert sum(1 for l in lines if l.lstrip().startswith("{")) == 1
+
+
+@pytest.mark.gpu
 def test_default_line_is_measured_in_this_run():
     """serial figures and the config-4 table are measured by the same process, nothing is replayed from a file except
     the hardware-counter fields, which say so."""
