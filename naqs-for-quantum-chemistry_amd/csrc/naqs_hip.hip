@@ -118,10 +118,24 @@ struct ElocParams {
     double2 *eloc;           // [n_rows]
 };
 
+// sum over the 64 lanes, valid in lane 0 (every lane of row 0..3 holds its row's sum on the way): four DPP exchanges
+// inside the rows of 16 lanes (xor 1, xor 2, mirror in 8, mirror in 16) and three scalar adds of the row sums.  Fixed
+// order, no LDS traffic (__shfl_xor on a double is two ds_bpermute per step: 24 LDS round trips for a (re, im) pair).
+template <int CTRL>
+__device__ __forceinline__ double dpp_swap(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
+    v += dpp_swap<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_swap<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_swap<0x141>(v);         // row_half_mirror
+    v += dpp_swap<0x140>(v);         // row_mirror
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // the builtin returns a signed int: go through uint32_t before widening, or bit 31 smears upwards
@@ -344,6 +358,166 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// eloc_kernel2: the same row walk with the candidates compacted TWICE.  In eloc_kernel a lane owns a group through
+// filter, probe and push, so after the particle-number filter (N2: 24 % pass, Li2O: ~15 %) the probe code — the bulk
+// of the ~75 instructions a candidate slot costs — issues for a quarter-full wave.  Here
+//   A. every lane filters one group per pass and the survivors' group numbers are compacted (ballot + mbcnt) into a
+//      per-wave LDS "pass queue";
+//   B. whenever 64 are queued, one dense pass probes them (Bloom test first in the BLOOM variant); hits go to the
+//      hit queue as (term range, sample index) entries;
+//   C. whenever 64 hits are queued every lane sums one entry's terms sequentially (as before).
+// Heavy groups (single excitations, tens of terms) no longer stall the wave per hit: the kernel walks a view of the
+// tables in which they are cut into chunks of <= HEAVY_TERMS terms, each a group of its own with the parent's flip mask
+// (naqs_ham::d_xy2 / d_rp2), so only the diagonal keeps the lanes-stride-terms form.
+// Light groups have <= HEAVY_TERMS terms by definition: one entry, summed in ascending term order = the reference's
+// order for a matrix element.  A chunked heavy element is the sum of its chunks' partial sums, each multiplied by
+// psi_j separately (equal to ~1 ulp; the strided form was not sequential either).
+// ------------------------------------------------------------------------------------------------
+constexpr int PASS_BATCH = 2;                              // filter passes between two looks at the pass queue
+constexpr int PQ_CAP = 64 * (PASS_BATCH + 1), HQ_CAP = 128;  // < 64 carried + what one batch / one probe pass can push
+constexpr size_t queue_bytes_v2(int nwaves) { return (size_t)nwaves * (HQ_CAP * sizeof(int2) + PQ_CAP * sizeof(int32_t)) + 16; }
+
+template <typename KT, int STAGE, int NT, bool BLOOM>
+__global__ __launch_bounds__(NT) void eloc_kernel2(const ElocParams<KT> p) {
+    constexpr int NWAVES = NT / WAVE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS layout: [c_t: K doubles][hit queues: NWAVES*HQ_CAP int2][pass queues: NWAVES*PQ_CAP int][row_ptr][xy][yz][bloom]
+    double *s_c = reinterpret_cast<double *>(smem);
+    int2 *s_hq = reinterpret_cast<int2 *>(s_c + (STAGE >= 2 ? p.K : 0));
+    int32_t *s_pq = reinterpret_cast<int32_t *>(s_hq + NWAVES * HQ_CAP);
+    int32_t *s_rp = s_pq + NWAVES * PQ_CAP + 4;
+    KT *s_xy = reinterpret_cast<KT *>(s_rp + (STAGE >= 1 ? (p.Kxy + 2) & ~1 : 0));
+    KT *s_yz = s_xy + (STAGE >= 1 ? p.Kxy : 0);
+    uint32_t *s_bloom = reinterpret_cast<uint32_t *>(
+        smem + ((reinterpret_cast<unsigned char *>(s_yz + (STAGE >= 2 ? p.K : 0)) - smem + 15) & ~15ull));
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+
+    if (BLOOM) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.bloom);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_bloom);
+#pragma unroll 4
+        for (int e = tid; e < BLOOM_WORDS / 4; e += NT) dst[e] = src[e];
+    }
+    if (STAGE >= 1) {
+#pragma unroll 4
+        for (int g = tid; g < p.Kxy; g += NT) s_xy[g] = p.xy_g[g];
+#pragma unroll 4
+        for (int g = tid; g <= p.Kxy; g += NT) s_rp[g] = p.row_ptr[g];
+    }
+    if (STAGE >= 2) {
+#pragma unroll 4
+        for (int t = tid; t < p.K; t += NT) s_yz[t] = p.yz_t[t];
+#pragma unroll 4
+        for (int t = tid; t < p.K; t += NT) s_c[t] = p.c_t[t];
+    }
+    __syncthreads();
+
+    const KT *xy = STAGE >= 1 ? s_xy : p.xy_g;
+    const int32_t *rp = STAGE >= 1 ? s_rp : p.row_ptr;
+    const KT *yz = STAGE >= 2 ? s_yz : p.yz_t;
+    const double *cf = STAGE >= 2 ? s_c : p.c_t;
+    int2 *hq = s_hq + wave * HQ_CAP;
+    int32_t *pq = s_pq + wave * PQ_CAP;
+
+    const int64_t blk_begin = (int64_t)blockIdx.x * p.rows_per_block;
+    const int blk_rows = (int)min((int64_t)p.rows_per_block, p.n_rows - blk_begin);
+    const bool filter = p.n_alpha >= 0;
+    const Slot<KT> *__restrict__ tab = p.tab;
+    const double2 *__restrict__ psi = p.psi;
+
+    for (int rl = wave; rl < blk_rows; rl += NWAVES) {
+        const int64_t r = blk_begin + rl;
+        const int64_t i = p.row_begin + r;
+        const KT key = to_sgpr(p.keys[i]);
+        const double2 psi_i = psi[i];
+        double sr = 0.0, si = 0.0;
+
+        // ---- diagonal group: lanes stride its terms
+        if (p.has_diag) {
+            const double h = sign_sum_strided<KT>(key, yz, cf, rp[0], rp[1], lane);
+            sr = h * psi_i.x;
+            si = h * psi_i.y;
+        }
+
+        int qn = 0, pn = 0;                                  // wave-uniform fill of the hit / pass queue
+        // C: one queued (term range, sample) entry per lane
+        auto drain = [&](int first, bool active) {
+            if (active) {
+                const int2 e = hq[first + lane];
+                const double2 pj = psi[e.y];
+                const int t0 = e.x & 0xFFFFFF;
+                const double h = sign_sum<KT>(key, yz, cf, t0, t0 + (int)((uint32_t)e.x >> 24));
+                sr += h * pj.x;
+                si += h * pj.y;
+            }
+        };
+        // hits of one dense pass -> hit queue (every group of this view has <= HEAVY_TERMS terms: one entry per hit)
+        auto push_hits = [&](int g, int idx) {
+            const unsigned long long m = __ballot(idx >= 0);
+            if (m) {
+                if (idx >= 0) {
+                    const int pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    const int t0 = rp[g];
+                    hq[pos] = make_int2(t0 | ((rp[g + 1] - t0) << 24), idx);
+                }
+                qn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= WAVE) {
+                    qn -= WAVE;
+                    drain(qn, true);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        };
+        // B: probe the queued candidates [first, first + 64)
+        auto probe_pass = [&](int first, bool active) {
+            int idx = -1, g = 0;
+            if (active) {
+                g = pq[first + lane];
+                const KT j = key ^ xy[g];
+                if (!BLOOM || naqs::bloom_test<KT>(s_bloom, j)) idx = hash_find<KT>(tab, p.bits, p.tag, j);
+            }
+            push_hits(g, idx);
+        };
+        // A: particle-number filter, one group per lane and pass
+        for (int g0 = p.has_diag; g0 < p.Kxy; g0 += PASS_BATCH * WAVE) {
+#pragma unroll
+            for (int u = 0; u < PASS_BATCH; ++u) {
+                const int g = g0 + u * WAVE + lane;
+                bool ok = false;
+                if (g < p.Kxy) {
+                    const KT j = key ^ xy[g];
+                    ok = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (ok) pq[pn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = g;
+                pn += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            while (pn >= WAVE) {
+                pn -= WAVE;
+                probe_pass(pn, true);
+            }
+        }
+        probe_pass(0, lane < pn);
+        drain(0, lane < qn);
+        __builtin_amdgcn_wave_barrier();
+
+        sr = wave_sum(sr);
+        si = wave_sum(si);
+        if (lane == 0) {
+            if (p.matvec) {
+                p.eloc[r] = make_double2(sr, si);
+            } else {
+                const double2 q = cdiv(make_double2(sr, si), psi_i);
+                p.eloc[r] = make_double2(q.x, -q.y);   // conj, energy.py:248
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weighted reduction (deterministic: fixed grid-stride order + LDS tree), one workgroup
 // ------------------------------------------------------------------------------------------------
 constexpr int RED_BLOCK = 1024;
@@ -446,6 +620,11 @@ struct naqs_ham {
     void *d_xy = nullptr, *d_yz = nullptr;
     int32_t *d_rp = nullptr, *d_col = nullptr;
     double *d_c = nullptr;
+    // eloc_kernel2's view of the same term arrays: every non-diagonal group cut into chunks of <= HEAVY_TERMS terms, each
+    // chunk a group of its own with the parent's flip mask (d_rp2 refines d_rp)
+    int64_t Kxy2 = 0;
+    void *d_xy2 = nullptr;
+    int32_t *d_rp2 = nullptr;
     // scratch
     int64_t cap_M = 0;
     void *d_keys = nullptr;
@@ -501,6 +680,18 @@ int upload_tables(naqs_ham *h, const std::vector<uint64_t> &xy_g, const std::vec
     HIP_TRY(hipMemcpy(h->d_yz, yz_n.data(), yz_n.size() * sizeof(KT), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_rp, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_c, c_t.data(), c_t.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<KT> xy2;
+    std::vector<int32_t> rp2;
+    for (size_t g = 0; g + 1 < rp.size(); ++g) {
+        const int32_t step = (int32_t)g < h->has_diag ? rp[g + 1] - rp[g] : HEAVY_TERMS;
+        for (int32_t t = rp[g]; t < rp[g + 1]; t += std::max(step, 1)) { xy2.push_back(xy_n[g]); rp2.push_back(t); }
+    }
+    rp2.push_back(rp.back());
+    h->Kxy2 = (int64_t)xy2.size();
+    HIP_TRY(hipMalloc(&h->d_xy2, std::max<size_t>(1, xy2.size()) * sizeof(KT)));
+    HIP_TRY(hipMalloc((void **)&h->d_rp2, rp2.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(h->d_xy2, xy2.data(), xy2.size() * sizeof(KT), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_rp2, rp2.data(), rp2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return NAQS_OK;
 }
 
@@ -590,8 +781,12 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
         p.rows_per_block = rpb;
     }
     const int grid2 = (int)((n_rows + rpb - 1) / rpb);
-    const size_t q_bytes = (size_t)nwaves * queue_cap(bloom) * sizeof(int2) + 16;
-    const size_t g_bytes = (size_t)((h->Kxy + 2) & ~1ll) * sizeof(int32_t) + (size_t)h->Kxy * sizeof(KT);
+    // NAQS_ELOC_V=1: the single-compaction kernel (kept for A/B); the term range of a queue entry is 24 + 8 bits
+    const bool v2 = env_int("NAQS_ELOC_V", 2) != 1 && h->K < (1 << 24);
+    const int64_t Kxy_k = v2 ? h->Kxy2 : h->Kxy;
+    if (v2) { p.xy_g = reinterpret_cast<const KT *>(h->d_xy2); p.row_ptr = h->d_rp2; p.Kxy = (int32_t)h->Kxy2; }
+    const size_t q_bytes = v2 ? queue_bytes_v2(nwaves) : (size_t)nwaves * queue_cap(bloom) * sizeof(int2) + 16;
+    const size_t g_bytes = (size_t)((Kxy_k + 2) & ~1ll) * sizeof(int32_t) + (size_t)Kxy_k * sizeof(KT);
     const size_t t_bytes = (size_t)h->K * (sizeof(double) + sizeof(KT));
     const int force = env_int("NAQS_STAGE", -1);   // tuning/testing: 0 none, 1 groups, 2 groups+terms
     int stage = (q_bytes + g_bytes + t_bytes + b_bytes <= budget) ? 2 : (q_bytes + g_bytes + b_bytes <= budget ? 1 : 0);
@@ -600,12 +795,17 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
 
     const bool prof = h->prof.armed();
     if (prof) { int st = h->prof.begin(s); if (st != NAQS_OK) return st; }
-#define NAQS_LAUNCH(ST, NTHREADS, BL)                                                                               \
+#define NAQS_LAUNCH_K(KERNEL, ST, NTHREADS, BL)                                                                     \
     do {                                                                                                            \
         if (lds > 64 * 1024)  /* above the default dynamic-LDS limit */                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_kernel<KT, ST, NTHREADS, BL>),           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<KT, ST, NTHREADS, BL>),                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);                      \
-        hipLaunchKernelGGL((eloc_kernel<KT, ST, NTHREADS, BL>), dim3(grid2), dim3(NTHREADS), lds, s, p);            \
+        hipLaunchKernelGGL((KERNEL<KT, ST, NTHREADS, BL>), dim3(grid2), dim3(NTHREADS), lds, s, p);                 \
+    } while (0)
+#define NAQS_LAUNCH(ST, NTHREADS, BL)                                                                               \
+    do {                                                                                                            \
+        if (v2) NAQS_LAUNCH_K(eloc_kernel2, ST, NTHREADS, BL);                                                      \
+        else NAQS_LAUNCH_K(eloc_kernel, ST, NTHREADS, BL);                                                          \
     } while (0)
 #define NAQS_LAUNCH_NT(ST)                                          \
     do {                                                            \
@@ -619,6 +819,7 @@ int launch_main(naqs_ham *h, int64_t M, const naqs::ElocFeed &f, int64_t row_beg
     else NAQS_LAUNCH_NT(0);
 #undef NAQS_LAUNCH_NT
 #undef NAQS_LAUNCH
+#undef NAQS_LAUNCH_K
     HIP_TRY(hipGetLastError());
     if (prof) { int st = h->prof.end(s); if (st != NAQS_OK) return st; }
     if (w_dev) {
@@ -758,7 +959,7 @@ NAQS_API int naqs_ham_destroy(naqs_ham_t *h) {
     DeviceGuard guard;
     (void)guard.init(h->device);
     (void)h->prof.enable(0);
-    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_col, h->d_c, h->d_keys, h->d_psi, h->d_tab, h->d_bloom};
+    void *ptrs[] = {h->d_xy, h->d_yz, h->d_rp, h->d_col, h->d_c, h->d_xy2, h->d_rp2, h->d_keys, h->d_psi, h->d_tab, h->d_bloom};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return NAQS_OK;

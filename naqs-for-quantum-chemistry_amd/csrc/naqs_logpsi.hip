@@ -780,6 +780,64 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
     __syncthreads();
 }
 
+// the same (tile, pair) items as a kernel of its own (NAQS_AMP_MODE=2): inside the phase kernel the prologue runs at
+// 2 waves per SIMD on the CUs that own a tile and pays its own latencies (key gather, item round trips, conditionals)
+// in full; here a wave owns one pair and AMPK_TG tiles of 16 samples, there are ceil(M/32) * P independent waves and
+// ~4 of them share a SIMD, so those latencies overlap.  No workgroup barrier: everything is private to the wave.
+// scratch[n][i] = conditional log-amplitude of sample i's outcome at pair n (summed by the phase kernel, block 0..P-1)
+constexpr int AMPK_TG = 2, AMPK_WAVES = 4;
+template <int CT>
+__global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void amp_mfma_kernel(const NetDims d, const ushort_t *__restrict__ wamp, int64_t M,
+                                                                   const uint64_t *__restrict__ keys,
+                                                                   float *__restrict__ scratch, const ElocFeed feed) {
+    constexpr int HLD = CT * 16 + 8;
+    extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = d.P;
+    const int64_t g = (int64_t)blockIdx.x * AMPK_WAVES + wave;
+    const int64_t grp = g / P;
+    const int n = (int)(g - grp * P);
+    const int64_t row0 = grp * (AMPK_TG * 16);
+    if (row0 >= M) return;                                                       // wave-uniform
+    ushort_t *hs = planes + (size_t)wave * (48 * HLD);                           // per wave: 3 planes [16][HLD] bf16
+    float *outs = reinterpret_cast<float *>(planes + (size_t)AMPK_WAVES * (48 * HLD)) + wave * 128;   // [16][8] raw outputs
+    AmpFrag<CT> f;
+    amp_mfma_load<CT>(wamp + (size_t)n * amp_mfma_pair_elems(CT * 16), lane, f);
+    const int64_t i = row0 + (lane & (AMPK_TG * 16 - 1));
+    const uint64_t key = i < M ? keys[i] : 0ull;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        if (k < P) {
+            a |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+            b |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+        }
+    }
+    const uint32_t ab_all = a | (b << 16);
+#pragma unroll
+    for (int t = 0; t < AMPK_TG; ++t) {
+        if (row0 + t * 16 < M) {                                                 // wave-uniform
+            const uint32_t ab = (uint32_t)__shfl((int)ab_all, t * 16 + (lane & 15), 64);
+            amp_mfma_item<CT>(d, f, n, ab, lane, hs, outs);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int64_t i2 = row0 + t * 16 + lane;
+            if (lane < 16 && i2 < M) {
+                float o[5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) o[c] = outs[lane * 8 + c];
+                const uint32_t mask = (1u << n) - 1u;
+                const int occ = (int)((ab >> n) & 1u) + 2 * (int)((ab >> (16 + n)) & 1u);
+                scratch[(int64_t)n * M + i2] = naqs::amp_finish(d, n, o, ab & mask, (ab >> 16) & mask, occ);
+            }
+        }
+    }
+    // fused log-psi + E_loc call: the waves of pair 0 narrow the keys and insert them into the E_loc hash table
+    if (n == 0 && lane < AMPK_TG * 16 && feed.tab != nullptr && i < M) {
+        if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, i, key);
+        else naqs::feed_key<uint64_t>(feed, i, key);
+    }
+}
+
 // SAVE: training forward (inputs and hidden activations also go to HBM); a template parameter because the stores'
 // address arithmetic and bounds branches are ~40 % of the write-back's instructions even when they are skipped
 template <int RB, bool SAVE>
@@ -1164,7 +1222,21 @@ static int pack_blocks(const NetDims &d, const int64_t *src_off, float *dst, con
     return NAQS_OK;
 }
 static int pack_amp_blocks(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
+    net->wamp_fresh = false;
     return pack_blocks(net->dims, net->amp_src_off, net->d_w, flat_dev, s);
+}
+// the amplitude blocks as MFMA fragments (naqs_net_set_weights only: the sampler's naqs_net_set_amp_weights keeps to the
+// VALU rows, and net_amp_forward falls back to amp_kernel while the fragments are stale)
+static int pack_amp_fragments(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
+    if (!net->d_wamp) return NAQS_OK;
+    const NetDims &d = net->dims;
+    AmpSrcOff so;
+    for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
+    const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
+    hipLaunchKernelGGL(pack_amp_mfma_kernel, dim3((frag + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_wamp);
+    HIP_TRY(hipGetLastError());
+    net->wamp_fresh = true;
+    return NAQS_OK;
 }
 
 NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
@@ -1193,6 +1265,8 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack
         st = pack_blocks(net->dph, net->ph_src_off, net->d_wph, flat_dev, s);
         if (st != NAQS_OK) return st;
+        st = pack_amp_fragments(net, flat_dev, s);
+        if (st != NAQS_OK) return st;
         net->have_weights = net->have_amp_weights = net->have_wb = true;
         return NAQS_OK;
     }
@@ -1214,13 +1288,8 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
         hipLaunchKernelGGL(pack_phase_all_kernel, dim3(gx, d.n_lin), dim3(256), 0, s, flat_dev, d, jobs, net->d_w, net->d_wh, with_f32);
         HIP_TRY(hipGetLastError());
     }
-    if (net->d_wamp) {
-        AmpSrcOff so;
-        for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
-        const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
-        hipLaunchKernelGGL(pack_amp_mfma_kernel, dim3((frag + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_wamp);
-        HIP_TRY(hipGetLastError());
-    }
+    st = pack_amp_fragments(net, flat_dev, s);
+    if (st != NAQS_OK) return st;
     st = naqs::net_pack_backward_weights(net, flat_dev, s);
     if (st != NAQS_OK) return st;
     net->have_weights = net->have_amp_weights = true;
@@ -1250,6 +1319,15 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
         net->cap_M = cap;
     }
     const ElocFeed none{};
+    if (net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) != 0) {      // matrix-core form (0: the VALU amp_kernel)
+        const int64_t waves = (M + AMPK_TG * 16 - 1) / (AMPK_TG * 16) * d.P;
+        const unsigned grid = (unsigned)((waves + AMPK_WAVES - 1) / AMPK_WAVES);
+        const size_t lds = (size_t)AMPK_WAVES * (48 * (d.Ha + 8) * sizeof(unsigned short) + 128 * sizeof(float));
+        if (d.Ha == 64) hipLaunchKernelGGL(amp_mfma_kernel<4>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        else hipLaunchKernelGGL(amp_mfma_kernel<2>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        HIP_TRY(hipGetLastError());
+        return NAQS_OK;
+    }
     return launch_amp_kernel(d, net->d_w, M, keys_dev, net->d_scratch, feed ? *feed : none, 0, s);
 }
 
@@ -1287,7 +1365,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;
     // amplitude conditionals inside the phase kernel (matrix cores) unless NAQS_AMP_MODE=0 or the width does not tile
     const size_t amp_scratch = (size_t)PH_WAVES * 48 * (d.Ha + 8) * sizeof(unsigned short) + (size_t)d.P * 48 * 8 * sizeof(float);
-    const bool amp_in_phase = use_h && net->d_wamp != nullptr && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
+    const bool amp_in_phase = use_h && net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
                               amp_scratch <= 3 * lds_h16;
     if (!amp_in_phase) {
         st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);

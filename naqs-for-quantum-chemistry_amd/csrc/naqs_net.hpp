@@ -168,6 +168,7 @@ struct naqs_net {
     int64_t samp_cap = 0;
     uint32_t samp_seq = 0;                  // sampling calls so far: tags the per-workgroup scan words of the fused level kernel
     int cu_count = 256;
+    bool wamp_fresh = false;                // d_wamp was packed from the current parameters
     bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
     bool packed_f32 = false;                // the f32-MFMA weight tiles are current (only packed when phase_kernel will run)
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
