@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NT) void eloc_kernel(const ElocParams<KT> p) {
 // order for a matrix element.  A chunked heavy element is the sum of its chunks' partial sums, each multiplied by
 // psi_j separately (equal to ~1 ulp; the strided form was not sequential either).
 // ------------------------------------------------------------------------------------------------
-constexpr int PASS_BATCH = 2;                              // filter passes between two looks at the pass queue
+constexpr int PASS_BATCH = 3;                              // filter passes between two looks at the pass queue
 constexpr int PQ_CAP = 64 * (PASS_BATCH + 1), HQ_CAP = 128;  // < 64 carried + what one batch / one probe pass can push
 constexpr size_t queue_bytes_v2(int nwaves) { return (size_t)nwaves * (HQ_CAP * sizeof(int2) + PQ_CAP * sizeof(int32_t)) + 16; }
 
@@ -480,22 +480,31 @@ __global__ __launch_bounds__(NT) void eloc_kernel2(const ElocParams<KT> p) {
             }
             push_hits(g, idx);
         };
-        // A: particle-number filter, one group per lane and pass
-        for (int g0 = p.has_diag; g0 < p.Kxy; g0 += PASS_BATCH * WAVE) {
-#pragma unroll
-            for (int u = 0; u < PASS_BATCH; ++u) {
-                const int g = g0 + u * WAVE + lane;
-                bool ok = false;
-                if (g < p.Kxy) {
-                    const KT j = key ^ xy[g];
-                    ok = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
-                }
-                const unsigned long long m = __ballot(ok);
-                if (ok) pq[pn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = g;
-                pn += __popcll(m);
+        // A: particle-number filter, one group per lane and pass; whole batches first (no bound check), then the tail
+        auto filter_pass = [&](int g, bool in_range) {
+            bool ok = false;
+            if (in_range) {
+                const KT j = key ^ xy[g];
+                ok = !filter || (popc((KT)(j & p.alpha_mask)) == p.n_alpha && popc((KT)(j & p.beta_mask)) == p.n_beta);
             }
+            const unsigned long long m = __ballot(ok);
+            if (ok) pq[pn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = g;
+            pn += __popcll(m);
+        };
+        int g0 = p.has_diag;
+        for (; g0 + PASS_BATCH * WAVE <= p.Kxy; g0 += PASS_BATCH * WAVE) {
+#pragma unroll
+            for (int u = 0; u < PASS_BATCH; ++u) filter_pass(g0 + u * WAVE + lane, true);
             __builtin_amdgcn_wave_barrier();
             while (pn >= WAVE) {
+                pn -= WAVE;
+                probe_pass(pn, true);
+            }
+        }
+        for (; g0 < p.Kxy; g0 += WAVE) {
+            filter_pass(g0 + lane, g0 + lane < p.Kxy);
+            __builtin_amdgcn_wave_barrier();
+            if (pn >= WAVE) {
                 pn -= WAVE;
                 probe_pass(pn, true);
             }

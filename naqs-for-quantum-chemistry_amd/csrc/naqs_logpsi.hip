@@ -626,6 +626,14 @@ __device__ __forceinline__ void amp_mfma_load(const ushort_t *__restrict__ wp, i
     f.b2 = reinterpret_cast<const float *>(w2 + (size_t)3 * KC * 512)[lane & 15];
 }
 
+// max(x, 0) in one instruction: fmaxf() canonicalises an operand that is not known to be quiet (a matrix-core result)
+// with a second v_max first; same value for every non-NaN input, and 0 for NaN as fmaxf gives
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // one wave, one (tile of 16 samples, pair n): the block's 5 raw outputs -> outs[sample][8]
 template <int CT>
 __device__ __forceinline__ void amp_mfma_item(const NetDims &d, const AmpFrag<CT> &f, int n, uint32_t ab,
@@ -637,14 +645,19 @@ __device__ __forceinline__ void amp_mfma_item(const NetDims &d, const AmpFrag<CT
         const uint32_t abits = ab & mask, bbits = (ab >> 16) & mask;
         const bool swap = d.sym && abits > bbits;                               // nade.py:519-530
         const uint32_t xbits = (swap ? bbits : abits) | ((swap ? abits : bbits) << n);
-        bf16x8 ax;
-        ushort_t *axu = reinterpret_cast<ushort_t *>(&ax);
+        // this lane's 8 inputs k = 8 kg .. 8 kg + 7 as four bf16 pairs: +-1 for k < 2n (2n is even: a pair is valid or not
+        // as a whole), 0 beyond, and input 31 the constant 1 that carries b1 (2n <= 30)
+        const uint32_t tb = xbits >> (8 * kg);
+        const int nv = min(max(2 * n - 8 * kg, 0), 8) >> 1;
+        uint32_t aw[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 8 * kg + e;
-            axu[e] = k < 2 * n ? (((xbits >> k) & 1u) ? (ushort_t)0x3F80 : (ushort_t)0xBF80)
-                               : (k == 31 ? (ushort_t)0x3F80 : (ushort_t)0);  // input 31 is the constant 1 that carries b1
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = 0xBF80BF80u ^ ((tb << (15 - 2 * j)) & 0x8000u) ^ ((tb << (30 - 2 * j)) & 0x80000000u);
+            aw[j] = j < nv ? w : 0u;
         }
+        if (kg == 3) aw[3] |= 0x3F800000u;
+        bf16x8 ax;
+        __builtin_memcpy(&ax, aw, sizeof(ax));
         f32x4 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -656,10 +669,10 @@ __device__ __forceinline__ void amp_mfma_item(const NetDims &d, const AmpFrag<CT
         for (int r = 0; r < 4; ++r) {                       // D: row = 4 kg + r (sample); tile ct of lane m = hidden unit CT m + ct
             ushort_t *dst = hs + (4 * kg + r) * HLD + CT * m;
             uint32_t a1, a2, a3;
-            split3t_pair(fmaxf(acc[0][r], 0.0f), fmaxf(acc[1][r], 0.0f), a1, a2, a3);
+            split3t_pair(relu1(acc[0][r]), relu1(acc[1][r]), a1, a2, a3);
             if (CT == 4) {
                 uint32_t b1, b2, b3;
-                split3t_pair(fmaxf(acc[2 % CT][r], 0.0f), fmaxf(acc[3 % CT][r], 0.0f), b1, b2, b3);
+                split3t_pair(relu1(acc[2 % CT][r]), relu1(acc[3 % CT][r]), b1, b2, b3);
                 *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
                 *reinterpret_cast<uint2 *>(dst + 16 * HLD) = make_uint2(a2, b2);
                 *reinterpret_cast<uint2 *>(dst + 32 * HLD) = make_uint2(a3, b3);
@@ -725,10 +738,16 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
     AmpFrag<CT> f0, f1;
     int na = q0 < q1 ? q0 / RB : -1, nb = -1;
     const int n_last = q0 < q1 ? (q1 - 1) / RB : -1;
-    if (q0 < q1) amp_mfma_load<CT>(wamp + (size_t)na * pair_elems, lane, f0);
+    // the key load goes out BEFORE the 18 fragment loads of the first pair: vector loads return in order, so behind them
+    // the first barrier would wait for the whole 147 KB the workgroup's waves request (~2.3 k cycles of the CU's 64 B/clk)
+    uint64_t key = 0ull;
+    if (tid < BM && row0 + tid < M) key = keys[row0 + tid];
+    __builtin_amdgcn_sched_barrier(0);
+    // (unconditional — a wave without items fetches pair 0 for nothing: inside a branch the compiler cannot count the
+    // loads that follow the key's and waits for all of them)
+    amp_mfma_load<CT>(wamp + (size_t)max(na, 0) * pair_elems, lane, f0);
+    __builtin_amdgcn_sched_barrier(0);
     if (tid < BM) {                      // model-order occupation strings of the tile's samples; E_loc hand-over of the key
-        const int64_t i = row0 + tid;
-        const uint64_t key = i < M ? keys[i] : 0ull;
         uint32_t a = 0, b = 0;
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {                  // unrolled: the qa/qb look-ups are independent scalar loads
@@ -863,10 +882,20 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
         if (tid < BM && row0 + tid < M)
             for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + row0 + tid];   // fixed order: block 0..P-1
     } else {
+        // touch layer 0's weight planes now (one dword per 128-byte line): their first use is ~20 k cycles away and at
+        // launch start every XCD's L2 misses them; the value only has to stay live until the prologue is over
+        uint32_t warm0 = 0, warm1 = 0;
+        {
+            const uint32_t *w0 = reinterpret_cast<const uint32_t *>(wh + d.wh_off[0]);
+            const int n_dw = 3 * d.N_pad[0] * d.Kh_pad[0] / 2;
+            if (tid * 32 < n_dw) warm0 = w0[tid * 32];
+            if ((tid + PH_THREADS) * 32 < n_dw) warm1 = w0[(tid + PH_THREADS) * 32];
+        }
         // amplitude conditionals of this tile on the matrix cores; the activation planes are still free -> scratch
         if (d.Ha == 64) amp_mfma_prologue<4, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, planes, tid, save.clk);
         else amp_mfma_prologue<2, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, planes, tid, save.clk);
         NAQS_MARK(2);
+        asm volatile("" ::"v"(warm0), "v"(warm1));
         if (tid < BM)
             for (int n = 0; n < P; ++n) la += s_lan[n][tid];                           // fixed order: block 0..P-1
         __syncthreads();                                                                // scratch becomes the activation planes
