@@ -442,6 +442,80 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
     }
 }
 
+// write-back of a wide hidden layer: the accumulators (+ bias, ReLU) go back to the LDS tile as three bf16 planes
+template <int RB, bool SAVE>
+__device__ __forceinline__ void mlp_writeback_h(ushort_t *__restrict__ planes, int ldh, int N_pad, f32x4 (&acc)[RB][CBT],
+                                                const float (&bvs)[CBT], int cb0, int my_cb, bool inter, int wave, int lane,
+                                                float *__restrict__ save, int save_ld, int64_t row0, int64_t M,
+                                                long long *clk) {
+    constexpr int BM = RB * 16;
+    const int m = lane & 15, kg = lane >> 4;
+    const int plane_stride = BM * ldh;
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 9] = clock64();
+    __syncthreads();                                      // everyone is done reading the input
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 10] = clock64();
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the three planes.
+    // Neighbouring lanes hold neighbouring columns: the even lane takes rows 0,1 of both columns and the odd lane rows
+    // 2,3 (two DPP exchanges), so every LDS store is a full dword (two bf16) instead of a 2-byte store — half the
+    // store instructions of the write-back and no sub-dword merging.
+    if (inter && my_cb == CBT) {
+        const int col0 = (cb0 >> 2) * 64 + 4 * m;         // this lane's four adjacent columns: tile c <-> col0 + c
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = fmaxf(acc[rb][c % CBT][r] + bvs[c % CBT], 0.0f);
+                const int row = rb * 16 + kg * 4 + r;
+                if (SAVE && save != nullptr && row0 + row < M)
+                    *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) = (f32x4){h[0], h[1], h[2], h[3]};
+                uint32_t a1, a2, a3, b1, b2, b3;
+                split3t_pair(h[0], h[1], a1, a2, a3);
+                split3t_pair(h[2], h[3], b1, b2, b3);
+                ushort_t *dst = planes + row * ldh + col0;                              // 8-byte aligned
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(dst + 2 * plane_stride) = make_uint2(a3, b3);
+            }
+        __syncthreads();
+        return;
+    }
+    uint32_t *planes32 = reinterpret_cast<uint32_t *>(planes);
+    const int ldw = ldh >> 1, plane_w = plane_stride >> 1;
+    const bool odd = m & 1;
+#pragma unroll
+    for (int c = 0; c < CBT; ++c) {
+        if (c < my_cb) {
+            const int col = (cb0 + c) * 16 + m;
+            const float bv = bvs[c];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h[r] = fmaxf(acc[rb][c][r] + bv, 0.0f);
+                    const int row = rb * 16 + kg * 4 + r;
+                    if (SAVE && save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = h[r];
+                }
+                const float x0 = __shfl_xor(odd ? h[0] : h[2], 1, 64), x1 = __shfl_xor(odd ? h[1] : h[3], 1, 64);
+                const float lo[2] = {odd ? x0 : h[0], odd ? x1 : h[1]}, hi[2] = {odd ? h[2] : x0, odd ? h[3] : x1};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t w1, w2, w3;
+                    split3t_pair(lo[j], hi[j], w1, w2, w3);
+                    const int o = (rb * 16 + kg * 4 + (odd ? 2 : 0) + j) * ldw + (col >> 1);
+                    planes32[o] = w1;
+                    planes32[plane_w + o] = w2;
+                    planes32[2 * plane_w + o] = w3;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+
 // one layer: planes[3][BM][ldh] (bf16) -> planes (hidden layers) or f32 out[BM][16] in the same LDS (last layer)
 template <int RB, bool SAVE>
 __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int ldh, int Kh_pad, int N_pad,
@@ -526,68 +600,47 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
     else if (my_cb == 3) mlp_accumulate_h<RB, (CBT > 3 ? 3 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 2) mlp_accumulate_h<RB, (CBT > 2 ? 2 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     else if (my_cb == 1) mlp_accumulate_h<RB, 1>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
-    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 9] = clock64();
-    __syncthreads();                                      // everyone is done reading the input
-    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 10] = clock64();
-    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the three planes.
-    // Neighbouring lanes hold neighbouring columns: the even lane takes rows 0,1 of both columns and the odd lane rows
-    // 2,3 (two DPP exchanges), so every LDS store is a full dword (two bf16) instead of a 2-byte store — half the
-    // store instructions of the write-back and no sub-dword merging.
-    if (inter && my_cb == CBT) {
-        const int col0 = (cb0 >> 2) * 64 + 4 * m;         // this lane's four adjacent columns: tile c <-> col0 + c
+    mlp_writeback_h<RB, SAVE>(planes, ldh, N_pad, acc, bvs, cb0, my_cb, inter, wave, lane, save, save_ld, row0, M, clk);
+}
+
+// layer 0 of the published shape (one K chunk, all eight waves own CBT column tiles): its weight fragments are requested
+// by the caller BEFORE the input tile is built, so their L2 round trip overlaps the build instead of following it
+template <int RB>
+__device__ __forceinline__ void mlp_layer0_fetch(const NetDims &d, const ushort_t *__restrict__ W, int wave, int lane,
+                                                 bf16x8 (&pre)[3][CBT]) {
+    const int Kh_pad = d.Kh_pad[0];
+    const size_t wplane = (size_t)d.N_pad[0] * Kh_pad;
+    const ushort_t *w_ptr = W + (size_t)(wave * CBT) * Kh_pad * 16 + lane * 8;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float h[4];
+        for (int c = 0; c < CBT; ++c) pre[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + (size_t)c * Kh_pad * 16);
+}
+template <int RB, bool SAVE>
+__device__ __forceinline__ void mlp_layer0_pre(ushort_t *__restrict__ planes, int ldh, int N_pad, const bf16x8 (&pre)[3][CBT],
+                                               const float *__restrict__ bias, int wave, int lane, float *__restrict__ save,
+                                               int save_ld, int64_t row0, int64_t M, long long *clk) {
+    const int m = lane & 15, kg = lane >> 4;
+    const int cb0 = wave * CBT;
+    float bvs[CBT];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) h[c] = fmaxf(acc[rb][c % CBT][r] + bvs[c % CBT], 0.0f);
-                const int row = rb * 16 + kg * 4 + r;
-                if (SAVE && save != nullptr && row0 + row < M)
-                    *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) = (f32x4){h[0], h[1], h[2], h[3]};
-                uint32_t a1, a2, a3, b1, b2, b3;
-                split3t_pair(h[0], h[1], a1, a2, a3);
-                split3t_pair(h[2], h[3], b1, b2, b3);
-                ushort_t *dst = planes + row * ldh + col0;                              // 8-byte aligned
-                *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2 *>(dst + 2 * plane_stride) = make_uint2(a3, b3);
-            }
-        __syncthreads();
-        return;
-    }
-    uint32_t *planes32 = reinterpret_cast<uint32_t *>(planes);
-    const int ldw = ldh >> 1, plane_w = plane_stride >> 1;
-    const bool odd = m & 1;
+    for (int c = 0; c < CBT; ++c) bvs[c] = bias[tile_col(cb0 + c, m, N_pad)];
+    const ushort_t *a_ptr = planes + m * ldh + 8 * kg;
+    f32x4 acc[RB][CBT];
 #pragma unroll
-    for (int c = 0; c < CBT; ++c) {
-        if (c < my_cb) {
-            const int col = (cb0 + c) * 16 + m;
-            const float bv = bvs[c];
+    for (int rb = 0; rb < RB; ++rb) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(a_ptr + rb * 16 * ldh);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                float h[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    h[r] = fmaxf(acc[rb][c][r] + bv, 0.0f);
-                    const int row = rb * 16 + kg * 4 + r;
-                    if (SAVE && save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = h[r];
-                }
-                const float x0 = __shfl_xor(odd ? h[0] : h[2], 1, 64), x1 = __shfl_xor(odd ? h[1] : h[3], 1, 64);
-                const float lo[2] = {odd ? x0 : h[0], odd ? x1 : h[1]}, hi[2] = {odd ? h[2] : x0, odd ? h[3] : x1};
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    uint32_t w1, w2, w3;
-                    split3t_pair(lo[j], hi[j], w1, w2, w3);
-                    const int o = (rb * 16 + kg * 4 + (odd ? 2 : 0) + j) * ldw + (col >> 1);
-                    planes32[o] = w1;
-                    planes32[plane_w + o] = w2;
-                    planes32[2 * plane_w + o] = w3;
-                }
-            }
+        for (int c = 0; c < CBT; ++c) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre[2][c], v, 0, 0, 0);       // smallest terms first
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre[1][c], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre[0][c], v, 0, 0, 0);
+            acc[rb][c] = v;
         }
     }
-    __syncthreads();
+    mlp_writeback_h<RB, SAVE>(planes, ldh, N_pad, acc, bvs, cb0, CBT, CBT == 4 && (N_pad & 63) == 0, wave, lane, save, save_ld,
+                              row0, M, clk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,12 +680,11 @@ __device__ __forceinline__ void amp_mfma_load(const ushort_t *__restrict__ wp, i
 }
 
 // max(x, 0) in one instruction: fmaxf() canonicalises an operand that is not known to be quiet (a matrix-core result)
-// with a second v_max first; same value for every non-NaN input, and 0 for NaN as fmaxf gives
-__device__ __forceinline__ float relu1(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
+// with a second v_max first (and folds a median-of-three the same way).  As integers: a float >= +0 is a non-negative
+// int32 with the same bits, anything with the sign bit set (negative, -0) is a negative int32 -> signed max with 0.
+// (Not inline asm: the compiler does not see an asm's operands when it inserts the wait states between an MFMA and a
+// VALU read of its result, and the read then returns the previous contents of the accumulator — measured.)
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // one wave, one (tile of 16 samples, pair n): the block's 5 raw outputs -> outs[sample][8]
 template <int CT>
@@ -902,6 +954,11 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     }
     NAQS_MARK(3);
 
+    // layer 0's weight fragments go out now; they land while the input tile is built
+    const bool pre0 = d.n_lin > 1 && d.Kh_pad[0] == 32 && d.N_pad[0] == PH_WAVES * CBT * 16;
+    bf16x8 pre[3][CBT];
+    if (pre0) mlp_layer0_fetch<RB>(d, wh + d.wh_off[0], wave, lane, pre);
+
     // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero); one thread builds 8 consecutive inputs of a row
     // and stores them as one 16-byte LDS write per plane (ldh and Kh_pad are multiples of 8)
     const int K0 = d.Kh_pad[0], G0 = K0 >> 3;
@@ -936,7 +993,12 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
     __syncthreads();
 
     NAQS_MARK(4);
-    for (int l = 0; l < d.n_lin; ++l) {
+    if (pre0) {
+        mlp_layer0_pre<RB, SAVE>(planes, ldh, d.N_pad[0], pre, w + d.b_off[0], wave, lane, save.act[0], save.act_ld[0], row0, M,
+                                 save.clk);
+        NAQS_MARK(5);
+    }
+    for (int l = pre0 ? 1 : 0; l < d.n_lin; ++l) {
         mlp_layer_h<RB, SAVE>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
                         l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M, l == 0 ? save.clk : nullptr,
                         /*in_plane0_only=*/l == 0);
