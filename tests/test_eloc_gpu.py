@@ -175,6 +175,23 @@ def test_staging_variants_agree_bitwise(env):
             del os.environ["NAQS_ROWS_PER_BLOCK"]
 
 
+@pytest.mark.parametrize("mol,tag", [("LiH", "c1"), ("H2O", "c1"), ("N2", "c2")])
+def test_single_and_double_compaction_kernels_agree(env, mol, tag):
+    """NAQS_ELOC_V=1 (one compaction: a lane owns a group through filter, probe and push; heavy hits summed by the whole
+    wave) and the default eloc_kernel2 (filter pass queue -> dense probe passes, heavy groups as <= 8-term chunks) are
+    the same sums in a different order: 1e-12 relative, and both within the golden tolerance."""
+    z = golden(f"eloc_{mol}.npz")
+    ham = dev_ham(env, mol)
+    os.environ["NAQS_ELOC_V"] = "1"
+    try:
+        e1 = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+    finally:
+        del os.environ["NAQS_ELOC_V"]
+    e2 = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+    assert rel_err(e1, e2) < 1e-12
+    assert rel_err(e1, z[f"{tag}_eloc_c128"]) < 1e-10 and rel_err(e2, z[f"{tag}_eloc_c128"]) < 1e-10
+
+
 def test_edge_cases(env):
     h = golden("ham_LiH.npz")
     ham = dev_ham(env, "LiH")

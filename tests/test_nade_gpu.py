@@ -76,6 +76,34 @@ def test_fused_log_psi_matches_reference_and_torch(mol):
         assert torch.max(torch.abs(lp_rb - lp_t[:-3])).item() < 2e-5, rb
 
 
+@pytest.mark.parametrize("mol", ["LiH", "N2"])
+def test_amplitude_kernel_forms_agree(mol):
+    """The amplitude conditionals exist in three forms: inside the phase kernel's prologue (default, NAQS_AMP_MODE=1),
+    the same matrix-core items as a kernel of their own (=2: what naqs_net_logamp and the aggregate-phase family use) and
+    the VALU amp_kernel (=0).  1 and 2 run identical arithmetic per (tile, pair) item -> identical log|psi|; 0 is exact
+    f32 FMA chains -> 2e-5; the phase column does not depend on the form at all."""
+    import os
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    fused = FusedLogPsi(wf)
+    keys = keys_to_device(z["eval_keys"], wf.device)
+    res = {}
+    for mode in ("1", "2", "0"):
+        os.environ["NAQS_AMP_MODE"] = mode
+        try:
+            res[mode] = fused.log_psi(keys).clone()
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["NAQS_AMP_MODE"]
+    assert torch.equal(res["1"], res["2"])
+    assert torch.max(torch.abs(res["1"] - res["0"])).item() < 2e-5
+    assert torch.equal(res["1"][:, 1], res["0"][:, 1])
+    assert np.max(np.abs(res["2"].cpu().numpy() - z["eval_log_psi"])) < 5e-5
+
+
 def test_fused_log_psi_unphysical_and_masking_modes():
     from test_nade import make_wf
     from naqs_amd.fused import FusedLogPsi
