@@ -12,9 +12,10 @@ Modes
   default        K independent batches per rank (4 distinct key sets, rotated), `--pipeline` of them in flight on as
                  many HIP streams; with N > 1 every rank owns its own batch stream (weak scaling: the 14 400-state N2
                  space cannot supply N x 10 000 unique samples for one table) and the per-step accumulators [K, 4]
-                 are summed over the ranks by one RCCL all-reduce at the end of the timed region.  After the timed
-                 region the same process also measures, and reports inside the same JSON line,
-                   * `serial`: the step one batch at a time (kernel durations with the GPU to themselves);
+                 are summed over the ranks by one RCCL all-reduce at the end of the timed region.  The same process
+                 also measures, and reports inside the same JSON line,
+                   * `serial` (before the warm-up): the step one batch at a time, 2 000 steps (kernel durations with
+                     the GPU to themselves; also what brings a freshly started GPU to its sustained state);
                    * `config4_row_sharded`: BASELINE config 4 / north_star's split — ONE Li2O table of 50 000 keys,
                      rows sharded over the ranks (below) — so that a 1/2/4/8-GPU sweep of the default command also
                      yields the strong-scaling curve of the sharded table.
@@ -462,8 +463,8 @@ def worker(args):
     # energy accumulators: one row of 4 doubles per step, written by the reduce kernel of that step; with N > 1 GPUs the
     # rows of the whole timed region are summed over the ranks by ONE RCCL all-reduce at its end (few, larger
     # collectives: a per-step 32-byte all-reduce is pure xGMI latency and only a training step needs <E> that early)
-    n_serial = min(args.steps, 200)
-    acc_all = torch.zeros((args.warmup + args.steps + n_serial + 1, 4), dtype=torch.float64, device=dev)
+    n_serial = int(os.environ.get("NAQS_BENCH_NSERIAL", "2000"))
+    acc_all = torch.zeros((args.warmup + args.steps + n_serial + 12, 4), dtype=torch.float64, device=dev)
     n_done = [0]
 
     def step(d_override=None):
@@ -485,12 +486,38 @@ def worker(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The same step one batch at a time (single stream, first handle pair), measured in this same run BEFORE the headline
+    # region: latency of a batch, and the kernels' durations when each has the GPU to itself.  2000 steps (~0.12 s; env
+    # NAQS_BENCH_NSERIAL) whatever --steps says: it is a measurement of its own, and it leaves the GPU in the state a
+    # long-running job sees.  A freshly started process needs ~0.1 s of load before the chip reaches its sustained state:
+    # with a 200-step segment here `--steps 20 --warmup 5` reads 53-54.5 us/step and the serial step 64.5 us; with 2000,
+    # 51.2 and 61.0 — the figures `--steps 400` gives regardless (measured in one gpurun call).
+    # (an event pair costs ~4 us of queue time on its stream: at most every 10th launch of a handle is bracketed, and a
+    # short region — the driver's `--steps 20` is 10 launches per handle — gets two brackets per handle, not one per step)
+    stride = max(1, min(PROF_STRIDE, (args.steps // depth) // 2))
+    serial = None
+    if depth > 1 and not args.no_serial_segment:
+        for _ in range(min(args.warmup, 10)):
+            step(0)
+        fence()
+        hams[0].prof_enable(n_serial // PROF_STRIDE + 1, PROF_STRIDE)
+        nets[0].prof_enable(n_serial // PROF_STRIDE + 1, PROF_STRIDE)
+        t1 = time.perf_counter()
+        for _ in range(n_serial):
+            step(0)
+        fence()
+        dts = time.perf_counter() - t1
+        e_ms, e_n = hams[0].prof_read(); hams[0].prof_enable(0)
+        p_ms, p_n = nets[0].prof_read(); nets[0].prof_enable(0)
+        serial = {"ms_per_step": dts / n_serial * 1e3, "steps": n_serial, "eloc_kernel_us": e_ms / max(e_n, 1) * 1e3,
+                  "logpsi_kernel_us": p_ms / max(p_n, 1) * 1e3, "measured": "this run, before the timed region"}
+
+    first_warm = n_done[0]
     for _ in range(args.warmup):
         step()
-    fence(first_row=0)                           # (also sets the communicator up outside the timed region)
+    fence(first_row=first_warm)                  # (also sets the communicator up outside the timed region)
     # kernel durations: hipEvent pairs on the launch stream around every PROF_STRIDE-th launch of the timed
     # region (an event pair costs ~4 us of queue time; recording all of them slows the step by ~15 %)
-    stride = max(1, min(PROF_STRIDE, args.steps // 8))
     for h_, n_ in zip(hams, nets):
         h_.prof_enable(args.steps // stride + 1, stride)
         n_.prof_enable(args.steps // stride + 1, stride)
@@ -507,22 +534,6 @@ def worker(args):
         h_.prof_enable(0)
         a, b = n_.prof_read(); mlp_ms += a; mlp_launches += b
         n_.prof_enable(0)
-    # the same step one batch at a time (single stream, first handle pair), measured in this same run: latency of a
-    # batch, and the kernels' durations when each has the GPU to itself
-    serial = None
-    if depth > 1 and not args.no_serial_segment:
-        hams[0].prof_enable(n_serial // stride + 1, stride)
-        nets[0].prof_enable(n_serial // stride + 1, stride)
-        t1 = time.perf_counter()
-        for _ in range(n_serial):
-            step(0)
-        fence()
-        dts = time.perf_counter() - t1
-        e_ms, e_n = hams[0].prof_read(); hams[0].prof_enable(0)
-        p_ms, p_n = nets[0].prof_read(); nets[0].prof_enable(0)
-        serial = {"ms_per_step": dts / n_serial * 1e3, "steps": n_serial, "eloc_kernel_us": e_ms / max(e_n, 1) * 1e3,
-                  "logpsi_kernel_us": p_ms / max(p_n, 1) * 1e3, "measured": "this run, after the timed region"}
-
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -715,7 +726,7 @@ def parse(argv=None):
                          "the ranks, all-gather of log psi + all-reduce of the accumulators per step (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-segment", action="store_true",
-                    help="skip the one-batch-at-a-time segment that follows the timed region (`serial`, `roofline.isolated`)")
+                    help="skip the one-batch-at-a-time segment that precedes the timed region (`serial`, `roofline.isolated`)")
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the secondary row-sharded Li2O 50 000 table that follows the timed region (`config4_row_sharded`)")
     ap.add_argument("--pipeline", type=int, default=2,
