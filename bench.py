@@ -315,12 +315,12 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
         if use_dist:
             pending.append(dist.all_reduce(acc[i], async_op=True))            # 32 B; overlaps the next step's kernels
 
-    def fence():
+    def fence(barrier=True):
         for w_ in pending:
             w_.wait()
         pending.clear()
         torch.cuda.synchronize()
-        if use_dist:
+        if use_dist and barrier:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -333,8 +333,10 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
-    fence()
+    fence(barrier=False)          # the last step's all-reduce is the closing barrier (every rank must have entered it)
     dt = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
     e_ms, e_n = ham.prof_read(); ham.prof_enable(0)
     p_ms, p_n = net.prof_read(); net.prof_enable(0)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -525,8 +527,16 @@ def worker(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence(first_row=first_timed)
+    # closing bracket: this rank's streams drained, then the job's ONE collective — an all-reduce is a barrier (no rank's
+    # call completes before every rank has entered it), so a separate dist.barrier() would only add a second collective's
+    # latency to a region that may be 1 ms long; MAX over the ranks' clocks below
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.all_reduce(acc_all[first_timed:n_done[0]])
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
     last_row = n_done[0] - 1
     kern_ms = launches = mlp_ms = mlp_launches = 0
     for h_, n_ in zip(hams, nets):
