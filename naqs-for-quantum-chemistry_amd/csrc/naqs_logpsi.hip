@@ -1039,9 +1039,8 @@ __device__ __forceinline__ void pack_phase_bf16(const float *__restrict__ src, i
 struct AmpSrcOff { int64_t off[MAXP]; };
 
 // amplitude blocks as MFMA operand fragments (3 bf16 planes): per pair W1 [3][Ha/16][64][8] then W2 [3][Ha/32][64][8]
-__global__ __launch_bounds__(256) void pack_amp_mfma_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
-                                                            ushort_t *__restrict__ wamp) {
-    const int n = blockIdx.y;
+__device__ __forceinline__ void pack_amp_mfma_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
+                                                   ushort_t *__restrict__ wamp, const int n) {
     const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
     const int CT = Ha >> 4, KC = Ha >> 5;
     const float *src = flat + so.off[n];
@@ -1073,10 +1072,14 @@ __global__ __launch_bounds__(256) void pack_amp_mfma_kernel(const float *__restr
     }
 }
 
+__global__ __launch_bounds__(256) void pack_amp_mfma_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
+                                                            ushort_t *__restrict__ wamp) {
+    pack_amp_mfma_body(flat, d, so, wamp, blockIdx.y);
+}
+
 // every amplitude block in one launch: blockIdx.y = pair n, rows [W1[j][:] | b1[j] | W2[:][j] | pad] + b2
-__global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
-                                                       float *__restrict__ w) {
-    const int n = blockIdx.y;
+__device__ __forceinline__ void pack_amp_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
+                                              float *__restrict__ w, const int n) {
     const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
     const float *src = flat + so.off[n];
     float *dst = w + d.amp_off[n];
@@ -1093,6 +1096,11 @@ __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__
         }
         dst[e] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
+                                                       float *__restrict__ w) {
+    pack_amp_body(flat, d, so, w, blockIdx.y);
 }
 
 __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
@@ -1114,9 +1122,8 @@ __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, in
 
 // every phase layer in one launch (blockIdx.y = layer): f32 MFMA tiles + bias, and the three bf16 planes
 struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
-__global__ __launch_bounds__(256) void pack_phase_all_kernel(const float *__restrict__ flat, const NetDims d, const PhasePackJobs jobs,
-                                                             float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32) {
-    const int l = blockIdx.y;
+__device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
+                                                float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32, const int l) {
     const float *src = flat + jobs.src_off[l];
     if (with_f32) pack_phase_f32(src, jobs.K[l], jobs.N[l], d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l]);
     else {                                              // the bf16x3 kernel only needs the (padded) bias from this buffer
@@ -1124,6 +1131,35 @@ __global__ __launch_bounds__(256) void pack_phase_all_kernel(const float *__rest
             w[d.b_off[l] + n] = n < jobs.N[l] ? src[jobs.N[l] * jobs.K[l] + n] : 0.0f;
     }
     pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
+}
+__global__ __launch_bounds__(256) void pack_phase_all_kernel(const float *__restrict__ flat, const NetDims d, const PhasePackJobs jobs,
+                                                             float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32) {
+    pack_phase_body(flat, d, jobs, w, wh, with_f32, blockIdx.y);
+}
+
+// naqs_net_set_weights of the single-phase network in ONE launch (it runs once per training step, and every launch of a
+// few thousand elements costs its 4-5 us): blockIdx.y walks the amplitude rows (P jobs), the amplitude fragments (P), the
+// phase layers (n_lin) and the row-major copies the backward GEMMs read (naqs::WbPackJobs, from naqs_phase_grad.hip)
+__global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
+                                                       const PhasePackJobs jobs, const naqs::WbPackJobs wb, float *__restrict__ w,
+                                                       ushort_t *__restrict__ wh, ushort_t *__restrict__ wamp, const int with_f32) {
+    int y = blockIdx.y;
+    if (y < d.P) { pack_amp_body(flat, d, so, w, y); return; }
+    y -= d.P;
+    if (wamp != nullptr) {
+        if (y < d.P) { pack_amp_mfma_body(flat, d, so, wamp, y); return; }
+        y -= d.P;
+    }
+    if (y < d.n_lin) { pack_phase_body(flat, d, jobs, w, wh, with_f32, y); return; }
+    y -= d.n_lin;
+    if (y < wb.n) {
+        const int total = wb.Np[y] * wb.Kp[y];
+        const float *src = flat + wb.src_off[y];
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            const int n = e / wb.Kp[y], k = e - n * wb.Kp[y];
+            wb.dst[y][e] = (n < wb.N[y] && k < wb.K[y]) ? src[n * wb.K[y] + k] : 0.0f;
+        }
+    }
 }
 
 }  // namespace
@@ -1351,9 +1387,9 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const NetDims &d = net->dims;
     net->have_weights = net->have_amp_weights = net->have_wb = false;
-    st = pack_amp_blocks(net, flat_dev, s);
-    if (st != NAQS_OK) return st;
     if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack
+        st = pack_amp_blocks(net, flat_dev, s);
+        if (st != NAQS_OK) return st;
         st = pack_blocks(net->dph, net->ph_src_off, net->d_wph, flat_dev, s);
         if (st != NAQS_OK) return st;
         st = pack_amp_fragments(net, flat_dev, s);
@@ -1363,7 +1399,7 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     }
     {
         PhasePackJobs jobs{};
-        int biggest = 0;
+        int biggest = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;                 // an amplitude block's packed rows
         for (int l = 0; l < d.n_lin; ++l) {
             jobs.src_off[l] = net->phase_src_off[(size_t)l];
             jobs.K[l] = net->phase_K[(size_t)l];
@@ -1375,14 +1411,21 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
                            3 * (3 * 16 * (size_t)d.ldh * sizeof(unsigned short)) <= 160 * 1024;      // as in net_logpsi_impl
         const int with_f32 = use_h ? 0 : 1;
         net->packed_f32 = with_f32 != 0;
+        naqs::WbPackJobs wb{};
+        st = naqs::net_backward_pack_jobs(net, &wb);
+        if (st != NAQS_OK) return st;
+        for (int i = 0; i < wb.n; ++i) biggest = std::max(biggest, wb.Np[i] * wb.Kp[i]);
+        AmpSrcOff so;
+        for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
         const int gx = std::min(256, (biggest + 255) / 256);
-        hipLaunchKernelGGL(pack_phase_all_kernel, dim3(gx, d.n_lin), dim3(256), 0, s, flat_dev, d, jobs, net->d_w, net->d_wh, with_f32);
+        const int gy = d.P + (net->d_wamp ? d.P : 0) + d.n_lin + wb.n;
+        net->wamp_fresh = false;
+        hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
+                           with_f32);
         HIP_TRY(hipGetLastError());
+        net->wamp_fresh = net->d_wamp != nullptr;
+        net->have_wb = true;
     }
-    st = pack_amp_fragments(net, flat_dev, s);
-    if (st != NAQS_OK) return st;
-    st = naqs::net_pack_backward_weights(net, flat_dev, s);
-    if (st != NAQS_OK) return st;
     net->have_weights = net->have_amp_weights = true;
     return NAQS_OK;
 }

@@ -194,8 +194,15 @@ struct PhaseSave {
 // naqs_logpsi.hip: amp_kernel + phase kernel -> (log|psi|, phase)
 int net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
                     const ElocFeed &feed, const PhaseSave &save);
-// naqs_phase_grad.hip: row-major padded copies of the phase weights for the backward GEMMs
-int net_pack_backward_weights(naqs_net *net, const float *flat_dev, hipStream_t s);
+// naqs_phase_grad.hip: row-major padded copies of the phase weights for the backward GEMMs — described as jobs for the
+// one packing launch of naqs_net_set_weights (allocates the destination on first use)
+struct WbPackJobs {
+    int n = 0;
+    int64_t src_off[MAXL] = {};
+    int32_t N[MAXL] = {}, K[MAXL] = {}, Np[MAXL] = {}, Kp[MAXL] = {};
+    float *dst[MAXL] = {};
+};
+int net_backward_pack_jobs(naqs_net *net, WbPackJobs *jobs);
 // naqs_grad.hip: d/d theta sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks, or the phase blocks of an
 // aggregate-phase network with raw = 1); grad_dev receives n_block_params floats in state_dict order
 int net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const int64_t *src_off, int64_t n_block_params,

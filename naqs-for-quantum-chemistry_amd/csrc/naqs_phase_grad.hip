@@ -208,15 +208,6 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
             }
 }
 
-// phase weights, row-major and zero-padded to multiples of 64 in both dimensions: Wb_l [Np][Kp]
-__global__ __launch_bounds__(256) void pack_wb_kernel(const float *__restrict__ src, const int N, const int K, const int Np,
-                                                      const int Kp, float *__restrict__ dst) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Np * Kp) return;
-    const int n = e / Kp, k = e - n * Kp;
-    dst[e] = (n < N && k < K) ? src[n * K + k] : 0.0f;
-}
-
 struct TrainLayout {            // carve-up of net->d_train for `cap` rows
     size_t x, act[MAXL], delta[2], top, g_amp, cpart, bpart, total;
     int x_ld, act_ld[MAXL], top_ld, max_ld;
@@ -279,18 +270,21 @@ size_t wb_offset(const naqs_net *net, int l) {
 }  // namespace
 
 // called by naqs_net_set_weights (naqs_logpsi.hip): row-major padded copies of the phase weights for grad_in_kernel
-int naqs::net_pack_backward_weights(naqs_net *net, const float *flat_dev, hipStream_t s) {
+// phase weights, row-major and zero-padded to multiples of 64 in both dimensions (Wb_l [Np][Kp]): what the packing
+// launch of naqs_net_set_weights has to copy (layer 0 has no delta to propagate)
+int naqs::net_backward_pack_jobs(naqs_net *net, naqs::WbPackJobs *jobs) {
     const NetDims &d = net->dims;
     if (!net->d_wb) {
         HIP_TRY(hipMalloc((void **)&net->d_wb, wb_offset(net, d.n_lin) * sizeof(float)));
     }
-    for (int l = 1; l < d.n_lin; ++l) {                     // layer 0 has no delta to propagate
-        const int N = net->phase_N[(size_t)l], K = net->phase_K[(size_t)l], Np = pad64(N), Kp = pad64(K);
-        hipLaunchKernelGGL(pack_wb_kernel, dim3((Np * Kp + 255) / 256), dim3(256), 0, s, flat_dev + net->phase_src_off[(size_t)l], N, K,
-                           Np, Kp, net->d_wb + wb_offset(net, l));
-        HIP_TRY(hipGetLastError());
+    jobs->n = 0;
+    for (int l = 1; l < d.n_lin; ++l) {
+        const int i = jobs->n++;
+        jobs->src_off[i] = net->phase_src_off[(size_t)l];
+        jobs->N[i] = net->phase_N[(size_t)l]; jobs->K[i] = net->phase_K[(size_t)l];
+        jobs->Np[i] = pad64(jobs->N[i]); jobs->Kp[i] = pad64(jobs->K[i]);
+        jobs->dst[i] = net->d_wb + wb_offset(net, l);
     }
-    net->have_wb = true;
     return NAQS_OK;
 }
 
