@@ -258,6 +258,19 @@ def test_64bit_keys(env, filtered):
     want = O.eloc_matrix_free(xy, yz, cf, keys, psi)
     assert np.count_nonzero(np.abs(want) > 0) > 100
     assert rel_err(e, want) < 1e-10
+    # the other code paths of the 64-bit instantiations: Bloom filter in LDS (needs the 1024-thread workgroup), the
+    # single-compaction kernel, both
+    for extra in ({"NAQS_BLOOM": "1", "NAQS_BLOCK": "1024"}, {"NAQS_ELOC_V": "1"},
+                  {"NAQS_ELOC_V": "1", "NAQS_BLOOM": "1", "NAQS_BLOCK": "1024"}):
+        os.environ.update(extra)
+        try:
+            e2 = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+        finally:
+            for k in extra:
+                del os.environ[k]
+        assert rel_err(e2, want) < 1e-10, extra
+        if "NAQS_ELOC_V" not in extra:
+            assert np.array_equal(e2, e), extra                      # the filter may only skip look-ups that would miss
 
 
 def test_li2o_subset_vs_oracle(env):
