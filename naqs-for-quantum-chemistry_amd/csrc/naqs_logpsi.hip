@@ -1120,7 +1120,7 @@ __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, in
     }
 }
 
-// every phase layer in one launch (blockIdx.y = layer): f32 MFMA tiles + bias, and the three bf16 planes
+// one phase layer: f32 MFMA tiles + bias, and the three bf16 planes
 struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
 __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
                                                 float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32, const int l) {
@@ -1132,11 +1132,6 @@ __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, 
     }
     pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
 }
-__global__ __launch_bounds__(256) void pack_phase_all_kernel(const float *__restrict__ flat, const NetDims d, const PhasePackJobs jobs,
-                                                             float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32) {
-    pack_phase_body(flat, d, jobs, w, wh, with_f32, blockIdx.y);
-}
-
 // naqs_net_set_weights of the single-phase network in ONE launch (it runs once per training step, and every launch of a
 // few thousand elements costs its 4-5 us): blockIdx.y walks the amplitude rows (P jobs), the amplitude fragments (P), the
 // phase layers (n_lin) and the row-major copies the backward GEMMs read (naqs::WbPackJobs, from naqs_phase_grad.hip)
