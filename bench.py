@@ -273,8 +273,10 @@ def dry_run(args, world, rank):
 # ------------------------------------------------------------------------------------------------------------------
 # the row-sharded table (config 4 / north_star's split)
 # ------------------------------------------------------------------------------------------------------------------
-def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
-    """-> dict with ms_per_step, samples/s and the kernel durations of one sharded table of M keys."""
+def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup, depth=2, streams=None):
+    """-> dict with ms_per_step, samples/s and the kernel durations of one sharded table of M keys.  `depth` evaluations
+    of the table are in flight (one HIP stream and one handle pair each, as in the default mode): the E_loc kernel and the
+    collectives of one overlap the log-psi kernel of the next."""
     import torch
     import torch.distributed as dist
     from naqs_amd import hamiltonian, packing
@@ -289,33 +291,55 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
     hil = Hilbert.get(ham_p.n_qubits, ham_p.n_alpha, ham_p.n_beta, encoding=Encoding.SIGNED)
     wf_args = published_ansatz(ham_p)
     wf = NAQSComplex_NADE_orbitals(hil, device=dev, **wf_args)
-    net = FusedLogPsi(wf)
+    depth = max(1, depth)
+    hams = [ham] + [hamiltonian.DevicePauliHamiltonian(ham_p, device=dev) for _ in range(depth - 1)]
+    nets = [FusedLogPsi(wf) for _ in range(depth)]
+    # (the caller's streams when it has some: the runtime multiplexes HIP streams onto a few hardware queues — 4 by
+    # default — and two streams that land on one queue run one after the other; with the default mode's two streams still
+    # alive, two fresh ones for this table shared a queue and nothing overlapped)
+    if streams is None or len(streams) < depth:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream(dev)]
     S, b, e = shard_rows(M, rank, world)
     pad = S * world - M
     keys_pad = torch.cat([keys, keys[:pad]]) if pad else keys
     my_keys = keys_pad[rank * S:(rank + 1) * S].contiguous()
-    lp_mine = torch.empty((S, 2), dtype=torch.float32, device=dev)
-    table = torch.empty((S * world, 2), dtype=torch.float32, device=dev)
+    lp_mine = [torch.empty((S, 2), dtype=torch.float32, device=dev) for _ in range(depth)]
+    table = [torch.empty((S * world, 2), dtype=torch.float32, device=dev) for _ in range(depth)]
     weights = torch.as_tensor(counts_np / counts_np.sum(), dtype=torch.float64, device=dev)
     w_mine = weights[b:e].contiguous()
-    eloc = torch.empty((max(e - b, 0), 2), dtype=torch.float64, device=dev)
+    eloc = [torch.empty((max(e - b, 0), 2), dtype=torch.float64, device=dev) for _ in range(depth)]
     acc = torch.zeros((warmup + steps, 4), dtype=torch.float64, device=dev)
-    ham.reserve(M)
-    pending = []
+    for h_ in hams:
+        h_.reserve(M)
+    torch.cuda.synchronize()
+    pending, to_reduce = [], []
 
     def step(i):
-        net.log_psi(my_keys, out=lp_mine)                                     # my rows of the table
+        d = i % depth
+        with torch.cuda.stream(streams[d]):
+            nets[d].log_psi(my_keys, out=lp_mine[d])                          # my rows of the table
+            if use_dist:
+                dist.all_gather_into_tensor(table[d], lp_mine[d])             # the exchange step: M x 8 B in all
+                lp_table = table[d]
+            else:
+                lp_table = lp_mine[d]
+            hams[d].local_energy(keys, lp_table[:M], kind="log_psi", row_begin=b, n_rows=e - b, weights=w_mine, out=eloc[d],
+                                 sums_out=acc[i])
+        # the all-reduce of a step is issued one step late: torch runs a communicator's collectives in issue order on one
+        # internal stream, and a reduce that waits for this step's E_loc would hold back the NEXT step's all-gather there
+        # (measured at RCCL world 1: no overlap at all, 0.54 ms/step at any depth)
         if use_dist:
-            dist.all_gather_into_tensor(table, lp_mine)                       # the exchange step: M x 8 B in all
-            lp_table = table
-        else:
-            lp_table = lp_mine
-        ham.local_energy(keys, lp_table[:M], kind="log_psi", row_begin=b, n_rows=e - b, weights=w_mine, out=eloc,
-                         sums_out=acc[i])
-        if use_dist:
-            pending.append(dist.all_reduce(acc[i], async_op=True))            # 32 B; overlaps the next step's kernels
+            to_reduce.append((i, d))
+            while len(to_reduce) > depth - 1:
+                reduce_step(*to_reduce.pop(0))
+
+    def reduce_step(i, d):
+        with torch.cuda.stream(streams[d]):
+            pending.append(dist.all_reduce(acc[i], async_op=True))            # 32 B
 
     def fence(barrier=True):
+        while to_reduce:
+            reduce_step(*to_reduce.pop(0))
         for w_ in pending:
             w_.wait()
         pending.clear()
@@ -327,9 +351,10 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
     for i in range(warmup):
         step(i)
     fence()
-    stride = max(1, min(PROF_STRIDE, steps // 8))
-    ham.prof_enable(steps // stride + 1, stride)
-    net.prof_enable(steps // stride + 1, stride)
+    stride = max(1, min(PROF_STRIDE, (steps // depth) // 4))
+    for h_, n_ in zip(hams, nets):
+        h_.prof_enable(steps // stride + 1, stride)
+        n_.prof_enable(steps // stride + 1, stride)
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
@@ -337,8 +362,10 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
     dt = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
-    e_ms, e_n = ham.prof_read(); ham.prof_enable(0)
-    p_ms, p_n = net.prof_read(); net.prof_enable(0)
+    e_ms = e_n = p_ms = p_n = 0
+    for h_, n_ in zip(hams, nets):
+        a_, b_ = h_.prof_read(); e_ms += a_; e_n += b_; h_.prof_enable(0)
+        a_, b_ = n_.prof_read(); p_ms += a_; p_n += b_; n_.prof_enable(0)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist and world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -349,6 +376,7 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
                        f"samples, rows sharded over {world} rank(s)",
            "value": M * steps / dt, "unit": "unique samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "warmup": warmup, "scaling": "strong", "rows_per_rank": int(e - b), "logpsi_rows_per_rank": int(S),
+           "pipeline": f"{depth} evaluation(s) of the table in flight on {depth} HIP stream(s)",
            "collectives_per_step": (f"1 all-gather of the (log|psi|, phase) table ({M * 8} B in all) + 1 all-reduce of 4 "
                                     f"accumulators (32 B), {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}, "
                                     f"{dist.get_world_size()} rank(s)") if use_dist else "none (single process)",
@@ -359,8 +387,10 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup):
     issue = issue_roofline(f"{molecule}_{M}", t_eloc) if world == 1 else None
     if issue:
         res["eloc_issue"] = issue
-    ham.close()
-    net.close()
+    for h_ in hams:
+        h_.close()
+    for n_ in nets:
+        n_.close()
     return res, (ham_p, keys_np, log_psi_np, wf_args)
 
 
@@ -559,7 +589,7 @@ def worker(args):
     if not args.no_config4 and args.molecule == "N2":
         try:
             config4, _ = run_row_sharded(dev, world, rank, use_dist, "Li2O", 50000, steps=max(20, min(args.steps, 100)),
-                                         warmup=max(2, min(args.warmup, 10)))
+                                         warmup=max(2, min(args.warmup, 10)), depth=depth, streams=streams)
         except Exception as ex:                                          # the headline must survive a secondary failure
             config4 = {"error": f"{type(ex).__name__}: {ex}"}
 
@@ -667,7 +697,7 @@ def sharded_main(args, dev, world, rank, use_dist):
     """--shard rows: the sharded table is the measurement (BASELINE config 4 with --molecule Li2O --samples 50000)."""
     import torch.distributed as dist
     res, (ham_p, keys_np, log_psi_np, wf_args) = run_row_sharded(dev, world, rank, use_dist, args.molecule, args.samples,
-                                                                 args.steps, args.warmup)
+                                                                 args.steps, args.warmup, depth=max(1, args.pipeline))
     out = None
     if rank == 0:
         t_eloc, t_lp = res["eloc_kernel_us"] * 1e-6, res["logpsi_kernel_us"] * 1e-6
