@@ -588,7 +588,7 @@ def worker(args):
     config4 = None
     if not args.no_config4 and args.molecule == "N2":
         try:
-            config4, _ = run_row_sharded(dev, world, rank, use_dist, "Li2O", 50000, steps=max(20, min(args.steps, 100)),
+            config4, _ = run_row_sharded(dev, world, rank, use_dist, "Li2O", 50000, steps=max(50, min(args.steps, 100)),
                                          warmup=max(2, min(args.warmup, 10)), depth=depth, streams=streams)
         except Exception as ex:                                          # the headline must survive a secondary failure
             config4 = {"error": f"{type(ex).__name__}: {ex}"}
