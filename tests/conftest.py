@@ -48,3 +48,28 @@ def golden(name):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def dense_pauli_case(N=6, n_terms=60, seed=5):
+    """A random real-symmetric qubit Hamiltonian as (terms dict, dense 2^N x 2^N matrix): Pauli strings with an even number
+    of Y, qubit q <-> bit q of the basis index, |1> = occupied; the dense matrix is the sum of Kronecker products."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    sig = {"I": np.eye(2, dtype=complex), "X": np.array([[0, 1], [1, 0]], complex),
+           "Y": np.array([[0, -1j], [1j, 0]], complex), "Z": np.array([[1, 0], [0, -1]], complex)}
+    terms, dense = {}, np.zeros((1 << N, 1 << N), complex)
+    while len(terms) < n_terms:
+        ops = rs.choice(list("IXYZ"), size=N, p=[0.4, 0.2, 0.2, 0.2])
+        if (ops == "Y").sum() % 2:
+            continue
+        key = tuple((q, str(o)) for q, o in enumerate(ops) if o != "I")
+        if key in terms:
+            continue
+        c = float(rs.normal())
+        terms[key] = c + 0j
+        m = np.eye(1, dtype=complex)
+        for q in range(N):                                  # bit q is the q-th least significant: kron from the top down
+            m = np.kron(sig[str(ops[q])], m)
+        dense += c * m
+    assert np.max(np.abs(dense.imag)) == 0.0 and np.max(np.abs(dense - dense.T)) < 1e-12
+    return terms, dense.real, rs

@@ -192,6 +192,22 @@ def test_single_and_double_compaction_kernels_agree(env, mol, tag):
     assert rel_err(e1, z[f"{tag}_eloc_c128"]) < 1e-10 and rel_err(e2, z[f"{tag}_eloc_c128"]) < 1e-10
 
 
+def test_eloc_against_dense_pauli_algebra(env):
+    """The HIP path against linear algebra, with neither the oracle nor the reference in between: a random real-symmetric
+    qubit Hamiltonian as a dense matrix of Kronecker products, restricted to a random sample set (no particle filter)."""
+    from conftest import dense_pauli_case
+    N = 6
+    terms, dense, rs = dense_pauli_case(N)
+    ham = env["H"].DevicePauliHamiltonian(env["P"].pack_qubit_hamiltonian(terms, N, -1, -1))
+    for M in (1 << N, 40):
+        keys = np.sort(rs.choice(1 << N, size=M, replace=False)).astype(np.uint64)
+        psi = rs.normal(size=M) + 1j * rs.normal(size=M)
+        sub = dense[np.ix_(keys.astype(int), keys.astype(int))]
+        want = np.conj(sub @ psi / psi)
+        e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+        assert np.max(np.abs(e - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
 def test_edge_cases(env):
     h = golden("ham_LiH.npz")
     ham = dev_ham(env, "LiH")

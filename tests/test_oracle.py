@@ -155,33 +155,16 @@ def test_eloc_against_dense_pauli_algebra():
     XY / YZ masks, coupling Re(i^nY) c) + the matrix-free formula H[i, i ^ xy] = sum c (-1)^popcount(i & yz).  Strings with
     an even number of Y are real matrices and must agree exactly; strings with an odd number are anti-symmetric imaginary
     matrices, which the reference drops (coupling 0) — checked separately."""
-    import itertools
     import sys
+    from conftest import dense_pauli_case
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "naqs-for-quantum-chemistry_amd"))
     from naqs_amd import packing
     N = 6
-    rs = np.random.RandomState(5)
-    sig = {"I": np.eye(2, dtype=complex), "X": np.array([[0, 1], [1, 0]], complex),
-           "Y": np.array([[0, -1j], [1j, 0]], complex), "Z": np.array([[1, 0], [0, -1]], complex)}
-    terms, dense = {}, np.zeros((1 << N, 1 << N), complex)
-    while len(terms) < 60:
-        ops = rs.choice(list("IXYZ"), size=N, p=[0.4, 0.2, 0.2, 0.2])
-        if (ops == "Y").sum() % 2:
-            continue
-        key = tuple((q, str(o)) for q, o in enumerate(ops) if o != "I")
-        if key in terms:
-            continue
-        c = float(rs.normal())
-        terms[key] = c + 0j
-        m = np.eye(1, dtype=complex)
-        for q in range(N):                                  # bit q is the q-th least significant: kron from the top down
-            m = np.kron(sig[str(ops[q])], m)
-        dense += c * m
-    assert np.max(np.abs(dense.imag)) == 0.0 and np.max(np.abs(dense - dense.T)) < 1e-12
+    terms, dense, rs = dense_pauli_case(N)
     ham = packing.pack_qubit_hamiltonian(terms, N, -1, -1)
     keys = np.sort(rs.choice(1 << N, size=40, replace=False)).astype(np.uint64)
     psi = rs.normal(size=40) + 1j * rs.normal(size=40)
-    sub = dense.real[np.ix_(keys.astype(int), keys.astype(int))]
+    sub = dense[np.ix_(keys.astype(int), keys.astype(int))]
     want = np.conj(sub @ psi / psi)
     got = oracle.eloc_matrix_free(ham.xy, ham.yz, ham.coeff, keys, psi)
     assert np.max(np.abs(got - want)) < 1e-12
