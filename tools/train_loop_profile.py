@@ -21,9 +21,13 @@ with contextlib.redirect_stdout(io.StringIO()):
     mol, qh = load_molecule(mol_f)
 na, nb = mol.get_n_alpha_electrons(), mol.get_n_beta_electrons()
 hil = Hilbert.get(N=mol.n_qubits, N_alpha=na, N_beta=nb, encoding=Encoding.SIGNED)
-wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, amp_hidden_size=[64],
-                               phase_hidden_size=[512, 512], use_amp_spin_sym=True, use_phase_spin_sym=False,
-                               aggregate_phase=False, n_alpha_electrons=na, n_beta_electrons=nb, device=dev)
+# NAQS_PROFILE_DEFAULT_ANSATZ=1: the reference's run.py default (aggregate phase: one phase block per pair, 128 hidden units)
+if os.environ.get("NAQS_PROFILE_DEFAULT_ANSATZ") == "1":
+    shape = dict(amp_hidden_size=[128], phase_hidden_size=[128], aggregate_phase=True)
+else:
+    shape = dict(amp_hidden_size=[64], phase_hidden_size=[512, 512], aggregate_phase=False)
+wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, use_amp_spin_sym=True,
+                               use_phase_spin_sym=False, n_alpha_electrons=na, n_beta_electrons=nb, device=dev, **shape)
 opt = PartialSamplingOptimizer(n_samples=n_samples, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5,
                                wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False, n_electrons=mol.n_electrons,
                                n_alpha_electrons=na, n_beta_electrons=nb, optimizer=torch.optim.Adam,
