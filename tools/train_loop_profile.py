@@ -36,10 +36,27 @@ opt = PartialSamplingOptimizer(n_samples=n_samples, n_samples_max=1e12, n_unq_sa
                                pauli_hamiltonian_dtype=np.float64, normalise_psi=True)
 with contextlib.redirect_stdout(io.StringIO()):
     opt.run(warmup, output_freq=10 ** 9)
+if os.environ.get("NAQS_GC") == "freeze":
+    import gc; gc.collect(); gc.freeze()
+elif os.environ.get("NAQS_GC") == "off":
+    import gc; gc.disable()
+prof = None
+if os.environ.get("NAQS_PROFILE_HOST") == "1":      # cProfile of the timed loop only (host side of a step)
+    import cProfile
+    prof = cProfile.Profile()
 torch.cuda.synchronize(); t0 = time.perf_counter()
+if prof:
+    prof.enable()
 with contextlib.redirect_stdout(io.StringIO()):
     opt.run(steps, output_freq=10 ** 9)
+if prof:
+    prof.disable()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
+if prof:
+    import pstats
+    buf = io.StringIO()
+    pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(24)
+    print(buf.getvalue()[:5000])
 from naqs_amd.optimizer import LogKey
 n_unq = opt.log[LogKey.N_UNIQUE_SAMP][-1][1]
 print(f"{os.path.basename(mol_f)}: {steps} steps, {dt / steps * 1e3:.3f} ms/step, {n_unq} unique samples in the last step, "
