@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 
 #include "naqs_common.hpp"
 #include "naqs_net.hpp"
@@ -121,7 +122,7 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
 // and the float32 conditional probabilities p[c] = exp(log-amp)^2 (nade.py:673).
 __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
                                             const int64_t cnt, const uint32_t k0, const uint32_t k1, int64_t (&out)[4],
-                                            float (&p)[4]) {
+                                            float (&p)[4], long long *clk = nullptr) {
     const int q = threadIdx.x & 3;
     const int nin = n == 0 ? 1 : 2 * n;
     const int S = (nin + 1 + 5 + 3) & ~3;
@@ -138,6 +139,7 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
 #undef CASE
         default: break;
     }
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[0] = clock64();     // MLP partial sums done
     const float *b2 = s_w + d.Ha * S;
     float t[5];
 #pragma unroll
@@ -154,10 +156,12 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
     // multinomial(count; p) as a binary tree of binomials (same distribution as the reference's conditional chain,
     // nade.py:31-35, two dependent rounds instead of three; the float64 renormalisation of :682-683 cancels in the
     // ratios): first {2,3} against {0,1}, then 1 within {0,1} and 3 within {2,3}
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[1] = clock64();     // conditional + probabilities done
     const double p01 = (double)p[0] + (double)p[1], p23 = (double)p[2] + (double)p[3], tot = p01 + p23;
     // first split by the whole quad (four attempts per round), then lanes {0,1} draw outcome 1 within {0,1} and lanes
     // {2,3} outcome 3 within {2,3} (two attempts per round each); every lane of a group ends up with the group's variate
     const int64_t n23 = binomial_group<4>(tot > 0.0, cnt, fmin(1.0, p23 / tot), k0, k1, ab, (uint32_t)n | (1u << 8));
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[2] = clock64();     // first binomial done
     const int64_t n01 = tot > 0.0 ? cnt - n23 : 0;
     const int sub = q >> 1;
     const int64_t m_sub = sub == 0 ? n01 : n23;
@@ -233,13 +237,17 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
                                                           const SampleBufs b, const int cur, const uint32_t k0,
                                                           const uint32_t k1, const uint32_t tag, const int64_t cap,
                                                           const int last, uint64_t *__restrict__ keys_out,
-                                                          int64_t *__restrict__ counts_out, float *__restrict__ probs_out) {
+                                                          int64_t *__restrict__ counts_out, float *__restrict__ probs_out,
+                                                          long long *__restrict__ clk) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_wave[SB / WAVE];
     __shared__ long long s_base;
+#define SMARK(k) do { if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[n * 12 + (k)] = clock64(); } while (0)
+    SMARK(0);
     const int64_t U = b.U[n];
     if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
     const int64_t nwg = (U + EXP_PARENTS - 1) / EXP_PARENTS;
+    SMARK(1);
     stage_pair_weights(d, w, n, s_w, SB);
     const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
     const bool active = u < U;
@@ -247,9 +255,11 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
     const int64_t cnt = active ? b.cnt[cur][u] : 0;
     const float pr = active ? b.prob[cur][u] : 0.0f;
     __syncthreads();
+    SMARK(2);
     int64_t out[4];
     float p[4];
-    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
+    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, clk ? clk + n * 12 + 6 : nullptr);
+    SMARK(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool owner = active && (threadIdx.x & 3) == 0;
     uint32_t mine = 0;
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
         if (lane == 0) s_base = part;
     }
     __syncthreads();
+    SMARK(4);
     const int64_t base = s_base;
     int64_t pos = base + before + (incl - mine);
     if (owner && mine) {
@@ -324,6 +335,8 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
         b.U[n + 1] = all < cap ? all : cap;
         if (all > cap) b.U[MAXP + 1] = 1;
     }
+    SMARK(5);
+#undef SMARK
 }
 
 // The first HL levels of the tree in ONE launch: level n has at most 4^n <= HT / 4 prefixes there, so a single
@@ -575,6 +588,11 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         net->samp_seq = 0;
     }
     ++net->samp_seq;
+    long long *clk_dev = nullptr;
+    if (naqs::env_int("NAQS_DEBUG_SAMPLE_CLOCKS", 0) == 1) {          // developer aid: stamps of workgroup 0 per level
+        HIP_TRY(hipMalloc((void **)&clk_dev, MAXP * 12 * sizeof(long long)));
+        HIP_TRY(hipMemset(clk_dev, 0, MAXP * 12 * sizeof(long long)));
+    }
     for (int n = n_first; n < d.P; ++n) {
         const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const int nin = n == 0 ? 1 : 2 * n;
@@ -584,7 +602,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         if (fused_levels && (int64_t)grid_e <= resident_wg) {
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
             hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
-                               keys_dev, counts_dev, probs_dev);
+                               keys_dev, counts_dev, probs_dev, clk_dev);
             HIP_TRY(hipGetLastError());
         } else {
             hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
@@ -598,6 +616,17 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
                        weights_dev);
     HIP_TRY(hipGetLastError());
+    if (clk_dev) {
+        long long h[MAXP * 12];
+        HIP_TRY(hipMemcpy(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(clk_dev);
+        for (int n = n_first; n < d.P; ++n) {
+            std::fprintf(stderr, "[naqs sample clocks] level %d: start(rel. prev end) %lld |", n,
+                         n > n_first && h[(n - 1) * 12 + 5] ? h[n * 12] - h[(n - 1) * 12 + 5] : 0ll);
+            for (int k = 1; k < 9; ++k) std::fprintf(stderr, " %lld", h[n * 12 + k] ? h[n * 12 + k] - h[n * 12] : 0ll);
+            std::fprintf(stderr, "\n");
+        }
+    }
     return NAQS_OK;
 }
 
