@@ -620,6 +620,11 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         long long h[MAXP * 12];
         HIP_TRY(hipMemcpy(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost));
         (void)hipFree(clk_dev);
+        int64_t hu[U_SLOTS];
+        HIP_TRY(hipMemcpy(hu, b.U, sizeof(hu), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[naqs sample clocks] level sizes:");
+        for (int n = 0; n <= d.P; ++n) std::fprintf(stderr, " %lld", (long long)hu[n]);
+        std::fprintf(stderr, "\n");
         for (int n = n_first; n < d.P; ++n) {
             std::fprintf(stderr, "[naqs sample clocks] level %d: start(rel. prev end) %lld |", n,
                          n > n_first && h[(n - 1) * 12 + 5] ? h[n * 12] - h[(n - 1) * 12 + 5] : 0ll);
