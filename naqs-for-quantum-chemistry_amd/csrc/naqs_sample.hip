@@ -28,6 +28,7 @@
 
 #include "naqs_common.hpp"
 #include "naqs_net.hpp"
+#include "naqs_amp_mfma.hpp"
 #include "naqs_rng.hpp"
 
 namespace {
@@ -122,7 +123,8 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
 // and the float32 conditional probabilities p[c] = exp(log-amp)^2 (nade.py:673).
 __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
                                             const int64_t cnt, const uint32_t k0, const uint32_t k1, int64_t (&out)[4],
-                                            float (&p)[4], long long *clk = nullptr) {
+                                            float (&p)[4], long long *clk = nullptr,
+                                            const naqs::ushort_t *__restrict__ wamp = nullptr) {
     const int q = threadIdx.x & 3;
     const int nin = n == 0 ? 1 : 2 * n;
     const int S = (nin + 1 + 5 + 3) & ~3;
@@ -131,19 +133,46 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
     const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
     const int per = (d.Ha + 3) / 4;
     const int j0 = min(d.Ha, q * per), j1 = min(d.Ha, j0 + per);
-    float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    switch (n) {
-#define CASE(NB) case NB: naqs::amp_partial<NB>(d, s_w, first, second, j0, j1, o); break;
-        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
-        CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
-#undef CASE
-        default: break;
-    }
-    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[0] = clock64();     // MLP partial sums done
-    const float *b2 = s_w + d.Ha * S;
     float t[5];
+    if (wamp != nullptr) {
+        // the block's MLP on the matrix cores: a wave's 64 lanes are 16 prefixes = one (tile, pair) item of the log-psi
+        // kernel's prologue (naqs_amp_mfma.hpp); s_w is then per-wave scratch (three planes of hidden activations + the
+        // raw outputs), not the pair's weights.  ~2.5 k cycles instead of the 5-8 k of four lanes walking 16 hidden units
+        // each through LDS reads nothing hides (one wave per SIMD).
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int hld = d.Ha + 8;
+        naqs::ushort_t *hs = reinterpret_cast<naqs::ushort_t *>(const_cast<float *>(s_w)) + (size_t)wave * (48 * hld + 256);
+        float *outs = reinterpret_cast<float *>(hs + 48 * hld);
+        const uint32_t ab16 = (uint32_t)__shfl((int)ab, 4 * (lane & 15), 64);
+        if (d.Ha == 64) {
+            naqs::AmpFrag<4> f;
+            naqs::amp_mfma_load<4>(wamp + (size_t)n * naqs::amp_mfma_pair_elems(64), lane, f);
+            naqs::amp_mfma_item<4>(d, f, n, ab16, lane, hs, outs);
+        } else {
+            naqs::AmpFrag<2> f;
+            naqs::amp_mfma_load<2>(wamp + (size_t)n * naqs::amp_mfma_pair_elems(32), lane, f);
+            naqs::amp_mfma_item<2>(d, f, n, ab16, lane, hs, outs);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + quad_sum(o[c]);
+        for (int c = 0; c < 5; ++c) t[c] = outs[(lane >> 2) * 8 + c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[0] = clock64();
+    } else {
+        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        switch (n) {
+#define CASE(NB) case NB: naqs::amp_partial<NB>(d, s_w, first, second, j0, j1, o); break;
+            CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
+            CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+#undef CASE
+            default: break;
+        }
+        if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[0] = clock64();     // MLP partial sums done
+        const float *b2 = s_w + d.Ha * S;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + quad_sum(o[c]);
+    }
     float la[4];
     bool ok[4], phys[4];
     naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
@@ -188,12 +217,12 @@ __device__ __forceinline__ void stage_pair_weights(const NetDims &d, const float
 
 __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, const float *__restrict__ w, const int n,
                                                            const SampleBufs b, const int cur, const uint32_t k0,
-                                                           const uint32_t k1) {
+                                                           const uint32_t k1, const naqs::ushort_t *__restrict__ wamp) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_red[SB / WAVE];
     const int64_t U = b.U[n];
     if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
-    stage_pair_weights(d, w, n, s_w, SB);
+    if (wamp == nullptr) stage_pair_weights(d, w, n, s_w, SB);
     const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
     const bool active = u < U;
     const uint32_t ab = active ? b.ab[cur][u] : 0u;
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(SB) void sample_expand_kernel(const NetDims d, cons
     __syncthreads();
     int64_t out[4];
     float p[4];
-    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
+    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, nullptr, wamp);
     uint32_t survivors = 0;
     if (active && (threadIdx.x & 3) == 0) {
         const float pr = b.prob[cur][u];
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
                                                           const uint32_t k1, const uint32_t tag, const int64_t cap,
                                                           const int last, uint64_t *__restrict__ keys_out,
                                                           int64_t *__restrict__ counts_out, float *__restrict__ probs_out,
-                                                          long long *__restrict__ clk) {
+                                                          long long *__restrict__ clk, const naqs::ushort_t *__restrict__ wamp) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_wave[SB / WAVE];
     __shared__ long long s_base;
@@ -248,7 +277,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
     if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * EXP_PARENTS >= U) return;          // workgroup-uniform
     const int64_t nwg = (U + EXP_PARENTS - 1) / EXP_PARENTS;
     SMARK(1);
-    stage_pair_weights(d, w, n, s_w, SB);
+    if (wamp == nullptr) stage_pair_weights(d, w, n, s_w, SB);
     const int64_t u = (int64_t)blockIdx.x * EXP_PARENTS + (threadIdx.x >> 2);
     const bool active = u < U;
     const uint32_t ab = active ? b.ab[cur][u] : 0u;
@@ -258,7 +287,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
     SMARK(2);
     int64_t out[4];
     float p[4];
-    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, clk ? clk + n * 12 + 6 : nullptr);
+    expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, clk ? clk + n * 12 + 6 : nullptr, wamp);
     SMARK(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool owner = active && (threadIdx.x & 3) == 0;
@@ -346,7 +375,8 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
 // launch, HT = 256 four (small max_unique).
 template <int HT, int HL>
 __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const float *__restrict__ w, const SampleBufs b,
-                                                         const int64_t n_samples, const uint32_t k0, const uint32_t k1) {
+                                                         const int64_t n_samples, const uint32_t k0, const uint32_t k1,
+                                                         const naqs::ushort_t *__restrict__ wamp) {
     constexpr int HP = HT / 4;                             // prefixes the workgroup can hold
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_ab[2][HP];
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
     for (int n = 0; n < HL; ++n) {
         const int cur = n & 1, nxt = cur ^ 1;
         __syncthreads();                                   // previous level's LDS writes / everyone done with s_w
-        stage_pair_weights(d, w, n, s_w, HT);
+        if (wamp == nullptr) stage_pair_weights(d, w, n, s_w, HT);
         const bool active = u < U;
         const uint32_t ab = active ? s_ab[cur][u] : 0u;
         const int64_t cnt = active ? s_cnt[cur][u] : 0;
@@ -371,7 +401,7 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         __syncthreads();
         int64_t out[4];
         float p[4];
-        expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p);
+        expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, nullptr, wamp);
         uint32_t mine = 0;                                 // survivors of this quad's prefix, held by its first lane
         if (active && q == 0)
 #pragma unroll
@@ -562,6 +592,12 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     int64_t bound = 1;                                     // worst-case prefixes entering level n: min(4^n, cap)
     int n_first = 0;
+    // the blocks' MLPs on the matrix cores when the fragment form of the current weights exists (naqs_net_set_weights; after
+    // naqs_net_set_amp_weights only the VALU rows are current); NAQS_SAMPLE_MFMA=0: always the VALU form.  The two forms
+    // round differently (f32 FMA chains vs the six-term bf16 split), so a draw may differ between them — never between
+    // the ways of cutting the tree into launches, which all take the same form
+    const naqs::ushort_t *wamp = (net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_SAMPLE_MFMA", 1) != 0) ? net->d_wamp : nullptr;
+    const size_t mf_wave_bytes = (size_t)(48 * (d.Ha + 8) + 256) * sizeof(unsigned short);
     // 0: per-level launches only, 1 (default): 4 levels / 256 threads, 2: 5 levels / 1024 threads — measured slower
     // (94 us against 38 + 18 for the fifth level on its own: sixteen latency-bound waves on one CU)
     const int head = naqs::env_int("NAQS_SAMPLE_HEAD", 1);
@@ -569,9 +605,12 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         const bool big = head >= 2 && d.P > 5 && cap >= 1024;
         const int hl = big ? 5 : 4;
         const int nin = 2 * (hl - 1);
-        const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
-        if (big) hipLaunchKernelGGL((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1);
-        else hipLaunchKernelGGL((sample_head_kernel<256, 4>), dim3(1), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1);
+        const size_t lds = wamp ? (size_t)(big ? 16 : 4) * mf_wave_bytes : ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+        if (big) {
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sample_head_kernel<1024, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp);
+        } else hipLaunchKernelGGL((sample_head_kernel<256, 4>), dim3(1), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp);
         HIP_TRY(hipGetLastError());
         n_first = hl;
         for (int n = 0; n < hl; ++n) bound *= 4;
@@ -596,16 +635,16 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     for (int n = n_first; n < d.P; ++n) {
         const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const int nin = n == 0 ? 1 : 2 * n;
-        const size_t lds = ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+        const size_t lds = wamp ? (size_t)(SB / WAVE) * mf_wave_bytes : ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
         const unsigned grid_e = (unsigned)((std::min(bound, cap) + EXP_PARENTS - 1) / EXP_PARENTS);
         const int last = n == d.P - 1 ? 1 : 0;
         if (fused_levels && (int64_t)grid_e <= resident_wg) {
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
             hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
-                               keys_dev, counts_dev, probs_dev, clk_dev);
+                               keys_dev, counts_dev, probs_dev, clk_dev, wamp);
             HIP_TRY(hipGetLastError());
         } else {
-            hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1);
+            hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, wamp);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, n & 1, cap, last, keys_dev, counts_dev,
                                probs_dev);
