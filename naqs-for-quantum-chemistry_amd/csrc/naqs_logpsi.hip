@@ -387,8 +387,40 @@ __host__ __device__ __forceinline__ int tile_col(int cb, int nn, int N_pad) {
     return (CBT == 4 && (N_pad & 63) == 0) ? ((cb >> 2) << 6) + 4 * nn + (cb & 3) : cb * 16 + nn;
 }
 
-// A1: the activations have a single non-zero plane (layer 0: the +-1 / 0 inputs are exact in bf16) -> three terms
-template <int RB, int NC, bool A1 = false>
+// The split formats of the phase MLP.  FMT 1 ("bf16x3"): three bf16 planes, six cross terms per product.  FMT 2 ("f16x2"):
+// two f16 planes of the power-of-two-scaled value (naqs::PhaseScales) — hi = f16(s v) carries 11 significant bits, lo =
+// f16(s v - hi) the next 11 (round-to-nearest at both levels: |s v - hi - lo| <= 2^-24 |s v|, an f32 rounding), and a product
+// is hi hi + hi lo + lo hi: THREE MFMAs instead of six; the dropped lo lo is <= 2^-24 |ab|.  The scales keep every tensor
+// high in the f16 range (largest entries at 2^13..2^15), so lo is a normal f16 for entries down to 2^-17 of the largest and
+// degrades gracefully (absolute error 2^-25 on the scaled value) below that.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int FMT> struct fmt_planes { static constexpr int value = FMT == 2 ? 2 : 3; };
+
+template <int FMT>
+__device__ __forceinline__ f32x4 mfma_h(const bf16x8 &a, const bf16x8 &b, const f32x4 &c) {
+    if constexpr (FMT == 2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// two adjacent values -> the two f16 planes, each packed as (x1 << 16) | x0
+__device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t &w1, uint32_t &w2) {
+    const f16x2 h = {(_Float16)x0, (_Float16)x1};
+    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    w1 = __builtin_bit_cast(uint32_t, h);
+    w2 = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void split2(float x, ushort_t &h1, ushort_t &h2) {
+    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+    h1 = __builtin_bit_cast(ushort_t, h);
+    h2 = __builtin_bit_cast(ushort_t, l);
+}
+
+// A1: the activations have a single non-zero plane (layer 0: the +-1 / 0 inputs are exact in bf16 and f16) -> one term per
+// weight plane
+template <int RB, int NC, bool A1 = false, int FMT = 1>
 __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
                                                  const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
                                                  f32x4 (&acc)[RB][CBT]) {
@@ -399,11 +431,12 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
     // half-chunks so that each load has half a chunk of MFMAs to land in, with the next chunk's activation fragments
     // prefetched from LDS — no faster (layer 1: 51.5k vs 49.7k cycles) and 58 VGPRs spilled around the loop: the loop
     // already runs at ~88 % of what v_mfma_f32_16x16x32_bf16 sustains (2 waves x 72 MFMAs x ~19 cycles per chunk).)
-    constexpr int AP = A1 ? 1 : 3;
+    constexpr int NP = fmt_planes<FMT>::value;
+    constexpr int AP = A1 ? 1 : NP;
     for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
-        bf16x8 a[AP][RB], b[3][NC];
+        bf16x8 a[AP][RB], b[NP][NC];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 b[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + ((size_t)c * Kh_pad + k0) * 16);
@@ -419,38 +452,47 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
             for (int c = 0; c < NC; ++c) {
                 f32x4 v = acc[rb][c];
                 // smallest terms first
-                if (A1) {
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[2][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[1][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[0][c], v, 0, 0, 0);
+                if constexpr (FMT == 2) {
+                    if (!A1) v = mfma_h<2>(a[1 % AP][rb], b[0][c], v);
+                    v = mfma_h<2>(a[0][rb], b[1][c], v);
+                    v = mfma_h<2>(a[0][rb], b[0][c], v);
+                } else if (A1) {
+                    v = mfma_h<1>(a[0][rb], b[2 % NP][c], v);
+                    v = mfma_h<1>(a[0][rb], b[1][c], v);
+                    v = mfma_h<1>(a[0][rb], b[0][c], v);
                 } else {
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1 % AP][rb], b[1][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 % AP][rb], b[0][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[2][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1 % AP][rb], b[0][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[1][c], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b[0][c], v, 0, 0, 0);
+                    v = mfma_h<1>(a[1 % AP][rb], b[1][c], v);
+                    v = mfma_h<1>(a[2 % AP][rb], b[0][c], v);
+                    v = mfma_h<1>(a[0][rb], b[2 % NP][c], v);
+                    v = mfma_h<1>(a[1 % AP][rb], b[0][c], v);
+                    v = mfma_h<1>(a[0][rb], b[1][c], v);
+                    v = mfma_h<1>(a[0][rb], b[0][c], v);
                 }
                 acc[rb][c] = v;
             }
     }
 }
 
-// write-back of a wide hidden layer: the accumulators (+ bias, ReLU) go back to the LDS tile as three bf16 planes
-template <int RB, bool SAVE>
+// scales of one layer in the f16x2 format (all 1 for bf16x3, which carries unscaled values)
+struct LayerScale { float c = 1.0f, sn = 1.0f, isn = 1.0f; };
+
+// write-back of a wide hidden layer: the accumulators (+ bias, ReLU) go back to the LDS tile as the format's planes.
+// FMT 2: the planes hold sn * h, computed as max(acc * c + sn * b, 0) (c, sn powers of two: the same rounding as the unscaled
+// sum); bvs arrive pre-scaled.
+template <int RB, bool SAVE, int FMT>
 __device__ __forceinline__ void mlp_writeback_h(ushort_t *__restrict__ planes, int ldh, int N_pad, f32x4 (&acc)[RB][CBT],
                                                 const float (&bvs)[CBT], int cb0, int my_cb, bool inter, int wave, int lane,
                                                 float *__restrict__ save, int save_ld, int64_t row0, int64_t M,
-                                                long long *clk) {
+                                                long long *clk, const LayerScale sc) {
     constexpr int BM = RB * 16;
     const int m = lane & 15, kg = lane >> 4;
     const int plane_stride = BM * ldh;
     if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 9] = clock64();
     __syncthreads();                                      // everyone is done reading the input
     if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 10] = clock64();
-    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the three planes.
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; bias + ReLU, then split into the planes.
     // Neighbouring lanes hold neighbouring columns: the even lane takes rows 0,1 of both columns and the odd lane rows
-    // 2,3 (two DPP exchanges), so every LDS store is a full dword (two bf16) instead of a 2-byte store — half the
+    // 2,3 (two DPP exchanges), so every LDS store is a full dword (two 16-bit parts) instead of a 2-byte store — half the
     // store instructions of the write-back and no sub-dword merging.
     if (inter && my_cb == CBT) {
         const int col0 = (cb0 >> 2) * 64 + 4 * m;         // this lane's four adjacent columns: tile c <-> col0 + c
@@ -460,17 +502,33 @@ __device__ __forceinline__ void mlp_writeback_h(ushort_t *__restrict__ planes, i
             for (int r = 0; r < 4; ++r) {
                 float h[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) h[c] = fmaxf(acc[rb][c % CBT][r] + bvs[c % CBT], 0.0f);
+                for (int c = 0; c < 4; ++c) {
+                    if constexpr (FMT == 2) h[c] = fmaxf(fmaf(acc[rb][c % CBT][r], sc.c, bvs[c % CBT]), 0.0f);
+                    else h[c] = fmaxf(acc[rb][c % CBT][r] + bvs[c % CBT], 0.0f);
+                }
                 const int row = rb * 16 + kg * 4 + r;
-                if (SAVE && save != nullptr && row0 + row < M)
-                    *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) = (f32x4){h[0], h[1], h[2], h[3]};
-                uint32_t a1, a2, a3, b1, b2, b3;
-                split3t_pair(h[0], h[1], a1, a2, a3);
-                split3t_pair(h[2], h[3], b1, b2, b3);
+                if (SAVE && save != nullptr && row0 + row < M) {
+                    if constexpr (FMT == 2)
+                        *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) =
+                            (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn};
+                    else
+                        *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) = (f32x4){h[0], h[1], h[2], h[3]};
+                }
                 ushort_t *dst = planes + row * ldh + col0;                              // 8-byte aligned
-                *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2 *>(dst + 2 * plane_stride) = make_uint2(a3, b3);
+                if constexpr (FMT == 2) {
+                    uint32_t a1, a2, b1, b2;
+                    split2_pair(h[0], h[1], a1, a2);
+                    split2_pair(h[2], h[3], b1, b2);
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
+                } else {
+                    uint32_t a1, a2, a3, b1, b2, b3;
+                    split3t_pair(h[0], h[1], a1, a2, a3);
+                    split3t_pair(h[2], h[3], b1, b2, b3);
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2 *>(dst + 2 * plane_stride) = make_uint2(a3, b3);
+                }
             }
         __syncthreads();
         return;
@@ -488,20 +546,28 @@ __device__ __forceinline__ void mlp_writeback_h(ushort_t *__restrict__ planes, i
                 float h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    h[r] = fmaxf(acc[rb][c][r] + bv, 0.0f);
+                    if constexpr (FMT == 2) h[r] = fmaxf(fmaf(acc[rb][c][r], sc.c, bv), 0.0f);
+                    else h[r] = fmaxf(acc[rb][c][r] + bv, 0.0f);
                     const int row = rb * 16 + kg * 4 + r;
-                    if (SAVE && save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = h[r];
+                    if (SAVE && save != nullptr && row0 + row < M) save[(row0 + row) * save_ld + col] = FMT == 2 ? h[r] * sc.isn : h[r];
                 }
                 const float x0 = __shfl_xor(odd ? h[0] : h[2], 1, 64), x1 = __shfl_xor(odd ? h[1] : h[3], 1, 64);
                 const float lo[2] = {odd ? x0 : h[0], odd ? x1 : h[1]}, hi[2] = {odd ? h[2] : x0, odd ? h[3] : x1};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    uint32_t w1, w2, w3;
-                    split3t_pair(lo[j], hi[j], w1, w2, w3);
                     const int o = (rb * 16 + kg * 4 + (odd ? 2 : 0) + j) * ldw + (col >> 1);
-                    planes32[o] = w1;
-                    planes32[plane_w + o] = w2;
-                    planes32[2 * plane_w + o] = w3;
+                    if constexpr (FMT == 2) {
+                        uint32_t w1, w2;
+                        split2_pair(lo[j], hi[j], w1, w2);
+                        planes32[o] = w1;
+                        planes32[plane_w + o] = w2;
+                    } else {
+                        uint32_t w1, w2, w3;
+                        split3t_pair(lo[j], hi[j], w1, w2, w3);
+                        planes32[o] = w1;
+                        planes32[plane_w + o] = w2;
+                        planes32[2 * plane_w + o] = w3;
+                    }
                 }
             }
         }
@@ -510,13 +576,13 @@ __device__ __forceinline__ void mlp_writeback_h(ushort_t *__restrict__ planes, i
 }
 
 
-// one layer: planes[3][BM][ldh] (bf16) -> planes (hidden layers) or f32 out[BM][16] in the same LDS (last layer)
-template <int RB, bool SAVE>
+// one layer: planes[NP][BM][ldh] (16-bit parts) -> planes (hidden layers) or f32 out[BM][16] in the same LDS (last layer)
+template <int RB, bool SAVE, int FMT>
 __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int ldh, int Kh_pad, int N_pad,
                                             const ushort_t *__restrict__ W, const float *__restrict__ bias, bool last,
                                             int wave, int lane, float *__restrict__ save, int save_ld,
                                             int64_t row0, int64_t M, long long *clk,
-                                            bool in_plane0_only) {
+                                            bool in_plane0_only, const LayerScale sc) {
     // save != nullptr (training forward): the post-ReLU activations of this hidden layer also go to HBM
     // ([M][save_ld] float32) for the backward pass
     constexpr int BM = RB * 16;
@@ -535,7 +601,7 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
         const int chunks = Kh_pad >> 5, cpw = (chunks + PH_WAVES - 1) / PH_WAVES;
         const int kbeg = min(chunks, wave * cpw) << 5, klen = (min(chunks, (wave + 1) * cpw) << 5) - kbeg;
         if (klen > 0)
-            mlp_accumulate_h<RB, 1>(a_ptr + kbeg, ldh, plane_stride, W + (size_t)kbeg * 16 + lane * 8, klen, wplane, acc);
+            mlp_accumulate_h<RB, 1, false, FMT>(a_ptr + kbeg, ldh, plane_stride, W + (size_t)kbeg * 16 + lane * 8, klen, wplane, acc);
         // NB: inside mlp_accumulate_h the chunk offset is ((c*Kh_pad + k0)*16) with the *layer's* Kh_pad only for
         // c > 0; with NC == 1 the sub-range length may be passed as Kh_pad.
         __syncthreads();
@@ -552,9 +618,15 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
             const int t = u * PH_THREADS + wave * WAVE + lane;
             v[u] = 0.0f;
             if (t < BM * 16) {
-                v[u] = bias[t & 15];
+                if constexpr (FMT == 2) {
 #pragma unroll
-                for (int q = 0; q < PH_WAVES; ++q) v[u] += part[q * BM * 16 + t];
+                    for (int q = 0; q < PH_WAVES; ++q) v[u] += part[q * BM * 16 + t];
+                    v[u] = fmaf(v[u], sc.c, bias[t & 15] * sc.sn);         // last layer: sn == 1 -> the unscaled output
+                } else {
+                    v[u] = bias[t & 15];
+#pragma unroll
+                    for (int q = 0; q < PH_WAVES; ++q) v[u] += part[q * BM * 16 + t];
+                }
             }
         }
         __syncthreads();
@@ -564,12 +636,19 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
             if (t < BM * 16) {
                 if (last) part[t] = v[u];                          // f32 [BM][16]
                 else {
-                    ushort_t h1, h2, h3;
                     const float hv = fmaxf(v[u], 0.0f);
-                    split3t(hv, h1, h2, h3);
                     const int o = (t >> 4) * ldh + (t & 15);
-                    planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
-                    if (SAVE && save != nullptr && row0 + (t >> 4) < M) save[(row0 + (t >> 4)) * save_ld + (t & 15)] = hv;
+                    if constexpr (FMT == 2) {
+                        ushort_t h1, h2;
+                        split2(hv, h1, h2);
+                        planes[o] = h1; planes[plane_stride + o] = h2;
+                    } else {
+                        ushort_t h1, h2, h3;
+                        split3t(hv, h1, h2, h3);
+                        planes[o] = h1; planes[plane_stride + o] = h2; planes[2 * plane_stride + o] = h3;
+                    }
+                    if (SAVE && save != nullptr && row0 + (t >> 4) < M)
+                        save[(row0 + (t >> 4)) * save_ld + (t & 15)] = FMT == 2 ? hv * sc.isn : hv;
                 }
             }
         }
@@ -581,44 +660,52 @@ __device__ __forceinline__ void mlp_layer_h(ushort_t *__restrict__ planes, int l
     const bool inter = CBT == 4 && (N_pad & 63) == 0;     // interleaved column map (tile_col): my_cb == CBT for every wave
     float bvs[CBT];                                       // fetched under the MFMAs, not after the barrier
 #pragma unroll
-    for (int c = 0; c < CBT; ++c) bvs[c] = c < my_cb ? bias[tile_col(cb0 + c, m, N_pad)] : 0.0f;
+    for (int c = 0; c < CBT; ++c) {
+        bvs[c] = c < my_cb ? bias[tile_col(cb0 + c, m, N_pad)] : 0.0f;
+        if constexpr (FMT == 2) bvs[c] *= sc.sn;
+    }
     const ushort_t *w_ptr = W + (size_t)cb0 * Kh_pad * 16 + lane * 8;
     if (my_cb == CBT) {
         // (layer 0's fragments were also requested ahead, from the prologue, so that their first-touch latency would be
         // off the critical path: the 48 registers they hold across the conditionals spill — layer 0 got 1.8k cycles
         // shorter and the kernel 3.9k longer, A/B on one box)
-        if (in_plane0_only) mlp_accumulate_h<RB, CBT, true>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
-        else mlp_accumulate_h<RB, CBT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+        if (in_plane0_only) mlp_accumulate_h<RB, CBT, true, FMT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+        else mlp_accumulate_h<RB, CBT, false, FMT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
     }
-    else if (my_cb >= 4) mlp_accumulate_h<RB, (CBT > 4 ? 4 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
-    else if (my_cb == 3) mlp_accumulate_h<RB, (CBT > 3 ? 3 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
-    else if (my_cb == 2) mlp_accumulate_h<RB, (CBT > 2 ? 2 : 1)>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
-    else if (my_cb == 1) mlp_accumulate_h<RB, 1>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
-    mlp_writeback_h<RB, SAVE>(planes, ldh, N_pad, acc, bvs, cb0, my_cb, inter, wave, lane, save, save_ld, row0, M, clk);
+    else if (my_cb >= 4) mlp_accumulate_h<RB, (CBT > 4 ? 4 : 1), false, FMT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb == 3) mlp_accumulate_h<RB, (CBT > 3 ? 3 : 1), false, FMT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb == 2) mlp_accumulate_h<RB, (CBT > 2 ? 2 : 1), false, FMT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    else if (my_cb == 1) mlp_accumulate_h<RB, 1, false, FMT>(a_ptr, ldh, plane_stride, w_ptr, Kh_pad, wplane, acc);
+    mlp_writeback_h<RB, SAVE, FMT>(planes, ldh, N_pad, acc, bvs, cb0, my_cb, inter, wave, lane, save, save_ld, row0, M, clk, sc);
 }
 
 // layer 0 of the published shape (one K chunk, all eight waves own CBT column tiles): its weight fragments are requested
 // by the caller BEFORE the input tile is built, so their L2 round trip overlaps the build instead of following it
-template <int RB>
+template <int RB, int NP>
 __device__ __forceinline__ void mlp_layer0_fetch(const NetDims &d, const ushort_t *__restrict__ W, int wave, int lane,
-                                                 bf16x8 (&pre)[3][CBT]) {
+                                                 bf16x8 (&pre)[NP][CBT]) {
     const int Kh_pad = d.Kh_pad[0];
     const size_t wplane = (size_t)d.N_pad[0] * Kh_pad;
     const ushort_t *w_ptr = W + (size_t)(wave * CBT) * Kh_pad * 16 + lane * 8;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int c = 0; c < CBT; ++c) pre[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + (size_t)c * Kh_pad * 16);
 }
-template <int RB, bool SAVE>
-__device__ __forceinline__ void mlp_layer0_pre(ushort_t *__restrict__ planes, int ldh, int N_pad, const bf16x8 (&pre)[3][CBT],
+template <int RB, bool SAVE, int FMT>
+__device__ __forceinline__ void mlp_layer0_pre(ushort_t *__restrict__ planes, int ldh, int N_pad,
+                                               const bf16x8 (&pre)[fmt_planes<FMT>::value][CBT],
                                                const float *__restrict__ bias, int wave, int lane, float *__restrict__ save,
-                                               int save_ld, int64_t row0, int64_t M, long long *clk) {
+                                               int save_ld, int64_t row0, int64_t M, long long *clk, const LayerScale sc) {
+    constexpr int NP = fmt_planes<FMT>::value;
     const int m = lane & 15, kg = lane >> 4;
     const int cb0 = wave * CBT;
     float bvs[CBT];
 #pragma unroll
-    for (int c = 0; c < CBT; ++c) bvs[c] = bias[tile_col(cb0 + c, m, N_pad)];
+    for (int c = 0; c < CBT; ++c) {
+        bvs[c] = bias[tile_col(cb0 + c, m, N_pad)];
+        if constexpr (FMT == 2) bvs[c] *= sc.sn;
+    }
     const ushort_t *a_ptr = planes + m * ldh + 8 * kg;
     f32x4 acc[RB][CBT];
 #pragma unroll
@@ -627,14 +714,13 @@ __device__ __forceinline__ void mlp_layer0_pre(ushort_t *__restrict__ planes, in
 #pragma unroll
         for (int c = 0; c < CBT; ++c) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre[2][c], v, 0, 0, 0);       // smallest terms first
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre[1][c], v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre[0][c], v, 0, 0, 0);
+#pragma unroll
+            for (int p = NP - 1; p >= 0; --p) v = mfma_h<FMT>(a, pre[p][c], v);       // smallest terms first
             acc[rb][c] = v;
         }
     }
-    mlp_writeback_h<RB, SAVE>(planes, ldh, N_pad, acc, bvs, cb0, CBT, CBT == 4 && (N_pad & 63) == 0, wave, lane, save, save_ld,
-                              row0, M, clk);
+    mlp_writeback_h<RB, SAVE, FMT>(planes, ldh, N_pad, acc, bvs, cb0, CBT, CBT == 4 && (N_pad & 63) == 0, wave, lane, save, save_ld,
+                                   row0, M, clk, sc);
 }
 
 // all (tile, pair) items of the workgroup, dealt round-robin to its waves, the loads of item k+1 in flight under item k;
@@ -777,19 +863,23 @@ __global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 }
 
 // SAVE: training forward (inputs and hidden activations also go to HBM); a template parameter because the stores'
-// address arithmetic and bounds branches are ~40 % of the write-back's instructions even when they are skipped
-template <int RB, bool SAVE>
-__global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims d, const float *__restrict__ w,
-                                                                  const ushort_t *__restrict__ wh, int64_t M,
-                                                                  const uint64_t *__restrict__ keys,
-                                                                  const float *__restrict__ scratch,
-                                                                  float2 *__restrict__ out, const ElocFeed feed,
-                                                                  const naqs::PhaseSave save,
-                                                                  const ushort_t *__restrict__ wamp) {
+// address arithmetic and bounds branches are ~40 % of the write-back's instructions even when they are skipped.
+// FMT: the split format of the phase MLP's operands (1 = bf16x3, 2 = f16x2, see mfma_h above); the amplitude prologue is
+// bf16x3 in both.
+template <int RB, bool SAVE, int FMT>
+__global__ __launch_bounds__(PH_THREADS) void phase_kernel_h(const NetDims d, const float *__restrict__ w,
+                                                             const ushort_t *__restrict__ wh, int64_t M,
+                                                             const uint64_t *__restrict__ keys,
+                                                             const float *__restrict__ scratch,
+                                                             float2 *__restrict__ out, const ElocFeed feed,
+                                                             const naqs::PhaseSave save,
+                                                             const ushort_t *__restrict__ wamp,
+                                                             const naqs::PhaseScales *__restrict__ scales) {
     extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
     __shared__ uint32_t s_ab[RB * 16];                 // model-order occupation strings of the tile's samples
     __shared__ float s_lan[MAXP][RB * 16];             // conditional log-amplitudes, pair-major
     constexpr int BM = RB * 16;
+    constexpr int NP = fmt_planes<FMT>::value;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int P = d.P, ldh = d.ldh;
@@ -806,7 +896,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
         uint32_t warm0 = 0, warm1 = 0;
         {
             const uint32_t *w0 = reinterpret_cast<const uint32_t *>(wh + d.wh_off[0]);
-            const int n_dw = 3 * d.N_pad[0] * d.Kh_pad[0] / 2;
+            const int n_dw = NP * d.N_pad[0] * d.Kh_pad[0] / 2;
             if (tid * 32 < n_dw) warm0 = w0[tid * 32];
             if ((tid + PH_THREADS) * 32 < n_dw) warm1 = w0[(tid + PH_THREADS) * 32];
         }
@@ -823,11 +913,12 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
 
     // layer 0's weight fragments go out now; they land while the input tile is built
     const bool pre0 = d.n_lin > 1 && d.Kh_pad[0] == 32 && d.N_pad[0] == PH_WAVES * CBT * 16;
-    bf16x8 pre[3][CBT];
-    if (pre0) mlp_layer0_fetch<RB>(d, wh + d.wh_off[0], wave, lane, pre);
+    bf16x8 pre[NP][CBT];
+    if (pre0) mlp_layer0_fetch<RB, NP>(d, wh + d.wh_off[0], wave, lane, pre);
 
-    // layer-0 input (+-1 / 0: exact in bf16, planes 2 and 3 are zero); one thread builds 8 consecutive inputs of a row
-    // and stores them as one 16-byte LDS write per plane (ldh and Kh_pad are multiples of 8)
+    // layer-0 input (+-1 / 0: exact in bf16 and f16, the other planes are zero); one thread builds 8 consecutive inputs of a
+    // row and stores them as one 16-byte LDS write per plane (ldh and Kh_pad are multiples of 8)
+    constexpr uint32_t ONE_P = FMT == 2 ? 0x3C00u : 0x3F80u, ONE_M = FMT == 2 ? 0xBC00u : 0xBF80u;
     const int K0 = d.Kh_pad[0], G0 = K0 >> 3;
     for (int e = tid; e < BM * G0; e += PH_THREADS) {
         const int r = e / G0, k8 = (e - r * G0) << 3;
@@ -847,28 +938,31 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
                 const int k = k8 + j;
                 if (k < 2 * (P - 1)) {
                     const bool set = k < P - 1 ? ((ab >> k) & 1u) : ((ab >> (16 + k - (P - 1))) & 1u);
-                    pk[j >> 1] |= (set ? 0x3F80u : 0xBF80u) << (16 * (j & 1));  // +1.0 / -1.0
+                    pk[j >> 1] |= (set ? ONE_P : ONE_M) << (16 * (j & 1));      // +1.0 / -1.0
                     if (SAVE && save.x != nullptr) save.x[i * save.x_ld + k] = set ? 1.0f : -1.0f;
                 }
             }
         }
         ushort_t *dst = planes + r * ldh + k8;
         *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        *reinterpret_cast<uint4 *>(dst + BM * ldh) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4 *>(dst + 2 * BM * ldh) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int p = 1; p < NP; ++p) *reinterpret_cast<uint4 *>(dst + p * BM * ldh) = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
 
     NAQS_MARK(4);
+    LayerScale sc;
+    if constexpr (FMT == 2) { sc.c = scales->c[0]; sc.sn = scales->sn[0]; sc.isn = scales->isn[0]; }
     if (pre0) {
-        mlp_layer0_pre<RB, SAVE>(planes, ldh, d.N_pad[0], pre, w + d.b_off[0], wave, lane, save.act[0], save.act_ld[0], row0, M,
-                                 save.clk);
+        mlp_layer0_pre<RB, SAVE, FMT>(planes, ldh, d.N_pad[0], pre, w + d.b_off[0], wave, lane, save.act[0], save.act_ld[0], row0, M,
+                                      save.clk, sc);
         NAQS_MARK(5);
     }
     for (int l = pre0 ? 1 : 0; l < d.n_lin; ++l) {
-        mlp_layer_h<RB, SAVE>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
+        if constexpr (FMT == 2) { sc.c = scales->c[l]; sc.sn = scales->sn[l]; sc.isn = scales->isn[l]; }
+        mlp_layer_h<RB, SAVE, FMT>(planes, ldh, d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], w + d.b_off[l], l + 1 == d.n_lin, wave, lane,
                         l + 1 < d.n_lin ? save.act[l] : nullptr, save.act_ld[l], row0, M, l == 0 ? save.clk : nullptr,
-                        /*in_plane0_only=*/l == 0);
+                        /*in_plane0_only=*/l == 0, sc);
         NAQS_MARK(5 + l);
     }
 
@@ -881,6 +975,56 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_bf16x3(const NetDims 
             out[i] = make_float2(la, ph);
             if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
         }
+    }
+}
+
+// the weight maxima the f16x2 scales are derived from: per phase layer max |W|, max_j sum_k |W[j][k]|, max |b|
+// (atomicMax on the bit patterns of non-negative floats; the buffer was zeroed by the previous pack_net_kernel)
+struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
+__global__ __launch_bounds__(256) void net_bounds_kernel(const float *__restrict__ flat, const PhasePackJobs jobs,
+                                                         naqs::PhaseRaw *__restrict__ raw) {
+    const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = jobs.K[l], N = jobs.N[l];
+    const float *W = flat + jobs.src_off[l], *b = W + (size_t)N * K;
+    float mw = 0.0f, mr = 0.0f, mb = 0.0f;
+    for (int j = blockIdx.x * 4 + wave; j < N; j += gridDim.x * 4) {            // a wave per row
+        float sum = 0.0f;
+        for (int k = lane; k < K; k += 64) { const float v = fabsf(W[(size_t)j * K + k]); sum += v; mw = fmaxf(mw, v); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        mr = fmaxf(mr, sum);
+        mb = fmaxf(mb, fabsf(b[j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    if (lane == 0) {
+        atomicMax(&raw->max_w[l], __float_as_uint(mw));
+        atomicMax(&raw->max_rowsum[l], __float_as_uint(mr));
+        atomicMax(&raw->max_b[l], __float_as_uint(mb));
+    }
+}
+
+// 2^e with e clamped to what keeps every product of two scales finite
+__device__ __forceinline__ float pow2_clamped(int e) { return __uint_as_float((uint32_t)(127 + min(max(e, -40), 40)) << 23); }
+// floor(log2 x) of a non-negative float from its exponent field (zero / subnormal: -127; inf / nan: 128)
+__device__ __forceinline__ int exp_of(float x) { return (int)((__float_as_uint(x) >> 23) & 0xFFu) - 127; }
+
+// weight scale of layer l: max |W| sw in [2^13, 2^14)
+__device__ __forceinline__ float phase_weight_scale(const naqs::PhaseRaw &raw, int l) {
+    return pow2_clamped(13 - exp_of(__uint_as_float(raw.max_w[l])));
+}
+// all scales of the network (one thread): activation bound chain |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
+__device__ __forceinline__ void phase_scales_fill(const naqs::PhaseRaw &raw, int n_lin, naqs::PhaseScales *out) {
+    float bound = 1.0f, s_in = 1.0f;
+    for (int l = 0; l < n_lin; ++l) {
+        bound = __uint_as_float(raw.max_rowsum[l]) * bound + __uint_as_float(raw.max_b[l]);
+        const float sw = phase_weight_scale(raw, l);
+        const float sn = l + 1 < n_lin ? pow2_clamped(14 - exp_of(bound)) : 1.0f;          // bound sn < 2^15
+        out->sw[l] = sw;
+        out->sn[l] = sn;
+        out->isn[l] = 1.0f / sn;
+        out->c[l] = (sn / s_in) / sw;                // powers of two: exact
+        s_in = sn;
     }
 }
 
@@ -897,6 +1041,20 @@ __device__ __forceinline__ void pack_phase_bf16(const float *__restrict__ src, i
         ushort_t h1, h2, h3;
         split3(x, h1, h2, h3);
         Wd[e] = h1; Wd[(size_t)total + e] = h2; Wd[2 * (size_t)total + e] = h3;
+    }
+}
+// the same tiling as two f16 planes of sw * W (f16x2 format)
+__device__ __forceinline__ void pack_phase_f16(const float *__restrict__ src, int K, int N, int Kh_pad,
+                                               int N_pad, ushort_t *__restrict__ Wd, const float sw) {
+    const int total = N_pad * Kh_pad;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e & 7, nn = (e >> 3) & 15, kg = (e >> 7) & 3, blk = e >> 9;
+        const int KC = Kh_pad >> 5, cb = blk / KC, kc = blk - cb * KC;
+        const int n = tile_col(cb, nn, N_pad), k = kc * 32 + kg * 8 + j;
+        const float x = (n < N && k < K) ? src[n * K + k] * sw : 0.0f;
+        ushort_t h1, h2;
+        split2(x, h1, h2);
+        Wd[e] = h1; Wd[(size_t)total + e] = h2;
     }
 }
 
@@ -987,24 +1145,29 @@ __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, in
     }
 }
 
-// one phase layer: f32 MFMA tiles + bias, and the three bf16 planes
-struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
+// one phase layer: f32 MFMA tiles + bias, and the split planes (fmt 1: three bf16, fmt 2: two scaled f16)
 __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
-                                                float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32, const int l) {
+                                                float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32, const int l,
+                                                const int fmt, const naqs::PhaseRaw *__restrict__ raw) {
     const float *src = flat + jobs.src_off[l];
     if (with_f32) pack_phase_f32(src, jobs.K[l], jobs.N[l], d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l]);
-    else {                                              // the bf16x3 kernel only needs the (padded) bias from this buffer
+    else {                                              // the split kernels only need the (padded) bias from this buffer
         for (int n = blockIdx.x * 256 + threadIdx.x; n < d.N_pad[l]; n += gridDim.x * 256)
             w[d.b_off[l] + n] = n < jobs.N[l] ? src[jobs.N[l] * jobs.K[l] + n] : 0.0f;
     }
-    pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
+    if (fmt == 2) pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l));
+    else pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
 }
 // naqs_net_set_weights of the single-phase network in ONE launch (it runs once per training step, and every launch of a
 // few thousand elements costs its 4-5 us): blockIdx.y walks the amplitude rows (P jobs), the amplitude fragments (P), the
-// phase layers (n_lin) and the row-major copies the backward GEMMs read (naqs::WbPackJobs, from naqs_phase_grad.hip)
+// phase layers (n_lin) and the row-major copies the backward GEMMs read (naqs::WbPackJobs, from naqs_phase_grad.hip).
+// fmt 2: raw holds the weight maxima of net_bounds_kernel (launched just before); the first phase job also writes the
+// scales the phase kernel reads and zeroes the maxima buffer of the NEXT call (raw_next).
 __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
                                                        const PhasePackJobs jobs, const naqs::WbPackJobs wb, float *__restrict__ w,
-                                                       ushort_t *__restrict__ wh, ushort_t *__restrict__ wamp, const int with_f32) {
+                                                       ushort_t *__restrict__ wh, ushort_t *__restrict__ wamp, const int with_f32,
+                                                       const int fmt, const naqs::PhaseRaw *__restrict__ raw,
+                                                       naqs::PhaseRaw *__restrict__ raw_next, naqs::PhaseScales *__restrict__ scales) {
     int y = blockIdx.y;
     if (y < d.P) { pack_amp_body(flat, d, so, w, y); return; }
     y -= d.P;
@@ -1012,7 +1175,14 @@ __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__
         if (y < d.P) { pack_amp_mfma_body(flat, d, so, wamp, y); return; }
         y -= d.P;
     }
-    if (y < d.n_lin) { pack_phase_body(flat, d, jobs, w, wh, with_f32, y); return; }
+    if (y < d.n_lin) {
+        if (fmt == 2 && y == 0 && blockIdx.x == 0) {
+            if (threadIdx.x == 0) phase_scales_fill(*raw, d.n_lin, scales);
+            if (threadIdx.x < 3 * MAXL) reinterpret_cast<unsigned int *>(raw_next)[threadIdx.x] = 0u;
+        }
+        pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw);
+        return;
+    }
     y -= d.n_lin;
     if (y < wb.n) {
         const int total = wb.Np[y] * wb.Kp[y];
@@ -1163,15 +1333,19 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 2);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max / 4 * 3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-            const int ldsh = 3 * 16 * d.ldh * (int)sizeof(unsigned short);      // per 16 rows
             // (the amplitude prologue's scratch can exceed one 16-row slab: allow the maximum for every variant)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_bf16x3<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ldsh);
+            const int lds_all = 160 * 1024 - 5 * 1024;         // the static part (s_ab, s_lan) is < 5 KiB for every RB
+#define NAQS_PH_ATTR(RB, FMT)                                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_h<RB, false, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_h<RB, true, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all);
+            NAQS_PH_ATTR(1, 1) NAQS_PH_ATTR(2, 1) NAQS_PH_ATTR(3, 1)
+            NAQS_PH_ATTR(1, 2) NAQS_PH_ATTR(2, 2) NAQS_PH_ATTR(3, 2) NAQS_PH_ATTR(4, 2)
+#undef NAQS_PH_ATTR
+            (void)hipGetLastError();            // a refused attribute must not stay behind as the runtime's "last error"
         }
+        if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, 2 * sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        if (st == NAQS_OK && hipMalloc((void **)&net->d_scales, sizeof(naqs::PhaseScales)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        if (st == NAQS_OK && hipMemset(net->d_raw, 0, 2 * sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_HIP;
     }
     if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
     *out = net;
@@ -1192,6 +1366,8 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_gpart) (void)hipFree(net->d_gpart);
     if (net->d_train) (void)hipFree(net->d_train);
     if (net->d_wb) (void)hipFree(net->d_wb);
+    if (net->d_raw) (void)hipFree(net->d_raw);
+    if (net->d_scales) (void)hipFree(net->d_scales);
     delete net;
     return NAQS_OK;
 }
@@ -1200,6 +1376,21 @@ NAQS_API int naqs_net_param_count(const naqs_net_t *net, int64_t *count) {
     if (!net || !count) return NAQS_ERR_INVALID;
     *count = net->n_params;
     return NAQS_OK;
+}
+
+// which kernel evaluates the phase MLP.  NAQS_PHASE_MODE: 2 (default) f16x2 split on the f16 matrix cores, 1 bf16x3 split on
+// the bf16 matrix cores, 0 exact-f32 MFMA.  A split format needs its 16-row slab of activation planes to fit the LDS
+// three times over (the tiling the amplitude prologue's scratch was sized for); else the f32 kernel runs.
+static int phase_format(const NetDims &d) {
+    const int mode = naqs::env_int("NAQS_PHASE_MODE", 2);
+    const size_t slab3 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
+    if (mode < 1 || 3 * slab3 > 160 * 1024) return 0;
+    return mode == 1 ? 1 : 2;
+}
+static size_t phase_slab_bytes(const NetDims &d, int fmt) { return (size_t)(fmt == 2 ? 2 : 3) * 16 * d.ldh * sizeof(unsigned short); }
+static int phase_rb_max(const NetDims &d, int fmt) {
+    if (fmt == 0) return 4;
+    return (int)std::min<size_t>(fmt == 2 ? 4 : 3, (size_t)(155 * 1024) / phase_slab_bytes(d, fmt));
 }
 
 static int pack_blocks(const NetDims &d, const int64_t *src_off, float *dst, const float *flat_dev, hipStream_t s) {
@@ -1269,10 +1460,10 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
             biggest = std::max(biggest, d.N_pad[l] * std::max(d.K_pad[l], d.Kh_pad[l]));
         }
         // the f32-MFMA weight tiles are only read by phase_kernel (NAQS_PHASE_MODE=0)
-        const bool use_h = naqs::env_int("NAQS_PHASE_MODE", 1) == 1 &&
-                           3 * (3 * 16 * (size_t)d.ldh * sizeof(unsigned short)) <= 160 * 1024;      // as in net_logpsi_impl
-        const int with_f32 = use_h ? 0 : 1;
+        const int fmt = phase_format(d);
+        const int with_f32 = fmt == 0 ? 1 : 0;
         net->packed_f32 = with_f32 != 0;
+        net->packed_fmt = fmt;
         naqs::WbPackJobs wb{};
         st = naqs::net_backward_pack_jobs(net, &wb);
         if (st != NAQS_OK) return st;
@@ -1282,8 +1473,16 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
         const int gx = std::min(256, (biggest + 255) / 256);
         const int gy = d.P + (net->d_wamp ? d.P : 0) + d.n_lin + wb.n;
         net->wamp_fresh = false;
+        naqs::PhaseRaw *raw = net->d_raw + (net->pack_seq & 1u), *raw_next = net->d_raw + ((net->pack_seq + 1u) & 1u);
+        if (fmt == 2) {
+            // weight maxima -> scales (device side; no host round trip).  The buffer of this parity was zeroed at creation
+            // or by the pack kernel of the previous f16x2 call on this handle's stream.
+            hipLaunchKernelGGL(net_bounds_kernel, dim3(32, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw);
+            HIP_TRY(hipGetLastError());
+            net->pack_seq++;
+        }
         hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
-                           with_f32);
+                           with_f32, fmt, raw, raw_next, net->d_scales);
         HIP_TRY(hipGetLastError());
         net->wamp_fresh = net->d_wamp != nullptr;
         net->have_wb = true;
@@ -1356,13 +1555,15 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const NetDims &d = net->dims;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (net->aggregate) return agg_logpsi(net, M, keys_dev, logpsi_dev, s, feed);
-    const int mode = naqs::env_int("NAQS_PHASE_MODE", 1);        // 1: bf16x3 split on the bf16 matrix cores, 0: f32 MFMA
-    const size_t lds_h16 = 3 * 16 * (size_t)d.ldh * sizeof(unsigned short);
-    const bool use_h = mode == 1 && 3 * lds_h16 <= 160 * 1024;
+    const int fmt = phase_format(d);
+    if (fmt != net->packed_fmt) return NAQS_ERR_INVALID;                       // NAQS_PHASE_MODE changed since naqs_net_set_weights
+    const bool use_h = fmt != 0;
+    const size_t lds_h16 = use_h ? phase_slab_bytes(d, fmt) : 0;
+    const int rb_max = phase_rb_max(d, fmt);
     // amplitude conditionals inside the phase kernel (matrix cores) unless NAQS_AMP_MODE=0 or the width does not tile
-    const size_t amp_scratch = (size_t)PH_WAVES * 48 * (d.Ha + 8) * sizeof(unsigned short) + (size_t)d.P * 48 * 8 * sizeof(float);
+    const size_t amp_scratch = (size_t)PH_WAVES * 48 * (d.Ha + 8) * sizeof(unsigned short) + (size_t)d.P * rb_max * 16 * 8 * sizeof(float);
     const bool amp_in_phase = use_h && net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
-                              amp_scratch <= 3 * lds_h16;
+                              amp_scratch <= 150 * 1024;
     if (!amp_in_phase) {
         st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
         if (st != NAQS_OK) return st;
@@ -1377,9 +1578,8 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     }
 
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
-    if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the bf16x3 kernel only
-    if (!use_h && !net->packed_f32) return NAQS_ERR_INVALID;                  // NAQS_PHASE_MODE changed since naqs_net_set_weights
-    const int rb_max = use_h ? 3 : 4;
+    if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the split kernels only
+    if (!use_h && !net->packed_f32) return NAQS_ERR_INVALID;
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
     if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
     const int bm = rb * 16;
@@ -1389,14 +1589,26 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
     if (use_h) {
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
-        switch (rb) {
-            case 1: if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_bf16x3<1, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp);
-                    else hipLaunchKernelGGL((phase_kernel_bf16x3<1, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
-            case 2: if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_bf16x3<2, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp);
-                    else hipLaunchKernelGGL((phase_kernel_bf16x3<2, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
-            default: if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_bf16x3<3, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp);
-                    else hipLaunchKernelGGL((phase_kernel_bf16x3<3, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp); break;
+#define NAQS_PH_LAUNCH(RB, FMT)                                                                                                         \
+        do {                                                                                                                            \
+            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_h<RB, true, FMT>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales); \
+            else hipLaunchKernelGGL((phase_kernel_h<RB, false, FMT>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales); \
+        } while (0)
+        if (fmt == 2) {
+            switch (rb) {
+                case 1: NAQS_PH_LAUNCH(1, 2); break;
+                case 2: NAQS_PH_LAUNCH(2, 2); break;
+                case 3: NAQS_PH_LAUNCH(3, 2); break;
+                default: NAQS_PH_LAUNCH(4, 2); break;
+            }
+        } else {
+            switch (rb) {
+                case 1: NAQS_PH_LAUNCH(1, 1); break;
+                case 2: NAQS_PH_LAUNCH(2, 1); break;
+                default: NAQS_PH_LAUNCH(3, 1); break;
+            }
         }
+#undef NAQS_PH_LAUNCH
     } else {
         const size_t lds = (size_t)bm * d.ld * sizeof(float);
         switch (rb) {

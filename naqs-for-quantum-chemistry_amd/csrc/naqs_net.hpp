@@ -36,6 +36,14 @@ struct NetDims {
     int32_t ldh;                       // LDS row stride of one activation plane (bf16 units)
 };
 
+// f16x2 form of the phase MLP (phase_kernel_h<.., FMT = 2>): every f32 value v is carried as two f16 planes of s*v (s a power
+// of two per tensor: hi = f16(s v), lo = f16(s v - hi)), so that the values sit high in the f16 range and lo stays normal.
+// Per linear layer l: sw = scale of the weights, sn = scale of the layer's OUTPUT activations (1 for the last layer),
+// c = sn / (s_in sw) takes an accumulator to the scaled output, isn = 1 / sn.  Written by pack_net_kernel from the
+// weight-derived bounds of net_bounds_kernel (|h_l| <= rowsum_l * bound_{l-1} + max|b_l| < 2^15 / sn: no overflow).
+struct PhaseScales { float sw[MAXL], c[MAXL], sn[MAXL], isn[MAXL]; };
+struct PhaseRaw { unsigned int max_w[MAXL], max_rowsum[MAXL], max_b[MAXL]; };    // float bits of non-negative maxima (atomicMax)
+
 // one packed row [W1[j][0..NIN) | b1[j] | W2[0..5)[j] | pad] from LDS as 16-byte reads (rows are 16-byte multiples);
 // element-wise `row[k]` reads compile to one ds_read_b32 each and those, not the FMAs, were the time of this loop
 template <int S>
@@ -171,6 +179,10 @@ struct naqs_net {
     bool wamp_fresh = false;                // d_wamp was packed from the current parameters
     bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
     bool packed_f32 = false;                // the f32-MFMA weight tiles are current (only packed when phase_kernel will run)
+    int packed_fmt = 0;                     // split format of d_wh: 1 = three bf16 planes, 2 = two scaled f16 planes
+    naqs::PhaseRaw *d_raw = nullptr;        // [2] weight maxima of the phase layers (parity = set_weights calls & 1)
+    naqs::PhaseScales *d_scales = nullptr;  // the f16x2 scales of the current weights
+    uint32_t pack_seq = 0;
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)

@@ -143,11 +143,40 @@ def test_fused_refresh_after_parameter_update():
     assert torch.max(torch.abs(after - before)).item() > 1e-3
 
 
-def test_bf16x3_phase_kernel_is_f32_equivalent():
-    """The default phase kernel runs on the bf16 matrix cores with every f32 operand split into three bf16
-    planes (six exact cross products per multiply, f32 accumulation).  Against a float64 evaluation of the
-    same network its error must be of the same size as the exact-f32 MFMA kernel's (NAQS_PHASE_MODE=0)."""
+def _phase_f64_reference(hil, wf, keys_np, P):
+    states = hil.idx2state(torch.tensor(keys_np)).double()
+    x = states[:, wf.qubit2model_permutation]
+    h = torch.cat([x[:, 0:2 * (P - 1):2], x[:, 1:2 * (P - 1):2]], 1)
+    lins = [l for l in wf.model.phase_layers[0].linears()]
+    for i, lin in enumerate(lins):
+        h = h @ lin.weight.detach().double().cpu().T + lin.bias.detach().double().cpu()
+        if i + 1 < len(lins):
+            h = torch.relu(h)
+    occ = ((x[:, 2 * (P - 1)] > 0).long() + 2 * (x[:, 2 * (P - 1) + 1] > 0).long())
+    return h.gather(1, occ.view(-1, 1)).squeeze(1).numpy()
+
+
+def _phase_errors(fused, keys, ref, modes):
     import os
+    errs = {}
+    for mode in modes:
+        os.environ["NAQS_PHASE_MODE"] = mode
+        try:
+            fused.refresh()                       # each mode packs its own weight format
+            lp = fused.log_psi(keys)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["NAQS_PHASE_MODE"]
+        errs[mode] = np.abs(lp[:, 1].cpu().numpy().astype(np.float64) - ref)
+    fused.refresh()
+    return errs
+
+
+def test_split_phase_kernels_are_f32_equivalent():
+    """The phase MLP runs on the 16-bit matrix cores with every f32 operand split exactly enough: mode 1 = three bf16
+    planes (six cross products per multiply), mode 2 (default) = two scaled f16 planes (three), f32 accumulation.
+    Against a float64 evaluation of the same network their error must be of the same size as the exact-f32 MFMA
+    kernel's (NAQS_PHASE_MODE=0)."""
     from test_nade import make_wf
     from naqs_amd.fused import FusedLogPsi
     from naqs_amd.hamiltonian import keys_to_device
@@ -159,33 +188,55 @@ def test_bf16x3_phase_kernel_is_f32_equivalent():
     fused = FusedLogPsi(wf)
     keys_np = z["samp_keys"][:4096].astype(np.int64)
     keys = keys_to_device(keys_np, wf.device)
-    # float64 reference of the phase MLP on the CPU
-    states = hil.idx2state(torch.tensor(keys_np)).double()
-    x = states[:, wf.qubit2model_permutation]
-    P = 10
-    h = torch.cat([x[:, 0:2 * (P - 1):2], x[:, 1:2 * (P - 1):2]], 1)
-    lins = [l for l in wf.model.phase_layers[0].linears()]
-    for i, lin in enumerate(lins):
-        h = h @ lin.weight.detach().double().cpu().T + lin.bias.detach().double().cpu()
-        if i + 1 < len(lins):
-            h = torch.relu(h)
-    occ = ((x[:, 2 * (P - 1)] > 0).long() + 2 * (x[:, 2 * (P - 1) + 1] > 0).long())
-    ref = h.gather(1, occ.view(-1, 1)).squeeze(1).numpy()
-    errs = {}
-    for mode in ("0", "1"):
-        os.environ["NAQS_PHASE_MODE"] = mode
-        try:
-            fused.refresh()                       # the f32-MFMA weight tiles are only packed when that kernel is selected
-            lp = fused.log_psi(keys)
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["NAQS_PHASE_MODE"]
-        errs[mode] = np.abs(lp[:, 1].cpu().numpy().astype(np.float64) - ref)
+    ref = _phase_f64_reference(hil, wf, keys_np, 10)
+    errs = _phase_errors(fused, keys, ref, ("0", "1", "2"))
     scale = np.abs(ref).max()
-    print("phase error vs float64: f32 MFMA max %.3e mean %.3e | bf16x3 max %.3e mean %.3e | scale %.3f"
-          % (errs["0"].max(), errs["0"].mean(), errs["1"].max(), errs["1"].mean(), scale))
-    assert errs["0"].max() < 5e-6 * scale and errs["1"].max() < 5e-6 * scale, (errs["0"].max(), errs["1"].max(), scale)
+    print("phase error vs float64: f32 MFMA max %.3e mean %.3e | bf16x3 max %.3e mean %.3e | f16x2 max %.3e mean %.3e | scale %.3f"
+          % (errs["0"].max(), errs["0"].mean(), errs["1"].max(), errs["1"].mean(), errs["2"].max(), errs["2"].mean(), scale))
+    for mode in ("0", "1", "2"):
+        assert errs[mode].max() < 5e-6 * scale, (mode, errs[mode].max(), scale)
     assert errs["1"].mean() < 2.0 * errs["0"].mean() + 1e-9, (errs["0"].mean(), errs["1"].mean())
+    assert errs["2"].mean() < 2.0 * errs["0"].mean() + 1e-9, (errs["0"].mean(), errs["2"].mean())
+
+
+@pytest.mark.parametrize("case", ["huge", "tiny", "wide", "zero_layer"])
+def test_f16x2_phase_kernel_dynamic_range(case):
+    """The f16x2 format scales every tensor by a power of two derived from the weights on the device (f16 tops out at
+    65 504): activations of order 1e6 (would overflow unscaled), weights of order 1e-7 (would be f16-subnormal
+    unscaled), weights spanning 12 orders of magnitude inside one layer, and an all-zero layer must all come out
+    with the exact-f32 kernel's accuracy."""
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    z = golden("nade_N2.npz")
+    hil, wf = make_wf("N2", z, device="cuda")
+    lins = [l for l in wf.model.phase_layers[0].linears()]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        if case == "huge":
+            lins[0].weight.mul_(3.0e4); lins[0].bias.mul_(3.0e4); lins[1].weight.mul_(40.0)
+            lins[2].weight.mul_(1e-6); lins[2].bias.mul_(1.0)
+        elif case == "tiny":
+            lins[0].weight.mul_(1e-6); lins[0].bias.mul_(1e-6); lins[1].weight.mul_(1e-6); lins[1].bias.mul_(1e-12)
+            lins[2].weight.mul_(1e12)
+        elif case == "wide":
+            f = torch.pow(10.0, torch.rand(lins[1].weight.shape, generator=g) * 12.0 - 9.0).to(lins[1].weight.device)
+            lins[1].weight.mul_(f)
+            lins[2].weight.mul_(1e-2)
+        else:
+            lins[1].weight.zero_()
+    fused = FusedLogPsi(wf)
+    keys_np = z["samp_keys"][:2048].astype(np.int64)
+    keys = keys_to_device(keys_np, wf.device)
+    ref = _phase_f64_reference(hil, wf, keys_np, 10)
+    assert np.all(np.isfinite(ref))
+    errs = _phase_errors(fused, keys, ref, ("0", "2"))
+    scale = max(np.abs(ref).max(), 1e-30)
+    print("%s: f32 MFMA max %.3e mean %.3e | f16x2 max %.3e mean %.3e | scale %.3e"
+          % (case, errs["0"].max(), errs["0"].mean(), errs["2"].max(), errs["2"].mean(), scale))
+    assert np.all(np.isfinite(errs["2"]))
+    assert errs["2"].max() < max(3.0 * errs["0"].max(), 2e-6 * scale), (errs["0"].max(), errs["2"].max(), scale)
+    assert errs["2"].mean() < 2.0 * errs["0"].mean() + 1e-7 * scale, (errs["0"].mean(), errs["2"].mean())
 
 
 @pytest.mark.parametrize("mol", ["LiH", "N2"])
