@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256) void agg_finish_kernel(const int P, const int6
 constexpr int PH_THREADS = NAQS_PH_THREADS;      // 8 waves = 2 per SIMD: one computes while the other waits on loads
 constexpr int PH_WAVES = PH_THREADS / WAVE;
 constexpr int CBT = NAQS_PH_CBT;                 // 16-column blocks per wave per pass
+#ifndef NAQS_PH_DBUF
+#define NAQS_PH_DBUF 1                           // f16x2: weight fragments of the next K chunk in flight under the MFMAs
+#endif
 
 // K loop of one linear layer for one wave: RB row blocks x NC column blocks of 16x16 outputs.
 // Operand layout of v_mfma_f32_16x16x4_f32: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15].
@@ -433,19 +436,21 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
     // already runs at ~88 % of what v_mfma_f32_16x16x32_bf16 sustains (2 waves x 72 MFMAs x ~19 cycles per chunk).)
     constexpr int NP = fmt_planes<FMT>::value;
     constexpr int AP = A1 ? 1 : NP;
-    for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
-        bf16x8 a[AP][RB], b[NP][NC];
+    auto load_b = [&](int k0, bf16x8 (&b)[NP][NC]) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 b[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + ((size_t)c * Kh_pad + k0) * 16);
-            if (p < AP) {
+    };
+    auto load_a = [&](int k0, bf16x8 (&a)[AP][RB]) {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-                    a[p][rb] = *reinterpret_cast<const bf16x8 *>(a_ptr + p * plane_stride + rb * 16 * ldh + k0);
-            }
-        }
+        for (int p = 0; p < AP; ++p)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                a[p][rb] = *reinterpret_cast<const bf16x8 *>(a_ptr + p * plane_stride + rb * 16 * ldh + k0);
+    };
+    auto mma = [&](const bf16x8 (&a)[AP][RB], const bf16x8 (&b)[NP][NC]) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -453,10 +458,10 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
                 f32x4 v = acc[rb][c];
                 // smallest terms first
                 if constexpr (FMT == 2) {
-                    if (!A1) v = mfma_h<2>(a[1 % AP][rb], b[0][c], v);
+                    if constexpr (!A1) v = mfma_h<2>(a[1 % AP][rb], b[0][c], v);
                     v = mfma_h<2>(a[0][rb], b[1][c], v);
                     v = mfma_h<2>(a[0][rb], b[0][c], v);
-                } else if (A1) {
+                } else if constexpr (A1) {
                     v = mfma_h<1>(a[0][rb], b[2 % NP][c], v);
                     v = mfma_h<1>(a[0][rb], b[1][c], v);
                     v = mfma_h<1>(a[0][rb], b[0][c], v);
@@ -470,6 +475,33 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
                 }
                 acc[rb][c] = v;
             }
+    };
+    if constexpr (FMT == 2 && NAQS_PH_DBUF) {
+        // f16x2: two planes of weight fragments are 32 VGPRs per chunk — room to keep the NEXT chunk's in flight under this
+        // chunk's MFMAs (with the three bf16 planes the same double buffer spilled, see above)
+        bf16x8 b0[NP][NC], b1[NP][NC], a[AP][RB];
+        load_b(0, b0);
+        int k0 = 0;
+        for (; k0 + 64 <= Kh_pad; k0 += 64) {
+            load_b(k0 + 32, b1);
+            load_a(k0, a);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(min(k0 + 64, Kh_pad - 32), b0);         // unconditional (clamped): a branch makes the s_waitcnt merge conservative
+            load_a(k0 + 32, a);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k0 < Kh_pad) { load_a(k0, a); mma(a, b0); }     // odd number of chunks: the last one is already loaded
+    } else {
+        for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
+            bf16x8 a[AP][RB], b[NP][NC];
+            load_b(k0, b);
+            load_a(k0, a);
+            mma(a, b);
+        }
     }
 }
 
