@@ -26,40 +26,70 @@ __device__ __forceinline__ void split3t_pair(float lo, float hi, uint32_t &w1, u
 }
 
 
+// two adjacent values -> two f16 planes (hi = f16(x), lo = f16(x - hi)), each packed as (x1 << 16) | x0
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t &w1, uint32_t &w2) {
+    const f16x2 h = {(_Float16)x0, (_Float16)x1};
+    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    w1 = __builtin_bit_cast(uint32_t, h);
+    w2 = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void split2(float x, ushort_t &h1, ushort_t &h2) {
+    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+    h1 = __builtin_bit_cast(ushort_t, h);
+    h2 = __builtin_bit_cast(ushort_t, l);
+}
+// 2^e with e clamped to what keeps every product of two scales finite
+__device__ __forceinline__ float pow2_clamped(int e) { return __uint_as_float((uint32_t)(127 + min(max(e, -40), 40)) << 23); }
+// floor(log2 x) of a non-negative float from its exponent field (zero / subnormal: -127; inf / nan: 128)
+__device__ __forceinline__ int exp_of(float x) { return (int)((__float_as_uint(x) >> 23) & 0xFFu) - 127; }
+
 // ------------------------------------------------------------------------------------------------
-// amplitude conditionals on the bf16 matrix cores, inside the phase kernel's workgroups (no amp_kernel launch):
-// one wave evaluates orbital pair n for a tile of 16 samples.  Layer 1: the +-1 inputs are exact in bf16, so
-// x . (W1_hi + W1_mid + W1_lo) is three 16x16x32 MFMAs per 16 hidden units (2n <= 30 inputs fit one K chunk);
-// the ReLU output is split into three planes through the wave's LDS scratch and layer 2 (Ha -> 5) is the usual
-// six-term bf16x3 product.  Weight fragments are pre-tiled per pair (pack_amp_mfma_kernel):
-//   W1 planes [3][Ha/16][64 lanes][8], W2 planes [3][Ha/32][64 lanes][8]   (bf16)
+// amplitude conditionals on the f16 matrix cores, inside the phase kernel's workgroups, the standalone amp_mfma_kernel
+// and the tree sampler: one wave evaluates orbital pair n for a tile of 16 samples, in the f16x2 split (two f16 planes
+// of the power-of-two-scaled value: three MFMAs per f32 product, see naqs_logpsi.hip) and TRANSPOSED, so that the hidden
+// activations never leave the registers:
+//   layer 1   H^T [Ha x 16] = W1 [Ha x 32] . X^T [32 x 16]: the weights are the A operand, the +-1 inputs (exact in f16;
+//             input 31 == 1 carries b1; 2n <= 30) the B operand -> D[row = hidden unit, col = sample]: a lane holds, for
+//             its sample, hidden units 16 ct + 4 kg + r of tile ct.
+//   layer 2   O^T [16 x 16] = W2 [16 x Ha] . H^T: exactly what a B operand wants — lane (sample, kg) supplies 8 values of
+//             the contraction index per 32-wide chunk; chunk kc takes tiles 2 kc and 2 kc + 1, i.e. slot j of lane-group
+//             kg is hidden unit 16 (2 kc + (j >> 2)) + 4 kg + (j & 3), and the W2 fragments are packed in that order.
+//   (Round 2 ran layer 1 with the samples as rows: the ReLU output then went through a per-wave LDS scratch — three
+//   bf16 planes written, a wave barrier, six 16-byte reads — to become layer 2's A operand.)
+// Fragments per pair (pack_amp_mfma_body): W1 planes [2][Ha/16][64 lanes][8], W2 planes [2][Ha/32][64 lanes][8] (f16), then
+// 16 floats: b2[0..8), c1 = s_h / s_w1 (layer-1 accumulator -> scaled activation), c2 = 1 / (s_h s_w2).
 // ------------------------------------------------------------------------------------------------
-// per pair: the fragments, then b2 as 16 floats
-__device__ __host__ __forceinline__ size_t amp_mfma_pair_elems(int Ha) { return (size_t)3 * 512 * ((Ha >> 4) + (Ha >> 5)) + 32; }
+__device__ __host__ __forceinline__ size_t amp_mfma_pair_elems(int Ha) { return (size_t)2 * 512 * ((Ha >> 4) + (Ha >> 5)) + 32; }
 
 // registers of one (tile, pair) work item: every global load is issued up front, one item ahead of its use
 template <int CT>
 struct AmpFrag {
-    bf16x8 w1[3][CT];
-    bf16x8 w2[3][CT / 2];
-    float b2;
+    bf16x8 w1[2][CT];
+    bf16x8 w2[2][CT / 2];
+    f32x4 b2;                // b2[4 (kg & 1) + r]: the outputs this lane's accumulator rows belong to
+    float c1, c2;
 };
 
 template <int CT>
 __device__ __forceinline__ void amp_mfma_load(const ushort_t *__restrict__ wp, int lane, AmpFrag<CT> &f) {
     constexpr int KC = CT / 2;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
             f.w1[p][ct] = *reinterpret_cast<const bf16x8 *>(wp + ((size_t)(p * CT + ct) * 64 + lane) * 8);
-    const ushort_t *w2 = wp + (size_t)3 * CT * 512;
+    const ushort_t *w2 = wp + (size_t)2 * CT * 512;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
             f.w2[p][kc] = *reinterpret_cast<const bf16x8 *>(w2 + ((size_t)(p * KC + kc) * 64 + lane) * 8);
-    f.b2 = reinterpret_cast<const float *>(w2 + (size_t)3 * KC * 512)[lane & 15];
+    const float *cst = reinterpret_cast<const float *>(w2 + (size_t)2 * KC * 512);
+    f.b2 = *reinterpret_cast<const f32x4 *>(cst + 4 * ((lane >> 4) & 1));
+    f.c1 = cst[8];
+    f.c2 = cst[9];
 }
 
 // max(x, 0) in one instruction: fmaxf() canonicalises an operand that is not known to be quiet (a matrix-core result)
@@ -69,88 +99,71 @@ __device__ __forceinline__ void amp_mfma_load(const ushort_t *__restrict__ wp, i
 // VALU read of its result, and the read then returns the previous contents of the accumulator — measured.)
 __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
-// one wave, one (tile of 16 samples, pair n): the block's 5 raw outputs -> outs[sample][8]
+__device__ __forceinline__ f32x4 mfma_f16(const bf16x8 &a, const bf16x8 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// one wave, one (tile of 16 samples, pair n): the block's 5 raw outputs -> outs[sample][8].  ab: the occupation strings
+// (alpha | beta << 16) of sample lane & 15.  No LDS scratch, no barrier: the caller orders its reads of outs.
 template <int CT>
 __device__ __forceinline__ void amp_mfma_item(const NetDims &d, const AmpFrag<CT> &f, int n, uint32_t ab,
-                                              int lane, ushort_t *__restrict__ hs, float *__restrict__ outs) {
-    constexpr int KC = CT / 2, HLD = CT * 16 + 8;
-    const int m = lane & 15, kg = lane >> 4;
+                                              int lane, float *__restrict__ outs) {
+    constexpr int KC = CT / 2;
+    const int s = lane & 15, kg = lane >> 4;
     const uint32_t mask = (1u << n) - 1u;
-    {
-        const uint32_t abits = ab & mask, bbits = (ab >> 16) & mask;
-        const bool swap = d.sym && abits > bbits;                               // nade.py:519-530
-        const uint32_t xbits = (swap ? bbits : abits) | ((swap ? abits : bbits) << n);
-        // this lane's 8 inputs k = 8 kg .. 8 kg + 7 as four bf16 pairs: +-1 for k < 2n (2n is even: a pair is valid or not
-        // as a whole), 0 beyond, and input 31 the constant 1 that carries b1 (2n <= 30)
-        const uint32_t tb = xbits >> (8 * kg);
-        const int nv = min(max(2 * n - 8 * kg, 0), 8) >> 1;
-        uint32_t aw[4];
+    const uint32_t abits = ab & mask, bbits = (ab >> 16) & mask;
+    const bool swap = d.sym && abits > bbits;                                   // nade.py:519-530
+    const uint32_t xbits = (swap ? bbits : abits) | ((swap ? abits : bbits) << n);
+    // this lane's 8 inputs k = 8 kg .. 8 kg + 7 as four f16 pairs: +-1 for k < 2n (2n is even: a pair is valid or not as a
+    // whole), 0 beyond, and input 31 the constant 1 that carries b1 (2n <= 30)
+    const uint32_t tb = xbits >> (8 * kg);
+    const int nv = min(max(2 * n - 8 * kg, 0), 8) >> 1;
+    uint32_t aw[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t w = 0xBF80BF80u ^ ((tb << (15 - 2 * j)) & 0x8000u) ^ ((tb << (30 - 2 * j)) & 0x80000000u);
-            aw[j] = j < nv ? w : 0u;
-        }
-        if (kg == 3) aw[3] |= 0x3F800000u;
-        bf16x8 ax;
-        __builtin_memcpy(&ax, aw, sizeof(ax));
-        f32x4 acc[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 2; p >= 0; --p)                                            // smallest plane first; CT independent chains
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, f.w1[p][ct], acc[ct], 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                       // D: row = 4 kg + r (sample); tile ct of lane m = hidden unit CT m + ct
-            ushort_t *dst = hs + (4 * kg + r) * HLD + CT * m;
-            uint32_t a1, a2, a3;
-            split3t_pair(relu1(acc[0][r]), relu1(acc[1][r]), a1, a2, a3);
-            if (CT == 4) {
-                uint32_t b1, b2, b3;
-                split3t_pair(relu1(acc[2 % CT][r]), relu1(acc[3 % CT][r]), b1, b2, b3);
-                *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2 *>(dst + 16 * HLD) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2 *>(dst + 32 * HLD) = make_uint2(a3, b3);
-            } else {
-                *reinterpret_cast<uint32_t *>(dst) = a1;
-                *reinterpret_cast<uint32_t *>(dst + 16 * HLD) = a2;
-                *reinterpret_cast<uint32_t *>(dst + 32 * HLD) = a3;
-            }
-        }
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = 0xBC00BC00u ^ ((tb << (15 - 2 * j)) & 0x8000u) ^ ((tb << (30 - 2 * j)) & 0x80000000u);
+        aw[j] = j < nv ? w : 0u;
     }
-    // the scratch is private to this wave: LDS operations of a wave complete in order, so a wave-level fence suffices
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        f32x4 v[KC];
+    if (kg == 3) aw[3] |= 0x3C000000u;
+    bf16x8 x;
+    __builtin_memcpy(&x, aw, sizeof(x));
+    f32x4 acc[CT];
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {                                       // one accumulation chain per K chunk
-            bf16x8 a[3];
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                a[p] = *reinterpret_cast<const bf16x8 *>(hs + p * 16 * HLD + m * HLD + kc * 32 + 8 * kg);
-            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], f.w2[1][kc], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], f.w2[0][kc], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], f.w2[2][kc], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], f.w2[0][kc], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], f.w2[1][kc], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], f.w2[0][kc], c, 0, 0, 0);
-            v[kc] = c;
+    for (int p = 1; p >= 0; --p)                                                // smallest plane first; CT independent chains
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma_f16(f.w1[p][ct], x, acc[ct]);
+    f32x4 v[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {                                           // one accumulation chain per K chunk
+        uint32_t hh[4], hl[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 &a = acc[2 * kc + t];
+            split2_pair(relu1(a[0]) * f.c1, relu1(a[1]) * f.c1, hh[2 * t], hl[2 * t]);
+            split2_pair(relu1(a[2]) * f.c1, relu1(a[3]) * f.c1, hh[2 * t + 1], hl[2 * t + 1]);
         }
-        if (m < 8) {                                                            // D: row = 4 kg + r (sample), col = m (output)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o = v[0][r];
-#pragma unroll
-                for (int kc = 1; kc < KC; ++kc) o += v[kc][r];
-                outs[(4 * kg + r) * 8 + m] = o + f.b2;
-            }
-        }
+        bf16x8 bh, bl;
+        __builtin_memcpy(&bh, hh, sizeof(bh));
+        __builtin_memcpy(&bl, hl, sizeof(bl));
+        f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+        c = mfma_f16(f.w2[1][kc], bh, c);
+        c = mfma_f16(f.w2[0][kc], bl, c);
+        c = mfma_f16(f.w2[0][kc], bh, c);
+        v[kc] = c;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                                            // hs is rewritten by the wave's next item
+    if (kg < 2) {                                                               // D: row = 4 kg + r (output), col = s (sample)
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = v[0][r];
+#pragma unroll
+            for (int kc = 1; kc < KC; ++kc) t += v[kc][r];
+            o[r] = fmaf(t, f.c2, f.b2[r]);
+        }
+        *reinterpret_cast<f32x4 *>(outs + s * 8 + 4 * kg) = o;
+    }
 }
 
 }  // namespace naqs

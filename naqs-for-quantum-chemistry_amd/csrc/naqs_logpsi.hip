@@ -396,8 +396,12 @@ __host__ __device__ __forceinline__ int tile_col(int cb, int nn, int N_pad) {
 // is hi hi + hi lo + lo hi: THREE MFMAs instead of six; the dropped lo lo is <= 2^-24 |ab|.  The scales keep every tensor
 // high in the f16 range (largest entries at 2^13..2^15), so lo is a normal f16 for entries down to 2^-17 of the largest and
 // degrades gracefully (absolute error 2^-25 on the scaled value) below that.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+using naqs::f16x8;
+using naqs::f16x2;
+using naqs::split2_pair;
+using naqs::split2;
+using naqs::pow2_clamped;
+using naqs::exp_of;
 template <int FMT> struct fmt_planes { static constexpr int value = FMT == 2 ? 2 : 3; };
 
 template <int FMT>
@@ -406,19 +410,6 @@ __device__ __forceinline__ f32x4 mfma_h(const bf16x8 &a, const bf16x8 &b, const 
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
-// two adjacent values -> the two f16 planes, each packed as (x1 << 16) | x0
-__device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t &w1, uint32_t &w2) {
-    const f16x2 h = {(_Float16)x0, (_Float16)x1};
-    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
-    w1 = __builtin_bit_cast(uint32_t, h);
-    w2 = __builtin_bit_cast(uint32_t, l);
-}
-__device__ __forceinline__ void split2(float x, ushort_t &h1, ushort_t &h2) {
-    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
-    h1 = __builtin_bit_cast(ushort_t, h);
-    h2 = __builtin_bit_cast(ushort_t, l);
 }
 
 // A1: the activations have a single non-zero plane (layer 0: the +-1 / 0 inputs are exact in bf16 and f16) -> one term per
@@ -479,6 +470,25 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
     if constexpr (FMT == 2 && NAQS_PH_DBUF) {
         // f16x2: two planes of weight fragments are 32 VGPRs per chunk — room to keep the NEXT chunk's in flight under this
         // chunk's MFMAs (with the three bf16 planes the same double buffer spilled, see above)
+#if NAQS_PH_DBUF == 2
+        bf16x8 b0[NP][NC], b1[NP][NC], a0[AP][RB], a1[AP][RB];
+        load_b(0, b0);
+        load_a(0, a0);
+        int k0 = 0;
+        for (; k0 + 64 <= Kh_pad; k0 += 64) {
+            load_b(k0 + 32, b1);
+            load_a(k0 + 32, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(min(k0 + 64, Kh_pad - 32), b0);
+            load_a(min(k0 + 64, Kh_pad - 32), a0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k0 < Kh_pad) mma(a0, b0);
+#else
         bf16x8 b0[NP][NC], b1[NP][NC], a[AP][RB];
         load_b(0, b0);
         int k0 = 0;
@@ -495,6 +505,7 @@ __device__ __forceinline__ void mlp_accumulate_h(const ushort_t *__restrict__ a_
             __builtin_amdgcn_sched_barrier(0);
         }
         if (k0 < Kh_pad) { load_a(k0, a); mma(a, b0); }     // odd number of chunks: the last one is already loaded
+#endif
     } else {
         for (int k0 = 0; k0 < Kh_pad; k0 += 32) {
             bf16x8 a[AP][RB], b[NP][NC];
@@ -762,14 +773,13 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
                                                   const uint64_t *__restrict__ keys, const ElocFeed &feed, uint32_t *s_ab,
                                                   float (*s_lan)[RB * 16], ushort_t *__restrict__ planes, int tid,
                                                   long long *clk) {
-    constexpr int HLD = CT * 16 + 8, BM = RB * 16;
+    constexpr int BM = RB * 16;
     const int lane = tid & 63, wave = tid >> 6;
-    ushort_t *hs = planes + (size_t)wave * (48 * HLD);                     // per wave: 3 planes [16][HLD] bf16
-    float *s_o = reinterpret_cast<float *>(planes + (size_t)PH_WAVES * (48 * HLD));       // [P][BM][8] raw outputs
+    float *s_o = reinterpret_cast<float *>(planes);                        // [P][BM][8] raw outputs
     const size_t pair_elems = amp_mfma_pair_elems(CT * 16);
     const int P = d.P, items = RB * P;
     // items in pair-major order (q = n * RB + t), a contiguous range per wave: consecutive items share the pair, so its
-    // 18 KB of fragments are fetched once per wave (the CU's 64 B/clk vector-memory path is what bounds this stage) and
+    // 12 KB of fragments are fetched once per wave (the CU's 64 B/clk vector-memory path is what bounds this stage) and
     // the next pair's are in flight while the current one is used
     const int q0 = items * wave / PH_WAVES, q1 = items * (wave + 1) / PH_WAVES;
     AmpFrag<CT> f0, f1;
@@ -804,11 +814,11 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
         if (n == na) {
             if (nb < n && n_last > n) { nb = n + 1; amp_mfma_load<CT>(wamp + (size_t)nb * pair_elems, lane, f1); }
             __builtin_amdgcn_sched_barrier(0);
-            amp_mfma_item<CT>(d, f0, n, ab, lane, hs, outs);
+            amp_mfma_item<CT>(d, f0, n, ab, lane, outs);
         } else {
             if (na < n && n_last > n) { na = n + 1; amp_mfma_load<CT>(wamp + (size_t)na * pair_elems, lane, f0); }
             __builtin_amdgcn_sched_barrier(0);
-            amp_mfma_item<CT>(d, f1, n, ab, lane, hs, outs);
+            amp_mfma_item<CT>(d, f1, n, ab, lane, outs);
         }
         if (clk != nullptr && blockIdx.x == 0 && lane == 0 && q - q0 < 4) clk[wave * 16 + 11 + (q - q0)] = clock64();
     }
@@ -846,8 +856,7 @@ template <int CT>
 __global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void amp_mfma_kernel(const NetDims d, const ushort_t *__restrict__ wamp, int64_t M,
                                                                    const uint64_t *__restrict__ keys,
                                                                    float *__restrict__ scratch, const ElocFeed feed) {
-    constexpr int HLD = CT * 16 + 8;
-    extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
+    __shared__ __attribute__((aligned(16))) float s_outs[AMPK_WAVES][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = d.P;
     const int64_t g = (int64_t)blockIdx.x * AMPK_WAVES + wave;
@@ -855,8 +864,7 @@ __global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const int n = (int)(g - grp * P);
     const int64_t row0 = grp * (AMPK_TG * 16);
     if (row0 >= M) return;                                                       // wave-uniform
-    ushort_t *hs = planes + (size_t)wave * (48 * HLD);                           // per wave: 3 planes [16][HLD] bf16
-    float *outs = reinterpret_cast<float *>(planes + (size_t)AMPK_WAVES * (48 * HLD)) + wave * 128;   // [16][8] raw outputs
+    float *outs = s_outs[wave];                                                  // [16][8] raw outputs
     AmpFrag<CT> f;
     amp_mfma_load<CT>(wamp + (size_t)n * amp_mfma_pair_elems(CT * 16), lane, f);
     const int64_t i = row0 + (lane & (AMPK_TG * 16 - 1));
@@ -874,7 +882,10 @@ __global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu
     for (int t = 0; t < AMPK_TG; ++t) {
         if (row0 + t * 16 < M) {                                                 // wave-uniform
             const uint32_t ab = (uint32_t)__shfl((int)ab_all, t * 16 + (lane & 15), 64);
-            amp_mfma_item<CT>(d, f, n, ab, lane, hs, outs);
+            amp_mfma_item<CT>(d, f, n, ab, lane, outs);
+            // outs is private to this wave: LDS operations of a wave complete in order, so a wave-level fence suffices
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int64_t i2 = row0 + t * 16 + lane;
             if (lane < 16 && i2 < M) {
@@ -885,6 +896,8 @@ __global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 const int occ = (int)((ab >> n) & 1u) + 2 * (int)((ab >> (16 + n)) & 1u);
                 scratch[(int64_t)n * M + i2] = naqs::amp_finish(d, n, o, ab & mask, (ab >> 16) & mask, occ);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                     // outs is rewritten by the next tile's item
         }
     }
     // fused log-psi + E_loc call: the waves of pair 0 narrow the keys and insert them into the E_loc hash table
@@ -1036,11 +1049,6 @@ __global__ __launch_bounds__(256) void net_bounds_kernel(const float *__restrict
     }
 }
 
-// 2^e with e clamped to what keeps every product of two scales finite
-__device__ __forceinline__ float pow2_clamped(int e) { return __uint_as_float((uint32_t)(127 + min(max(e, -40), 40)) << 23); }
-// floor(log2 x) of a non-negative float from its exponent field (zero / subnormal: -127; inf / nan: 128)
-__device__ __forceinline__ int exp_of(float x) { return (int)((__float_as_uint(x) >> 23) & 0xFFu) - 127; }
-
 // weight scale of layer l: max |W| sw in [2^13, 2^14)
 __device__ __forceinline__ float phase_weight_scale(const naqs::PhaseRaw &raw, int l) {
     return pow2_clamped(13 - exp_of(__uint_as_float(raw.max_w[l])));
@@ -1095,37 +1103,65 @@ __device__ __forceinline__ void pack_phase_f16(const float *__restrict__ src, in
 // Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
 struct AmpSrcOff { int64_t off[MAXP]; };
 
-// amplitude blocks as MFMA operand fragments (3 bf16 planes): per pair W1 [3][Ha/16][64][8] then W2 [3][Ha/32][64][8]
+// amplitude blocks as MFMA operand fragments of the transposed f16x2 item (naqs_amp_mfma.hpp): per pair W1 planes
+// [2][Ha/16][64][8] (A operand: lane (m, kg) = hidden unit 16 ct + m, inputs 8 kg..8 kg + 7, input 31 = b1), W2 planes
+// [2][Ha/32][64][8] (A operand: lane (m, kg) = output m, slot j = hidden unit 16 (2 kc + (j >> 2)) + 4 kg + (j & 3)), then
+// 16 floats {b2[8], c1, c2}.  Every block of a pair derives the pair's scales itself (<= 1.6 k parameters).
 __device__ __forceinline__ void pack_amp_mfma_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
                                                    ushort_t *__restrict__ wamp, const int n) {
+    __shared__ float s_red[3][4];
     const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
     const int CT = Ha >> 4, KC = Ha >> 5;
     const float *src = flat + so.off[n];
-    const float *W1 = src, *W2 = src + Ha * nin + Ha;
+    const float *W1 = src, *b1 = src + Ha * nin, *W2 = src + Ha * nin + Ha;
+    // maxima: |W1|, |b1| (one scale: b1 rides in the W1 fragments), row bound sum_k |W1[j][k]| + |b1[j]| (inputs +-1), |W2|
+    float mw1 = 0.0f, mrow = 0.0f, mw2 = 0.0f;
+    for (int j = threadIdx.x; j < Ha; j += 256) {
+        float sum = fabsf(b1[j]);
+        mw1 = fmaxf(mw1, sum);
+        if (n > 0)
+            for (int k = 0; k < nin; ++k) { const float v = fabsf(W1[j * nin + k]); sum += v; mw1 = fmaxf(mw1, v); }
+        mrow = fmaxf(mrow, sum);
+        for (int c = 0; c < nout; ++c) mw2 = fmaxf(mw2, fabsf(W2[c * Ha + j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mw1 = fmaxf(mw1, __shfl_xor(mw1, o, 64)); mrow = fmaxf(mrow, __shfl_xor(mrow, o, 64)); mw2 = fmaxf(mw2, __shfl_xor(mw2, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = mw1; s_red[1][threadIdx.x >> 6] = mrow; s_red[2][threadIdx.x >> 6] = mw2; }
+    __syncthreads();
+    mw1 = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+    mrow = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    mw2 = fmaxf(fmaxf(s_red[2][0], s_red[2][1]), fmaxf(s_red[2][2], s_red[2][3]));
+    const float sw1 = pow2_clamped(13 - exp_of(mw1)), sh = pow2_clamped(14 - exp_of(mrow)), sw2 = pow2_clamped(13 - exp_of(mw2));
     const size_t pair = amp_mfma_pair_elems(Ha);
     ushort_t *dst = wamp + (size_t)n * pair;
-    if (blockIdx.x == 0 && threadIdx.x < 16)
-        reinterpret_cast<float *>(dst + (size_t)3 * 512 * (CT + KC))[threadIdx.x] =
-            (int)threadIdx.x < nout ? src[Ha * nin + Ha + nout * Ha + threadIdx.x] : 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+        float v = 0.0f;
+        if ((int)threadIdx.x < nout) v = src[Ha * nin + Ha + nout * Ha + threadIdx.x];
+        else if (threadIdx.x == 8) v = sh / sw1;
+        else if (threadIdx.x == 9) v = (1.0f / sh) / sw2;
+        reinterpret_cast<float *>(dst + (size_t)2 * 512 * (CT + KC))[threadIdx.x] = v;
+    }
     const int frag1 = CT * 512, frag2 = KC * 512;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < frag1 + frag2; e += gridDim.x * 256) {
         float x;
         size_t o0, plane;
-        if (e < frag1) {            // e = (ct * 64 + l) * 8 + j  <-  W1[ct*16 + (l&15)][8 (l>>4) + j]
+        if (e < frag1) {            // e = (ct * 64 + l) * 8 + j  <-  W1[16 ct + (l & 15)][8 (l >> 4) + j]
             const int j = e & 7, l = (e >> 3) & 63, ct = e >> 9;
-            const int h = CT * (l & 15) + ct, k = 8 * (l >> 4) + j;      // a lane's CT tiles are CT adjacent hidden units
-            x = (n > 0 && k < nin) ? W1[h * nin + k] : (k == 31 ? src[Ha * nin + h] : 0.0f);     // input 31 == 1 carries b1
+            const int h = 16 * ct + (l & 15), k = 8 * (l >> 4) + j;
+            x = ((n > 0 && k < nin) ? W1[h * nin + k] : (k == 31 ? b1[h] : 0.0f)) * sw1;        // input 31 == 1 carries b1
             o0 = (size_t)e; plane = (size_t)frag1;
-        } else {                    // e' = (kc * 64 + l) * 8 + j  <-  W2[l&15][kc*32 + 8 (l>>4) + j]
+        } else {                    // e' = (kc * 64 + l) * 8 + j  <-  W2[l & 15][16 (2 kc + (j >> 2)) + 4 (l >> 4) + (j & 3)]
             const int e2 = e - frag1;
             const int j = e2 & 7, l = (e2 >> 3) & 63, kc = e2 >> 9;
-            const int c = l & 15, k = kc * 32 + 8 * (l >> 4) + j;
-            x = c < nout ? W2[c * Ha + k] : 0.0f;
-            o0 = (size_t)3 * frag1 + e2; plane = (size_t)frag2;
+            const int c = l & 15, k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+            x = c < nout ? W2[c * Ha + k] * sw2 : 0.0f;
+            o0 = (size_t)2 * frag1 + e2; plane = (size_t)frag2;
         }
-        ushort_t h1, h2, h3;
-        split3(x, h1, h2, h3);
-        dst[o0] = h1; dst[o0 + plane] = h2; dst[o0 + 2 * plane] = h3;
+        ushort_t h1, h2;
+        split2(x, h1, h2);
+        dst[o0] = h1; dst[o0 + plane] = h2;
     }
 }
 
@@ -1444,7 +1480,7 @@ static int pack_amp_fragments(naqs_net_t *net, const float *flat_dev, hipStream_
     const NetDims &d = net->dims;
     AmpSrcOff so;
     for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
-    const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
+    const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;          // elements of one plane
     hipLaunchKernelGGL(pack_amp_mfma_kernel, dim3((frag + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_wamp);
     HIP_TRY(hipGetLastError());
     net->wamp_fresh = true;
@@ -1549,7 +1585,7 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
     if (net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) != 0) {      // matrix-core form (0: the VALU amp_kernel)
         const int64_t waves = (M + AMPK_TG * 16 - 1) / (AMPK_TG * 16) * d.P;
         const unsigned grid = (unsigned)((waves + AMPK_WAVES - 1) / AMPK_WAVES);
-        const size_t lds = (size_t)AMPK_WAVES * (48 * (d.Ha + 8) * sizeof(unsigned short) + 128 * sizeof(float));
+        const size_t lds = 0;
         if (d.Ha == 64) hipLaunchKernelGGL(amp_mfma_kernel<4>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
         else hipLaunchKernelGGL(amp_mfma_kernel<2>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
         HIP_TRY(hipGetLastError());
@@ -1593,7 +1629,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const size_t lds_h16 = use_h ? phase_slab_bytes(d, fmt) : 0;
     const int rb_max = phase_rb_max(d, fmt);
     // amplitude conditionals inside the phase kernel (matrix cores) unless NAQS_AMP_MODE=0 or the width does not tile
-    const size_t amp_scratch = (size_t)PH_WAVES * 48 * (d.Ha + 8) * sizeof(unsigned short) + (size_t)d.P * rb_max * 16 * 8 * sizeof(float);
+    const size_t amp_scratch = (size_t)d.P * rb_max * 16 * 8 * sizeof(float);          // [P][BM][8] raw outputs of the items
     const bool amp_in_phase = use_h && net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
                               amp_scratch <= 150 * 1024;
     if (!amp_in_phase) {

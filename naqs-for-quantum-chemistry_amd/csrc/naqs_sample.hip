@@ -136,23 +136,23 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
     float t[5];
     if (wamp != nullptr) {
         // the block's MLP on the matrix cores: a wave's 64 lanes are 16 prefixes = one (tile, pair) item of the log-psi
-        // kernel's prologue (naqs_amp_mfma.hpp); s_w is then per-wave scratch (three planes of hidden activations + the
+        // kernel's prologue (naqs_amp_mfma.hpp); s_w is then per-wave scratch (the
         // raw outputs), not the pair's weights.  ~2.5 k cycles instead of the 5-8 k of four lanes walking 16 hidden units
         // each through LDS reads nothing hides (one wave per SIMD).
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int hld = d.Ha + 8;
-        naqs::ushort_t *hs = reinterpret_cast<naqs::ushort_t *>(const_cast<float *>(s_w)) + (size_t)wave * (48 * hld + 256);
-        float *outs = reinterpret_cast<float *>(hs + 48 * hld);
+        float *outs = const_cast<float *>(s_w) + (size_t)wave * 128;
         const uint32_t ab16 = (uint32_t)__shfl((int)ab, 4 * (lane & 15), 64);
         if (d.Ha == 64) {
             naqs::AmpFrag<4> f;
             naqs::amp_mfma_load<4>(wamp + (size_t)n * naqs::amp_mfma_pair_elems(64), lane, f);
-            naqs::amp_mfma_item<4>(d, f, n, ab16, lane, hs, outs);
+            naqs::amp_mfma_item<4>(d, f, n, ab16, lane, outs);
         } else {
             naqs::AmpFrag<2> f;
             naqs::amp_mfma_load<2>(wamp + (size_t)n * naqs::amp_mfma_pair_elems(32), lane, f);
-            naqs::amp_mfma_item<2>(d, f, n, ab16, lane, hs, outs);
+            naqs::amp_mfma_item<2>(d, f, n, ab16, lane, outs);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int c = 0; c < 5; ++c) t[c] = outs[(lane >> 2) * 8 + c];
@@ -552,17 +552,22 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     const int64_t cap = max_unique;
-    const int64_t nwg_cap = (cap + EXP_PARENTS - 1) / EXP_PARENTS;
-    // carve the scratch: 2 x (ab, cnt, prob), children counts / probs, workgroup totals, level sizes
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // carve the scratch: 2 x (ab, cnt, prob), children counts / probs, workgroup totals, level sizes.  The layout is a
+    // function of the ALLOCATION's capacity, not of this call's: calls with a smaller cap (evaluation / solve_H next to
+    // training) then find the look-back words (wg_state: "tag 0 = never written, never cleared") where the allocation
+    // zeroed them, instead of over bytes that earlier calls used for something else
+    const int64_t lay = std::max(cap, net->samp_cap);
+    const int64_t nwg_cap = (lay + EXP_PARENTS - 1) / EXP_PARENTS;
     size_t off = 0;
     size_t o_ab[2], o_cnt[2], o_prob[2];
     for (int i = 0; i < 2; ++i) {
-        o_ab[i] = off; off = align_up(off + (size_t)cap * sizeof(uint32_t));
-        o_cnt[i] = off; off = align_up(off + (size_t)cap * sizeof(int64_t));
-        o_prob[i] = off; off = align_up(off + (size_t)cap * sizeof(float));
+        o_ab[i] = off; off = align_up(off + (size_t)lay * sizeof(uint32_t));
+        o_cnt[i] = off; off = align_up(off + (size_t)lay * sizeof(int64_t));
+        o_prob[i] = off; off = align_up(off + (size_t)lay * sizeof(float));
     }
-    const size_t o_cc = off; off = align_up(off + (size_t)cap * 4 * sizeof(int64_t));
-    const size_t o_cp = off; off = align_up(off + (size_t)cap * 4 * sizeof(float));
+    const size_t o_cc = off; off = align_up(off + (size_t)lay * 4 * sizeof(int64_t));
+    const size_t o_cp = off; off = align_up(off + (size_t)lay * 4 * sizeof(float));
     const size_t o_wg = off; off = align_up(off + (size_t)nwg_cap * sizeof(uint32_t));
     const size_t o_ws = off; off = align_up(off + (size_t)nwg_cap * sizeof(unsigned long long));
     const size_t o_U = off; off = align_up(off + (size_t)U_SLOTS * sizeof(int64_t));
@@ -571,7 +576,8 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         if (net->d_samp) (void)hipFree(net->d_samp);
         net->d_samp = nullptr; net->samp_cap = 0;
         HIP_TRY(hipMalloc(&net->d_samp, off));
-        HIP_TRY(hipMemset(static_cast<char *>(net->d_samp) + o_ws, 0, (size_t)nwg_cap * sizeof(unsigned long long)));   // tag 0 = never written
+        // tag 0 = never written; on the call's own stream (a null-stream memset is not ordered against a non-blocking one)
+        HIP_TRY(hipMemsetAsync(static_cast<char *>(net->d_samp) + o_ws, 0, (size_t)nwg_cap * sizeof(unsigned long long), s));
         net->samp_cap = cap;
         net->samp_seq = 0;
     }
@@ -588,7 +594,6 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     b.wg_state = reinterpret_cast<unsigned long long *>(base + o_ws);
     b.U = reinterpret_cast<int64_t *>(base + o_U);
 
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     int64_t bound = 1;                                     // worst-case prefixes entering level n: min(4^n, cap)
     int n_first = 0;
@@ -597,7 +602,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     // round differently (f32 FMA chains vs the six-term bf16 split), so a draw may differ between them — never between
     // the ways of cutting the tree into launches, which all take the same form
     const naqs::ushort_t *wamp = (net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_SAMPLE_MFMA", 1) != 0) ? net->d_wamp : nullptr;
-    const size_t mf_wave_bytes = (size_t)(48 * (d.Ha + 8) + 256) * sizeof(unsigned short);
+    const size_t mf_wave_bytes = 128 * sizeof(float);                 // per wave: the raw outputs [16 prefixes][8] of its item
     // 0: per-level launches only, 1 (default): 4 levels / 256 threads, 2: 5 levels / 1024 threads — measured slower
     // (94 us against 38 + 18 for the fifth level on its own: sixteen latency-bound waves on one CU)
     const int head = naqs::env_int("NAQS_SAMPLE_HEAD", 1);

@@ -4,7 +4,7 @@
 set -e
 out=$1; shift
 name=$(basename "$out" .so)
-src=naqs-for-quantum-chemistry_amd/csrc
+src=${NAQS_SRC:-naqs-for-quantum-chemistry_amd/csrc}
 obj=build/ab/$name
 mkdir -p "$obj"
 pids=()
