@@ -45,12 +45,18 @@ for _p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 PROF_STRIDE = 10
-MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.5 PF dense")
 MFMA_F32_PEAK_TF = 157.3   # f32-in/f32-acc MFMA dense peak (MI355X_MICROARCH.md: = the f32 vector rate)
 N_CU, SIMD_PER_CU, VALU_CYCLES_PER_WAVE_INST, MAX_CLOCK_HZ = 256, 4, 2, 2.4e9   # MI355X_MICROARCH.md (SIMD-32: 2 cycles)
 N_KEY_SETS = 4
-PMC_TRAFFIC = "profiles/r02_pmc_traffic.json"
-PMC_ISSUE = "profiles/r02_pmc_issue.json"
+PMC_TRAFFIC = "profiles/r03_pmc_traffic.json"
+PMC_ISSUE = "profiles/r03_pmc_issue.json"
+
+
+def phase_format():
+    """Split format of the log-psi kernel (NAQS_PHASE_MODE, default 2): 2 = f16x2 (three f16 MFMA products per f32
+    product), 1 = bf16x3 (six bf16 products), 0 = exact-f32 MFMA."""
+    return int(os.environ.get("NAQS_PHASE_MODE", "2"))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -105,14 +111,16 @@ def logpsi_flops(n_qubits, M, amp_in_kernel=True):
     return f
 
 
-def logpsi_executed_flops(n_qubits, M):
-    """bf16 flops the matrix cores execute for the same launch: every f32 product is six bf16 products (three where one
-    operand is exact in bf16: the +-1 / 0 inputs of the phase MLP's first layer and of the amplitude blocks' first
-    layer)."""
+def logpsi_executed_flops(n_qubits, M, fmt=None):
+    """16-bit flops the matrix cores execute for the same launch.  f16x2 (fmt 2): every f32 product is three f16 products
+    (two where one operand is exact in f16: the +-1 / 0 inputs of the phase MLP's first layer and of the amplitude blocks'
+    first layer); bf16x3 (fmt 1): six (three) bf16 products in the phase MLP — the amplitude blocks are f16x2 in both."""
+    fmt = phase_format() if fmt is None else fmt
+    full, exact = (3, 2) if fmt == 2 else (6, 3)
     P = n_qubits // 2
     dims = [max(1, 2 * (P - 1)), 512, 512, 4]
-    f = 2.0 * M * (3 * dims[0] * dims[1] + 6 * dims[1] * dims[2] + 6 * dims[2] * dims[3])
-    f += 2.0 * M * sum(3 * max(1, 2 * n) * 64 + 6 * 64 * 5 for n in range(P))
+    f = 2.0 * M * (exact * dims[0] * dims[1] + full * dims[1] * dims[2] + full * dims[2] * dims[3])
+    f += 2.0 * M * sum(2 * max(1, 2 * n) * 64 + 3 * 64 * 5 for n in range(P))
     return f
 
 
@@ -381,7 +389,8 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup, dept
                                     f"accumulators (32 B), {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}, "
                                     f"{dist.get_world_size()} rank(s)") if use_dist else "none (single process)",
            "energy": float(s[0] / s[3]),
-           "eloc_kernel_us": t_eloc * 1e6, "logpsi_kernel_us": t_lp * 1e6}
+           "eloc_kernel_us": t_eloc * 1e6, "logpsi_kernel_us": t_lp * 1e6,
+           "eloc_kernel_name": hams[0].last_kernel(), "logpsi_kernel_name": nets[0].last_kernel()}
     b_alg = algorithmic_bytes(e - b, ham.K, ham.Kxy) if e > b else 0
     res["eloc_algorithmic_GBps"] = b_alg / t_eloc / 1e9 if t_eloc > 0 else 0.0
     issue = issue_roofline(f"{molecule}_{M}", t_eloc) if world == 1 else None
@@ -405,6 +414,17 @@ def _load_json(rel):
         return None
 
 
+def library_source_hash():
+    from naqs_amd import _lib
+    return _lib.load_library().naqs_source_hash().decode()
+
+
+def counters_match_library(pmc):
+    """A committed counter file is replayed only when it was collected on the kernels this run executes: tools/collect_pmc.py
+    stamps it with naqs_source_hash() (SHA-256 prefix of csrc/*.hip, *.hpp) of the library the passes ran."""
+    return bool(pmc) and pmc.get("_source_hash") == library_source_hash()
+
+
 def issue_roofline(workload_key, t_kernel_s):
     """VALU issue utilisation of eloc_kernel = wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed
     --pmc pass, tools/collect_pmc.py) x 2 cycles each (a wave64 VALU instruction occupies its SIMD-32 for 2 cycles,
@@ -413,6 +433,8 @@ def issue_roofline(workload_key, t_kernel_s):
     re-prices the same instruction count against THIS run's kernel duration at the clock the counter pass ran at."""
     pmc = _load_json(PMC_ISSUE)
     if not pmc or workload_key not in pmc or "eloc_kernel" not in pmc[workload_key] or t_kernel_s <= 0:
+        return None
+    if not counters_match_library(pmc):
         return None
     c = pmc[workload_key]["eloc_kernel"]
     clock = c.get("effective_clock_hz") or MAX_CLOCK_HZ
@@ -428,6 +450,63 @@ def issue_roofline(workload_key, t_kernel_s):
         out["insts_per_cu_cycle"] = total / (N_CU * c["kernel_cycles"])
         out["salu_insts_per_cu_cycle"] = c.get("SQ_INSTS_SALU", 0.0) / (N_CU * c["kernel_cycles"])
     return out
+
+
+def eloc_roofline(kernel_name, t_kernel_s, rows, K, Kxy, workload_key, t_isolated_s):
+    """The local-energy kernel is integer / bit work whose bound is instruction issue: `achieved` = VALU
+    wave-instructions per second from the committed counter pass re-priced at this run's kernel duration, `peak` = what
+    the chip's SIMD-32s can issue (a wave64 VALU instruction holds its SIMD for 2 cycles).  The survey's algorithmic-bytes
+    rate is kept beside it without a fraction: candidates that are rejected in registers never become bytes
+    (76 % of them on N2, more on Li2O), so it is not a DRAM rate and can exceed the HBM peak."""
+    b_alg = algorithmic_bytes(rows, K, Kxy)
+    roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G VALU wave-instructions/s", "frac": None,
+            "traffic": None, "kernel": kernel_name, "kernel_us": t_kernel_s * 1e6,
+            "algorithmic_bytes_rate": {"GBps": b_alg / t_kernel_s / 1e9 if t_kernel_s > 0 else 0.0, "bytes_per_launch": b_alg,
+                                       "note": "SURVEY 8d bytes / kernel time: an algorithmic rate, not DRAM traffic"}}
+    t_use = t_isolated_s if t_isolated_s else t_kernel_s
+    issue = issue_roofline(workload_key, t_use) if workload_key else None
+    if issue:
+        per_cycle = N_CU * SIMD_PER_CU / VALU_CYCLES_PER_WAVE_INST
+        roof["achieved"] = issue["valu_insts_per_launch"] / t_use / 1e9
+        roof["peak"] = per_cycle * issue["clock_hz"] / 1e9
+        roof["frac"] = issue["frac"]
+        issue["kernel_us_used"] = t_use * 1e6
+        roof["issue"] = issue
+    else:
+        roof["note"] = ("no committed counter pass for this workload on this library build (source hash "
+                        f"{library_source_hash()}): achieved / frac need tools/collect_pmc.py")
+    if t_isolated_s:
+        roof["isolated"] = {"kernel_us": t_isolated_s * 1e6, "algorithmic_GBps": b_alg / t_isolated_s / 1e9}
+    return roof
+
+
+def logpsi_roofline(kernel_name, t_s, n_qubits, rows, amp_in_kernel, t_isolated_s):
+    """`frac` is what the silicon does: executed 16-bit flops (three f16 MFMA products per f32 product in the f16x2 split,
+    six bf16 ones in bf16x3) against the dense bf16/f16 MFMA peak.  The algorithmic view — the network's f32 flops against
+    the f32-MFMA peak, the rate an exact-f32 kernel could reach at most — is kept under `f32_equivalent`; it may exceed 1."""
+    fmt = phase_format()
+    flops = logpsi_flops(n_qubits, rows, amp_in_kernel)
+    tf = flops / t_s / 1e12 if t_s > 0 else 0.0
+    if fmt == 0:
+        return {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                "traffic": None, "kernel": kernel_name, "kernel_us": t_s * 1e6, "algorithmic_flops_per_launch": flops}
+    exec_flops = logpsi_executed_flops(n_qubits, rows, fmt) if amp_in_kernel else flops
+    etf = exec_flops / t_s / 1e12 if t_s > 0 else 0.0
+    roof = {"bound": "mfma", "achieved": etf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": etf / MFMA_BF16_PEAK_TF,
+            "traffic": None, "dtype_executed": ("f16" if fmt == 2 else "bf16") + " (f32 accumulate)", "kernel": kernel_name,
+            "kernel_us": t_s * 1e6, "executed_flops_per_launch": exec_flops, "algorithmic_flops_per_launch": flops,
+            "f32_equivalent": {"achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF}}
+    if t_isolated_s:
+        roof["isolated"] = {"kernel_us": t_isolated_s * 1e6, "achieved": exec_flops / t_isolated_s / 1e12,
+                            "frac": exec_flops / t_isolated_s / 1e12 / MFMA_BF16_PEAK_TF,
+                            "f32_equivalent_frac": flops / t_isolated_s / 1e12 / MFMA_F32_PEAK_TF}
+    return roof
+
+
+def dtype_label():
+    fmt = phase_format()
+    net = {2: "f16x2-split MFMA, f32-equivalent", 1: "bf16x3-split MFMA, f32-equivalent", 0: "f32 MFMA"}[fmt if fmt in (0, 1, 2) else 2]
+    return f"f32 network ({net}) / f64 E_loc"
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -595,68 +674,22 @@ def worker(args):
 
     out = None
     if rank == 0:
-        b_alg = algorithmic_bytes(M, ham.K, ham.Kxy)
         t_kernel = kern_ms / max(launches, 1) * 1e-3
-        achieved = b_alg / t_kernel / 1e9 if t_kernel > 0 else 0.0
-        eloc_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "eloc_kernel",
-                     "kernel_us": t_kernel * 1e6, "algorithmic_bytes_per_launch": b_alg,
-                     "note": "algorithmic rate (SURVEY 8d bytes / kernel time): 76 % of the candidates are rejected by two "
-                             "popcounts and the tables are L2-resident, so this is not a DRAM rate — `traffic` is the DRAM "
-                             "bytes, `issue` the bound that actually applies (VALU issue slots)"}
-        amp_in_kernel = os.environ.get("NAQS_AMP_MODE", "1") == "1" and os.environ.get("NAQS_PHASE_MODE", "1") == "1"
-        flops = logpsi_flops(ham.n_qubits, M, amp_in_kernel)
         t_mlp = mlp_ms / max(mlp_launches, 1) * 1e-3
-        mlp_tf = flops / t_mlp / 1e12 if t_mlp > 0 else 0.0
-        # The kernel evaluates the f32 network with every operand split into three bf16 planes (six exact cross
-        # products per multiply on the bf16 matrix cores, f32 accumulate): f32-equivalent results (tests/
-        # test_nade_gpu.py compares against float64).  `achieved` = ALGORITHMIC f32 flops / time, priced against
-        # the dense f32-MFMA peak (the precision class of the computation); the executed-instruction view (6x
-        # as many bf16 flops against the 2.5 PFLOP/s bf16 peak) is given next to it.
-        bf16_mode = os.environ.get("NAQS_PHASE_MODE", "1") == "1"
-        exec_flops = logpsi_executed_flops(ham.n_qubits, M) if (bf16_mode and amp_in_kernel) else flops
-        exec_tf = exec_flops / t_mlp / 1e12 if t_mlp > 0 else 0.0
-        # `frac` is what the silicon does: executed bf16 flops against the dense bf16 MFMA peak.  The algorithmic view
-        # (f32 flops of the network against the f32-MFMA peak, the rate an exact-f32 kernel could reach at most) is kept
-        # under `f32_equivalent` — it may exceed 1, since six bf16 MFMAs cost less than the 16 f32-MFMA-equivalents of time
-        if bf16_mode:
-            mlp_roof = {"bound": "mfma", "achieved": exec_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": exec_tf / MFMA_BF16_PEAK_TF, "traffic": None, "dtype_executed": "bf16 (f32 accumulate)",
-                        "kernel": ("phase_kernel_bf16x3 (" + ("amplitude conditionals + " if amp_in_kernel else "") +
-                                   "phase MLP; f32 via 3-way bf16 split on the bf16 matrix cores)"),
-                        "kernel_us": t_mlp * 1e6, "executed_flops_per_launch": exec_flops,
-                        "algorithmic_flops_per_launch": flops,
-                        "f32_equivalent": {"achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                           "frac": mlp_tf / MFMA_F32_PEAK_TF}}
-        else:
-            mlp_roof = {"bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": mlp_tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "phase_kernel (f32 MFMA 16x16x4)",
-                        "kernel_us": t_mlp * 1e6, "algorithmic_flops_per_launch": flops}
+        amp_in_kernel = os.environ.get("NAQS_AMP_MODE", "1") == "1" and phase_format() >= 1
+        eloc_roof = eloc_roofline(ham.last_kernel(), t_kernel, M, ham.K, ham.Kxy, f"{args.molecule}_{M}",
+                                  serial["eloc_kernel_us"] * 1e-6 if serial and serial["eloc_kernel_us"] > 0 else None)
+        mlp_roof = logpsi_roofline(nets[0].last_kernel(), t_mlp, ham.n_qubits, M, amp_in_kernel,
+                                   serial["logpsi_kernel_us"] * 1e-6 if serial and serial["logpsi_kernel_us"] > 0 else None)
         # HBM bytes per launch: hardware counters, from the committed rocprofv3 --pmc passes of this same command
-        # (tools/collect_pmc.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 corrections applied there)
+        # (tools/collect_pmc.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 corrections applied there) — replayed only
+        # when the file was collected on the library build that is running (source hash)
         pmc = _load_json(PMC_TRAFFIC)
-        if pmc and args.molecule == "N2" and M == 10000:               # the PMC passes were taken on this workload
+        if counters_match_library(pmc) and args.molecule == "N2" and M == 10000:   # the PMC passes were taken on this workload
             for roof, name in ((eloc_roof, "eloc_kernel"), (mlp_roof, "phase_kernel")):
                 if name in pmc:
                     roof["traffic"] = pmc[name]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = {"replayed": True, "file": PMC_TRAFFIC}
-        if serial is not None:
-            # the same kernels with the GPU to themselves (one batch at a time): what the kernel itself achieves; the
-            # durations above are longer because the next batch's kernels share the CUs during the timed region
-            if serial["logpsi_kernel_us"] > 0:
-                tf = exec_flops / (serial["logpsi_kernel_us"] * 1e-6) / 1e12
-                pk = MFMA_BF16_PEAK_TF if bf16_mode else MFMA_F32_PEAK_TF
-                mlp_roof["isolated"] = {"kernel_us": serial["logpsi_kernel_us"], "achieved": tf, "frac": tf / pk}
-                if bf16_mode:
-                    mlp_roof["isolated"]["f32_equivalent_frac"] = flops / (serial["logpsi_kernel_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF
-            if serial["eloc_kernel_us"] > 0:
-                gb = b_alg / (serial["eloc_kernel_us"] * 1e-6) / 1e9
-                eloc_roof["isolated"] = {"kernel_us": serial["eloc_kernel_us"], "achieved": gb, "frac": gb / HBM_PEAK_GBS}
-        t_issue = (serial["eloc_kernel_us"] * 1e-6) if serial and serial["eloc_kernel_us"] > 0 else t_kernel
-        issue = issue_roofline(f"{args.molecule}_{M}", t_issue)
-        if issue:
-            issue["kernel_us_used"] = t_issue * 1e6
-            eloc_roof["issue"] = issue
+                    roof["traffic_source"] = {"replayed": True, "file": PMC_TRAFFIC, "source_hash": pmc["_source_hash"]}
         dominant, other = (mlp_roof, eloc_roof) if t_mlp >= t_kernel else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]
@@ -667,7 +700,7 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 network (bf16x3-split MFMA, f32-equivalent) / f64 E_loc", "data": "synthetic",
+            "dtype": dtype_label(), "data": "synthetic",
             "config": {"workload": f"{args.molecule} STO-3G ({ham.n_qubits} qubits, K={ham.K} Pauli terms, "
                                    f"Kxy={ham.Kxy}), {M} unique samples per GPU, 1xMI355X per rank",
                        "stages": "fused NADE log-psi eval (amp 1x64, phase 2x512; builds the key hash + psi table) + matrix-free E_loc "
@@ -704,21 +737,10 @@ def sharded_main(args, dev, world, rank, use_dist):
         rows, S = res["rows_per_rank"], res["logpsi_rows_per_rank"]
         from naqs_amd import packing  # noqa: F401
         K, Kxy = ham_p.K, len(np.unique(ham_p.xy))
-        b_alg = algorithmic_bytes(rows, K, Kxy)
-        gb = b_alg / t_eloc / 1e9 if t_eloc > 0 else 0.0
-        eloc_roof = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "eloc_kernel", "kernel_us": t_eloc * 1e6,
-                     "algorithmic_bytes_per_launch": b_alg,
-                     "note": "algorithmic rate (SURVEY 8d bytes / kernel time), not a DRAM rate: most candidates are rejected "
-                             "in registers / by the LDS Bloom filter — see `issue` for the bound that applies"}
-        if "eloc_issue" in res:
-            eloc_roof["issue"] = res.pop("eloc_issue")
-        flops, exec_flops = logpsi_flops(ham_p.n_qubits, S), logpsi_executed_flops(ham_p.n_qubits, S)
-        tf, etf = (flops / t_lp / 1e12, exec_flops / t_lp / 1e12) if t_lp > 0 else (0.0, 0.0)
-        mlp_roof = {"bound": "mfma", "achieved": etf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": etf / MFMA_BF16_PEAK_TF,
-                    "traffic": None, "kernel": "phase_kernel_bf16x3", "kernel_us": t_lp * 1e6, "dtype_executed": "bf16 (f32 accumulate)",
-                    "executed_flops_per_launch": exec_flops, "algorithmic_flops_per_launch": flops,
-                    "f32_equivalent": {"achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF}}
+        eloc_roof = eloc_roofline(res.pop("eloc_kernel_name", "eloc_kernel2"), t_eloc, rows, K, Kxy,
+                                  f"{args.molecule}_{args.samples}" if world == 1 else None, None)
+        res.pop("eloc_issue", None)
+        mlp_roof = logpsi_roofline(res.pop("logpsi_kernel_name", "phase_kernel_h"), t_lp, ham_p.n_qubits, S, True, None)
         dominant, other = (mlp_roof, eloc_roof) if t_lp >= t_eloc else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]
@@ -726,7 +748,7 @@ def sharded_main(args, dev, world, rank, use_dist):
                          f"row-sharded table",
                "value": res["value"], "unit": "unique samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f32 network (bf16x3-split MFMA, f32-equivalent) / f64 E_loc", "data": "synthetic",
+               "dtype": dtype_label(), "data": "synthetic",
                "config": {"workload": res["workload"], "collectives_per_step": res["collectives_per_step"],
                           "ranks": (f"{dist.get_world_size()} {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} rank(s)"
                                     if use_dist else "single process, no process group"),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 3
+#define NAQS_ABI_VERSION 4
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -49,6 +49,10 @@ enum naqs_psi_kind {
 };
 
 int naqs_abi_version(void);
+/* 16 hex digits: SHA-256 prefix of the kernel sources (the .hip and .hpp files under csrc) this library was built from.  No counterpart in
+ * the reference; it lets measurement tooling (bench.py, tools/collect_pmc.py) tie replayed hardware-counter files to the
+ * exact kernels they were collected on. */
+const char *naqs_source_hash(void);
 const char *naqs_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none) and its text. */
 int naqs_last_hip_error(void);
@@ -168,6 +172,9 @@ int naqs_csr_mv(int64_t rows, const double *data_dev, const int32_t *indices_dev
 int naqs_prof_enable(naqs_ham_t *h, int max_records);
 /* Synchronises the recorded events: total milliseconds and number of launches since enable. */
 int naqs_prof_read(naqs_ham_t *h, double *total_ms, int64_t *launches);
+/* Name (with template arguments) of the local-energy kernel the handle's most recent call launched, e.g.
+ * "eloc_kernel2<uint32_t, STAGE=2, NT=1024, BLOOM=0>"; empty before the first call.  Measurement aid (bench.py). */
+int naqs_ham_last_kernel(const naqs_ham_t *h, char *buf, int buf_len);
 /* Record only every stride-th launch (default 1): an event pair costs a few microseconds of queue time,
  * so a sparse sample keeps the timed region representative. */
 int naqs_prof_stride(naqs_ham_t *h, int stride);
@@ -225,6 +232,8 @@ int naqs_logpsi_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t
 int naqs_net_prof_enable(naqs_net_t *net, int max_records);
 int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches);
 int naqs_net_prof_stride(naqs_net_t *net, int stride);
+/* Name of the log-psi kernel the most recent naqs_net_logpsi / naqs_logpsi_eloc / training forward launched. */
+int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len);
 
 
 /* ================================================================================================

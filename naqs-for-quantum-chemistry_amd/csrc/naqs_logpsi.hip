@@ -1655,6 +1655,9 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
+    if (use_h) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_h<RB=%d, SAVE=%d, FMT=%d (%s)>%s", rb, save.x != nullptr ? 1 : 0,
+                             fmt, fmt == 2 ? "f16x2" : "bf16x3", amp_in_phase ? " incl. amplitude prologue" : "");
+    else std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel<RB=%d> (f32 MFMA)", rb);
     if (use_h) {
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
 #define NAQS_PH_LAUNCH(RB, FMT)                                                                                                         \
@@ -1742,6 +1745,12 @@ NAQS_API int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *laun
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     return net->prof.read(total_ms, launches);
+}
+
+NAQS_API int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len) {
+    if (!net || !buf || buf_len <= 0) return NAQS_ERR_INVALID;
+    std::snprintf(buf, (size_t)buf_len, "%s", net->aggregate ? "amp_mfma_kernel + amp_kernel(raw) + agg_finish_kernel" : net->last_kernel);
+    return NAQS_OK;
 }
 
 NAQS_API int naqs_net_prof_stride(naqs_net_t *net, int stride) {

@@ -191,6 +191,7 @@ struct naqs_net {
     bool have_wb = false;
     bool grad_attr_set = false;
     naqs::EventRing prof;
+    char last_kernel[96] = {0};             // naqs_net_last_kernel
 };
 
 namespace naqs {

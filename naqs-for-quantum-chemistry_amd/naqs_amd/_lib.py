@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(os.path.dirname(_HERE), "lib")
 
 NAQS_OK = 0
-ABI_VERSION = 3          # NAQS_ABI_VERSION of include/naqs_hip.h
+ABI_VERSION = 4          # NAQS_ABI_VERSION of include/naqs_hip.h
 PSI_F32, PSI_F64, LOGPSI_F32, LOGPSI_F64 = 0, 1, 2, 3
 
 c_i64, c_u64p, c_f64p, c_vp = ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
@@ -18,6 +18,7 @@ c_i64, c_u64p, c_f64p, c_vp = ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), c
 # symbol -> (restype, argtypes); mirrors include/naqs_hip.h one-to-one (tests/test_abi.py checks it)
 SIGNATURES = {
     "naqs_abi_version": (ctypes.c_int, []),
+    "naqs_source_hash": (ctypes.c_char_p, []),
     "naqs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "naqs_last_hip_error": (ctypes.c_int, []),
     "naqs_last_hip_error_string": (ctypes.c_char_p, []),
@@ -36,6 +37,8 @@ SIGNATURES = {
     "naqs_get_hij": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "naqs_hij_from_parity": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp]),
     "naqs_csr_mv": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_ham_last_kernel": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
+    "naqs_net_last_kernel": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "naqs_prof_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_prof_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "naqs_prof_stride": (ctypes.c_int, [c_vp, ctypes.c_int]),

@@ -335,6 +335,12 @@ class FusedLogPsi:
         _lib.check(self._lib.naqs_net_prof_read(self._h, ctypes.byref(ms), ctypes.byref(n)), "naqs_net_prof_read")
         return ms.value, n.value
 
+    def last_kernel(self):
+        """Name (with template arguments) of the kernel the most recent call launched (measurement aid)."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(self._lib.naqs_net_last_kernel(self._h, buf, 128), "naqs_net_last_kernel")
+        return buf.value.decode()
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.naqs_net_destroy(self._h)

@@ -198,6 +198,12 @@ class DevicePauliHamiltonian:
         _lib.check(self._lib.naqs_prof_read(self._h, ctypes.byref(ms), ctypes.byref(n)), "naqs_prof_read")
         return ms.value, n.value
 
+    def last_kernel(self):
+        """Name (with template arguments) of the kernel the most recent call launched (measurement aid)."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(self._lib.naqs_ham_last_kernel(self._h, buf, 128), "naqs_ham_last_kernel")
+        return buf.value.decode()
+
 
 def popcount_parity_device(arr):
     """Device counterpart of src.utils.hamiltonian_math.popcount_parity: int8 tensor, same shape.

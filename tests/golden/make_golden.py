@@ -475,6 +475,69 @@ def variants():
     gen_compat_lih()
 
 
+TRAJ_FLAGS = ["-single_phase", "-n1", "-n_layer", "1", "-n_hid", "64", "-n_layer_phase", "2", "-n_hid_phase", "512",
+              "-n_train", "10000", "-output_freq", "25", "-save_freq", "-1", "-full_mask_psi"]      # batch_train_full_mask.sh:14
+
+
+def gen_trajectory(mol, seed=111, threads=4):
+    """Whole-run known answer: the reference's own ``experiments/run.py`` entry (``experiments/_base.py:394-659`` ->
+    ``PartialSamplingOptimizer.run``, ``energy.py:902-1056``) with the flags of ``batch_train_full_mask.sh`` on one
+    geometry of the N2 sweep.  Only the molecule loader (needs openfermion / h5py: replaced by the repository's own
+    readers of the same files) and the plotting at the end are stubbed.  Writes ``traj_<mol>_s<seed>.json`` (final
+    energies, unique-sample counts along the run, wall time) which ``kat.json`` then indexes."""
+    import importlib
+    torch.set_num_threads(threads)
+    B = importlib.import_module("experiments._base")             # the REFERENCE's (scratch copy first on sys.path) ...
+    assert os.path.abspath(B.__file__).startswith(os.path.abspath(rh.SCRATCH)), B.__file__
+    sys.path.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "naqs-for-quantum-chemistry_amd"))
+    from naqs_amd import system as repo_system                 # ... the repository's file readers: no openfermion / h5py
+    from src.optimizer.utils import LogKey
+    made = []
+
+    class Spy(B.PartialSamplingOptimizer):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+
+    class _Fig:
+        def savefig(self, *a, **k):
+            pass
+
+    B.PartialSamplingOptimizer = Spy
+    B.load_molecule = lambda fname, hamiltonian_fname=None, verbose=True: repo_system.load_molecule(fname, hamiltonian_fname, verbose)
+    B.plot_training = lambda *a, **k: _Fig()
+    out = f"/tmp/golden_traj/{mol}_s{seed}"
+    argv = ["run", "-o", out, "-m", os.path.join(rh.REFERENCE, "molecules", mol), "-s", str(seed)] + TRAJ_FLAGS
+    old_argv, sys.argv = sys.argv, argv
+    t0 = time.time()
+    try:
+        # the keyword defaults of experiments/run.py:3-33, then the command line above on top of them
+        B.run(molecule=None, out=None, number=1, lr=-1, n_samps=1e7, n_samps_max=1e12, n_unq_samps_min=1e4, n_unq_samps_max=1e5,
+              n_hid=128, n_layer=1, reweight_samples_by_psi=False, n_train=10000, n_pretrain=0, output_freq=25, save_freq=-1,
+              load_hamiltonian=False, overwrite_hamiltonian=False, presolve_hamiltonian=False, cont=False, n_excitations_max=-1,
+              use_amp_spin_sym=True, use_phase_spin_sym=False, comb_amp_phase=False, aggregate_phase=True, restrict_H=True,
+              reset_opt=False)
+    finally:
+        sys.argv = old_argv
+    wall = time.time() - t0
+    opt = made[-1]
+    e_loc = np.array([e for _, e in opt.log[LogKey.E_LOC]], dtype=np.float64)
+    n_unq = np.array([n for _, n in opt.log[LogKey.N_UNIQUE_SAMP]], dtype=np.int64)
+    t_run = np.array([t for _, t in opt.log[LogKey.TIME]], dtype=np.float64)
+    w = 25
+    conv = np.convolve(e_loc, np.ones(w) / w, "valid")
+    rec = {"molecule": mol, "seed": seed, "flags": " ".join(TRAJ_FLAGS), "steps": int(len(e_loc)), "threads": threads,
+           "wall_s": wall, "train_s": float(t_run[-1]),
+           "final_E_loc": float(e_loc[-1]), "mean_last_100": float(e_loc[-100:].mean()), "min_E_loc": float(e_loc.min()),
+           "min_sliding_25": float(conv.min()),
+           "n_unq_every_500": [int(x) for x in n_unq[::500]], "n_unq_last": int(n_unq[-1]),
+           "E_loc_every_500": [float(x) for x in e_loc[::500]],
+           "where": "build container, reference experiments/run.py via tests/golden/ref_harness.py"}
+    with open(os.path.join(OUT, f"traj_{mol}_s{seed}.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print(f"[traj] {mol} seed {seed}: final {rec['final_E_loc']:.8f} mean100 {rec['mean_last_100']:.8f} in {wall:.0f} s")
+
+
 def main():
     kat = {}
     gen_molecule("LiH", {"c1": (150, 1.0), "half": (100, 2.0)}, (64, 32, 2), kat=kat)
@@ -496,5 +559,7 @@ if __name__ == "__main__":
         variants()
     if which == "compat":
         gen_compat_lih()
+    if which == "trajectory":           # python make_golden.py trajectory N2_2.25 [seed]   (~6 min on 4 threads)
+        gen_trajectory(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 111)
     if which == "check-LiH":            # re-derive one base fixture into $NAQS_GOLDEN_OUT (refactoring guard)
         gen_molecule("LiH", {"c1": (150, 1.0), "half": (100, 2.0)}, (64, 32, 2), kat={})

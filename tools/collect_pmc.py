@@ -58,9 +58,25 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items() if len(v) >= 10}
 
 
+def source_hash_of(path):
+    """naqs_source_hash() of the library the pass ran (the collecting script leaves it in <pass dir>/source_hash.txt):
+    bench.py replays a counter file only on the library build it was collected on."""
+    fn = os.path.join(path, "source_hash.txt")
+    if not os.path.exists(fn):
+        raise SystemExit(f"{fn} missing: run  python -c 'from naqs_amd import _lib; print(_lib.load_library()."
+                         f"naqs_source_hash().decode())' > {fn}  next to the rocprofv3 pass")
+    return open(fn).read().strip()
+
+
+def full_names(path):
+    return sorted({r["Kernel_Name"] for r in rows_of(path) if short_name(r["Kernel_Name"])})
+
+
 def traffic(fetch_dir, write_dir, out):
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
-    res = {}
+    res = {"_source_hash": source_hash_of(fetch_dir), "_kernels": full_names(fetch_dir)}
+    if source_hash_of(write_dir) != res["_source_hash"]:
+        raise SystemExit("the FETCH and WRITE passes ran different library builds")
     for name in sorted(set(fetch) | set(write)):
         short = short_name(name)
         if short is None:
@@ -104,6 +120,11 @@ def issue(path, workload_key, out):
             allres = json.load(f)
     except (OSError, ValueError):
         allres = {}
+    h = source_hash_of(path)
+    if allres.get("_source_hash", h) != h:
+        raise SystemExit(f"{out} holds counters of library build {allres['_source_hash']}, this pass ran {h}: start a new file")
+    allres["_source_hash"] = h
+    allres["_kernels"] = sorted(set(allres.get("_kernels", [])) | set(full_names(path)))
     allres[workload_key] = res
     with open(out, "w") as f:
         json.dump(allres, f, indent=1, sort_keys=True)
