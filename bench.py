@@ -221,21 +221,29 @@ def launch_ranks(n, argv):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    codes = []
+    # poll all ranks together: the first failing one ends the launch (the others would sit in a collective until the
+    # deadline); fresh children only, never a re-exec
     deadline = time.time() + float(os.environ.get("NAQS_BENCH_LAUNCH_TIMEOUT", "3600"))
-    for pr in procs:
-        try:
-            codes.append(pr.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            codes.append(124)
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    pr.kill()
+                    pr.wait()
+                    codes[i] = 124 if not failed else -9
+            break
+        time.sleep(0.05)
     bad = [c for c in codes if c != 0]
     if bad:
-        for pr in procs:           # one rank failed: the others would wait in a collective for ever
-            if pr.poll() is None:
-                pr.kill()
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-    return max(codes, key=abs) if bad else 0
+        first = next(c for c in codes if c not in (0, -9)) if any(c not in (0, -9) for c in codes) else bad[0]
+        return first
+    return 0
 
 
 def dry_run(args, world, rank):

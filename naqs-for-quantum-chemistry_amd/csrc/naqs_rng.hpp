@@ -62,6 +62,11 @@ struct RngStream {
 // (div_scale, rcp, five fmas, div_fmas, div_fixup) and these loops are latency-bound — one wave's draws are the critical
 // path of a whole tree level — so the reciprocal comes from v_rcp_f64 refined by two Newton steps (full double
 // accuracy for the well-scaled arguments that occur here: k + 1 >= 1, 1 - p >= 1/2, b >= 1.15, ...).
+// The host build (naqs_rng_binomial_host: known-answer and chi-square tests of the generator's DISTRIBUTION) divides
+// exactly, so host and device run the same algorithm but not bit-identical arithmetic: a last-ulp difference can flip a
+// floor() or an accept test, i.e. individual variates may differ between the two.  Bit-exact comparisons of draws are
+// therefore device-vs-device only (tests/test_sampler_gpu.py: launch fusions, head kernel); host/device agreement is
+// statistical.
 NAQS_HD double rcp_fast(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rcp(x);

@@ -167,7 +167,11 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
         exp_name_i = exp_name + (f"_{i}" if num_experiments > 1 else "")
         n_alpha, n_beta = molecule.get_n_alpha_electrons(), molecule.get_n_beta_electrons()
         if n_alpha != n_beta:
-            raise NotImplementedError("open-shell molecules (m_s != 0) are out of scope (BASELINE configs are closed-shell)")
+            # open shell: the reference restricts to m_s = S (restrict_to_ms=True is not a command-line option,
+            # experiments/_base.py:72, :101-123) — the same (n_alpha, n_beta)-restricted space with n_alpha != n_beta — and
+            # switches the amplitude spin symmetry off, which assumes interchangeable spin sectors
+            print("S!=0 and we are restricting ourselves to ms=S --> turning off use_amp_spin_sym as this is not helpful.")
+            use_amp_spin_sym = False
         print("\n--- Initialising Hilbert ---\n")
         hilbert = Hilbert.get(N=N, N_alpha=n_alpha, N_beta=n_beta, encoding=Encoding.SIGNED, make_basis=True,
                               verbose=verbose)

@@ -301,7 +301,7 @@ class FusedLogPsi:
         the float64 weights counts / sum(counts) written by the sampler's last launch (``naqs_net_sample_weighted``).
         Raises ``MaxBatchSizeExceededError`` when more than ``max_unique`` prefixes are alive at some level
         (nade.py:710-712).  One host synchronisation (to learn M); the results are views of buffers allocated for
-        this call (no copies)."""
+        this call (copies only when they would pin a much larger buffer)."""
         from .nade import MaxBatchSizeExceededError
         cap = int(max_unique)
         keys = torch.empty(cap, dtype=torch.int64, device=self.device)
@@ -322,9 +322,12 @@ class FusedLogPsi:
         m, overflow = info.tolist()
         if overflow:
             raise MaxBatchSizeExceededError
-        if with_weights:
-            return keys[:m], counts[:m], probs[:m], weights[:m]
-        return keys[:m], counts[:m], probs[:m]
+        out = (keys[:m], counts[:m], probs[:m]) + ((weights[:m],) if with_weights else ())
+        if 4 * m < cap and cap > (1 << 16):
+            # a view keeps its whole cap-sized buffer alive (28 B x cap: 117 MB at the evaluation path's cap of 2^22) for as
+            # long as the caller holds the result; the training path (cap = n_unq_samples_max) keeps its views
+            out = tuple(t.clone() for t in out)
+        return out
 
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")

@@ -51,7 +51,12 @@ N2_SWEEP = ["N2_0.75", "N2_0.9", "N2_1.05", "N2_1.2", "N2_1.35", "N2_1.5", "N2_1
 
 
 def electrons(mol):
-    return rh.ELECTRONS["N2" if mol.startswith("N2") else mol]
+    key = "N2" if mol.startswith("N2") else mol
+    if key in rh.ELECTRONS:
+        return rh.ELECTRONS[key]
+    v = molecule_scalars(mol)                       # (n_alpha, n_beta) with m_s = S, as experiments/_base.py:101-123 restricts
+    n, mult = int(v["n_electrons"]), int(v["multiplicity"])
+    return (n + mult - 1) // 2, (n - mult + 1) // 2
 
 
 def make_hilbert(mol, qh):
@@ -119,6 +124,35 @@ def gen_ham_only(mol):
     pack_hamiltonian(mol, ph, N, os.path.join(OUT, f"ham_{mol}.npz"))
     print(f"[ham] {mol}: N={N} K={len(ph.couplings)} Kxy={len(ph._unique_XY_sites_idx)} "
           f"Kyz={len(ph._unique_YZ_sites_idx)}")
+
+
+def reference_packing(mol):
+    qh = rh.load_qubit_hamiltonian(mol)
+    N = rh.n_qubits_of(qh)
+    ph = object.__new__(_PauliHamiltonianDynamic)
+    ph.hilbert, ph.qubit_hamiltonian = _StubHilbert(N), qh
+    ph.n_excitations_max, ph.dtype, ph.verbose = None, np.float64, False
+    xy, yz, c = ph._PauliHamiltonianDynamic__calc_coupling_info()
+    return N, np.asarray(xy).astype(np.uint64), np.asarray(yz).astype(np.uint64), np.asarray(c).squeeze().astype(np.float64)
+
+
+def gen_packing_hashes():
+    """SHA-256 of the reference's own term packing (hamiltonian.py:373-430: xy | yz | coeff, little-endian uint64 / uint64 /
+    float64, reference term order) for EVERY molecule folder it ships with a qubit-Hamiltonian pickle ->
+    packing_sha256.json; tests/test_packing.py holds naqs_amd.packing to them (build container: needs the folders)."""
+    import hashlib
+    out = {}
+    root = os.path.join(rh.REFERENCE, "molecules")
+    for mol in sorted(os.listdir(root)):
+        if not os.path.exists(os.path.join(root, mol, f"{mol}_qubit_hamiltonian.pkl")):
+            continue
+        N, xy, yz, c = reference_packing(mol)
+        h = hashlib.sha256(xy.tobytes() + yz.tobytes() + c.tobytes()).hexdigest()
+        out[mol] = {"n_qubits": int(N), "K": int(len(c)), "Kxy": int(len(np.unique(xy))), "Kyz": int(len(np.unique(yz))),
+                    "sha256": h}
+        print(f"[packing] {mol}: N={N} K={len(c)} {h[:16]}")
+    with open(os.path.join(OUT, "packing_sha256.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
 
 
 def gen_li2o_subset():
@@ -366,8 +400,9 @@ VARIANTS = {
     # batch_train_no_mask.sh:14 / batch_train_full_mask.sh:14 (the N2 sweep, N2_energy_surface.sh:5-8)
     "nomask": (dict(), "small", NadeMasking.NONE),
     "fullmask": (dict(), None, NadeMasking.FULL),
+    "fullmask_noampsym": (dict(use_amp_spin_sym=False), None, NadeMasking.FULL),
 }
-PUBLISHED_CFG = {"LiH": (64, 32, 2), "H2O": (64, 32, 2)}        # small phase nets for the small fixtures; else 64/512x2
+PUBLISHED_CFG = {"LiH": (64, 32, 2), "H2O": (64, 32, 2), "CH2": (64, 32, 2)}        # small phase nets for the small fixtures; else 64/512x2
 SMALL_CFG = {"N2": (64, 128, 2)}                                 # keeps the fixture small where the 512-wide phase net is not the point
 
 
@@ -473,6 +508,14 @@ def variants():
     for mol in ("N2_0.75", "N2_2.25"):
         gen_variant(mol, "fullmask", with_eloc={"c2": (10000, 2.0)})
     gen_compat_lih()
+    gen_open_shell()
+
+
+def gen_open_shell():
+    """Open-shell molecule restricted to m_s = S (experiments/_base.py:101-123: CH2 is a triplet -> 5 alpha / 3 beta
+    electrons, amplitude spin symmetry switched off): network vectors, sampler draw, _SGD_step and E_loc."""
+    gen_variant("CH2", "noampsym", with_eloc={"c1": (400, 1.5)})
+    gen_variant("CH2", "fullmask_noampsym")
 
 
 TRAJ_FLAGS = ["-single_phase", "-n1", "-n_layer", "1", "-n_hid", "64", "-n_layer_phase", "2", "-n_hid_phase", "512",
@@ -559,6 +602,13 @@ if __name__ == "__main__":
         variants()
     if which == "compat":
         gen_compat_lih()
+    if which == "open-shell":
+        gen_open_shell()
+    if which == "packing":              # python make_golden.py packing   (every molecule folder; seconds)
+        gen_packing_hashes()
+    if which == "ham":                  # python make_golden.py ham PH3 H4O2 C2 ...   (packed-term fixtures only)
+        for mol in sys.argv[2:]:
+            gen_ham_only(mol)
     if which == "trajectory":           # python make_golden.py trajectory N2_2.25 [seed]   (~6 min on 4 threads)
         gen_trajectory(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 111)
     if which == "check-LiH":            # re-derive one base fixture into $NAQS_GOLDEN_OUT (refactoring guard)

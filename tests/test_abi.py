@@ -84,3 +84,22 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.NaqsError):
         _lib.load_library()
+
+
+@pytest.mark.gpu
+def test_torch_free_cpp_client_through_the_c_abi(tmp_path):
+    """tools/abi_smoke.cpp: a C++ program that includes only include/naqs_hip.h and links libnaqs_hip.so — no Python, no
+    torch in the process — creates a Hamiltonian handle from a dumped golden case (LiH and N2, the reference's own
+    E_loc values), runs naqs_eloc and compares.  The binary is built by __graft_entry__.build() (or here if missing)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    exe = ge.build_abi_smoke()
+    for mol, tag in (("LiH", "c1"), ("N2", "small")):
+        dump = str(tmp_path / f"{mol}.bin")
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "dump_case.py"), mol, tag, dump])
+        r = subprocess.run([exe, dump], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "-> OK" in r.stdout, r.stdout

@@ -313,6 +313,51 @@ def test_li2o_subset_vs_oracle(env):
     assert rel_err(e, want) < 1e-10
 
 
+def clustered_keys(h, M, seed):
+    """M physical keys grown from one determinant by the Hamiltonian's own flip masks, so that couplings do hit."""
+    N, na, nb = int(h["n_qubits"]), int(h["n_alpha"]), int(h["n_beta"])
+    am = sum(1 << q for q in range(0, N, 2))
+    bm = sum(1 << q for q in range(1, N, 2))
+    rs = np.random.RandomState(seed)
+    base = int(random_physical_keys(N, na, nb, 1, seed)[0])
+    keys, frontier = {base}, [base]
+    uxy = np.unique(h["xy"])
+    while len(keys) < M:
+        k = frontier[rs.randint(len(frontier))]
+        j = k ^ int(uxy[rs.randint(len(uxy))])
+        if bin(j & am).count("1") == na and bin(j & bm).count("1") == nb and j not in keys:
+            keys.add(j)
+            frontier.append(j)
+    return np.sort(np.array(list(keys), np.uint64))
+
+
+@pytest.mark.parametrize("mol", ["PH3", "H4O2", "C2", "CH2", "O2"])
+def test_hamiltonian_shapes_beyond_baseline_vs_oracle(env, mol):
+    """Shapes BASELINE never selects: PH3 (24 qubits, 24 369 Pauli strings — more terms than Li2O), H4O2 (28 qubits,
+    28 393 strings: the term tables no longer fit the LDS budget -> STAGE 1), C2 (20 qubits), and the open-shell
+    triplets CH2 (5 alpha / 3 beta) and O2 (9 / 7) whose sectors have n_alpha != n_beta.  Packing of each is pinned to
+    the reference's by tests/test_packing.py; E_loc at M = 2 000 against the pinned oracle."""
+    h = golden(f"ham_{mol}.npz")
+    ham = dev_ham(env, mol)
+    keys = clustered_keys(h, 2000, 21)
+    lp = synth_logpsi(len(keys), 12)
+    psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
+    e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+    print(mol, ham.last_kernel())
+    want = env["O"].eloc_matrix_free(h["xy"], h["yz"], h["coeff"], keys, psi)
+    assert rel_err(e, want) < 1e-10
+    n_conn = np.count_nonzero(np.abs(want - want.real.mean()) > 0)        # the test is vacuous if nothing couples
+    assert n_conn > len(keys) // 2
+    # every LDS-staging tier the size selects or allows must agree bit for bit
+    for stage in ("0", "1"):
+        os.environ["NAQS_STAGE"] = stage
+        try:
+            e2 = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
+        finally:
+            del os.environ["NAQS_STAGE"]
+        assert np.array_equal(e, e2), (mol, stage)
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 @pytest.mark.parametrize("mol", ["LiH", "H2O", "N2"])
 def test_exact_eigenvector_gives_constant_local_energy(env, mol):

@@ -10,7 +10,7 @@ from naqs_amd.hilbert import Encoding, Hilbert
 from naqs_amd.nade import NadeMasking
 from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
 
-ELECTRONS = {"LiH": (12, 2, 2), "H2O": (14, 5, 5), "N2": (20, 7, 7)}
+ELECTRONS = {"LiH": (12, 2, 2), "H2O": (14, 5, 5), "N2": (20, 7, 7), "CH2": (14, 5, 3)}   # CH2: triplet restricted to m_s = S
 
 
 def make_wf(mol, z, device="cpu", masking=None):

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN, golden
 from naqs_amd import packing
@@ -36,3 +37,28 @@ def test_save_load_roundtrip(tmp_path):
     again = packing.load_packed(p)
     assert again.n_qubits == 14 and (again.n_alpha, again.n_beta) == (5, 5)
     assert np.array_equal(again.xy, ham.xy) and np.array_equal(again.coeff, ham.coeff)
+
+
+REF_MOLECULES = "/root/reference/molecules"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MOLECULES), reason="build container only: needs the reference's molecule folders")
+def test_packing_matches_the_reference_for_every_molecule_folder():
+    """Every molecule folder the reference ships with a qubit-Hamiltonian pickle (32: 4 to 30 qubits, up to 28 393 Pauli
+    strings, closed and open shell) through this repository's own readers (stub unpickler, built-in HDF5 reader) and
+    packing rule, against SHA-256 digests of the reference's own ``__calc_coupling_info`` output
+    (``hamiltonian.py:373-430``; ``tests/golden/make_golden.py packing``): xy | yz | coeff bit for bit, term order included."""
+    import hashlib
+    import json
+    from naqs_amd import system
+    with open(os.path.join(GOLDEN, "packing_sha256.json")) as f:
+        want = json.load(f)
+    assert len(want) >= 32
+    for mol, rec in sorted(want.items()):
+        molecule, qh = system.load_molecule(os.path.join(REF_MOLECULES, mol), verbose=False)
+        n_qubits = packing.n_qubits_of_terms(qh.terms)
+        ham = packing.pack_qubit_hamiltonian(qh.terms, n_qubits, molecule.get_n_alpha_electrons(), molecule.get_n_beta_electrons())
+        got = hashlib.sha256(ham.xy.astype(np.uint64).tobytes() + ham.yz.astype(np.uint64).tobytes()
+                             + ham.coeff.astype(np.float64).tobytes()).hexdigest()
+        assert (n_qubits, ham.K) == (rec["n_qubits"], rec["K"]), mol
+        assert got == rec["sha256"], mol

@@ -15,13 +15,18 @@ from naqs_amd import packing
 from test_nade import ELECTRONS, make_wf
 
 VARIANT_FIXTURES = ["LiH_aggphase", "LiH_noampsym", "LiH_fullmask", "N2_aggphase", "N2_noampsym", "N2_nomask",
-                    "N2_0.75_fullmask", "N2_2.25_fullmask"]
+                    "N2_0.75_fullmask", "N2_2.25_fullmask",
+                    # open shell restricted to m_s = S (experiments/_base.py:101-123): CH2 triplet, 5 alpha / 3 beta electrons
+                    "CH2_noampsym", "CH2_fullmask_noampsym"]
+TAGS = ["fullmask_noampsym", "aggphase", "noampsym", "nomask", "fullmask"]
 ADAM = [{'lr': 1e-3, 'betas': (0.9, 0.99), 'weight_decay': 0, 'eps': 1e-15, 'amsgrad': False}, {'lr': 1e-2}]
 
 
 def split(fix):
-    mol, tag = fix.rsplit("_", 1)
-    return mol, tag
+    for tag in TAGS:
+        if fix.endswith("_" + tag):
+            return fix[:-len(tag) - 1], tag
+    raise ValueError(fix)
 
 
 @pytest.mark.parametrize("fix", VARIANT_FIXTURES)
@@ -29,7 +34,7 @@ def test_variant_log_psi_matches_reference(fix):
     mol, tag = split(fix)
     z = golden(f"nade_{fix}.npz")
     hil, wf = make_wf(mol, z)
-    assert wf.model.aggregate_phase == (tag == "aggphase") and wf.model.use_amp_spin_sym == (tag != "noampsym")
+    assert wf.model.aggregate_phase == (tag == "aggphase") and wf.model.use_amp_spin_sym == ("noampsym" not in tag)
     assert len(wf.model.phase_layers) == (wf.model.P if tag == "aggphase" else 1)
     s = torch.tensor(z["eval_states"])
     with torch.no_grad():
@@ -38,7 +43,7 @@ def test_variant_log_psi_matches_reference(fix):
     ref = z["eval_cond"]
     finite = np.isfinite(ref)
     assert np.array_equal(np.isfinite(cond), finite)
-    if tag == "fullmask":
+    if "fullmask" in tag:
         assert (~finite).any()
     if tag == "nomask":
         assert finite.all()
@@ -51,7 +56,8 @@ def test_variant_log_psi_matches_reference(fix):
     assert np.max(np.abs(lps - z["samp_log_psi"])) < 5e-5
 
 
-@pytest.mark.parametrize("fix", ["LiH_aggphase", "LiH_noampsym", "LiH_fullmask", "N2_aggphase", "N2_noampsym"])
+@pytest.mark.parametrize("fix", ["LiH_aggphase", "LiH_noampsym", "LiH_fullmask", "N2_aggphase", "N2_noampsym",
+                                 "CH2_noampsym", "CH2_fullmask_noampsym"])
 def test_variant_sgd_step_matches_reference_step(fix, tmp_path, monkeypatch):
     """energy, variance, loss, every gradient and every parameter after the reference's own _SGD_step."""
     import oracle_backend

@@ -22,13 +22,16 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 FUSED = ["LiH_noampsym", "LiH_fullmask", "N2_noampsym", "N2_nomask", "N2_0.75_fullmask", "N2_2.25_fullmask",
-         "LiH_aggphase", "N2_aggphase"]
+         "LiH_aggphase", "N2_aggphase",
+         # open shell restricted to m_s = S (experiments/_base.py:101-123): CH2 triplet, 5 alpha / 3 beta electrons, no amp symmetry
+         "CH2_noampsym", "CH2_fullmask_noampsym"]
 EAGER = []
 
 
 def _wf(fix):
     from test_nade import make_wf
-    mol = fix.rsplit("_", 1)[0]
+    from test_variants import split
+    mol = split(fix)[0]
     z = golden(f"nade_{fix}.npz")
     hil, wf = make_wf(mol, z, device="cuda")
     return mol, z, hil, wf
@@ -39,7 +42,7 @@ def _opt(mol, wf, tmp, **kw):
     from naqs_amd.optimizer import PartialSamplingOptimizer
     from test_optimizer import ADAM
     ham = packing.load_packed(os.path.join(GOLDEN, f"ham_{mol}.npz"))
-    na = nb = int(ham.n_alpha)
+    na, nb = int(ham.n_alpha), int(ham.n_beta)
     args = dict(n_samples=100000, n_samples_max=1e12, n_unq_samples_min=10, n_unq_samples_max=1e5, log_exact_energy=False,
                 wavefunction=wf, qubit_hamiltonian=ham, pre_compute_H=False, n_electrons=na + nb, n_alpha_electrons=na,
                 n_beta_electrons=nb, normalise_psi=True, grad_clip_factor=None, optimizer=torch.optim.Adam,
@@ -169,6 +172,67 @@ def test_eloc_on_sweep_geometries(mol):
     e, sums = ham.local_energy(keys, psi, kind="psi", weights=torch.as_tensor(w, device=ham.device))
     energy = (sums[0] / sums[3]).item()
     assert abs(energy - (w * ref.real).sum() / w.sum()) < 1e-9
+
+
+def test_open_shell_eloc_matches_reference_golden():
+    """CH2 (triplet: 5 alpha / 3 beta electrons): the reference's calculate_local_energy on 400 of the sector's 735 states."""
+    from naqs_amd import hamiltonian, packing
+    z = golden("eloc_CH2.npz")
+    ham_p = packing.load_packed(os.path.join(GOLDEN, "ham_CH2.npz"))
+    assert (ham_p.n_alpha, ham_p.n_beta) == (5, 3)
+    ham = hamiltonian.DevicePauliHamiltonian(ham_p, device="cuda:0")
+    keys = hamiltonian.keys_to_device(z["c1_keys"], ham.device)
+    e = ham.local_energy(keys, torch.as_tensor(z["c1_psi_f32"], device=ham.device), kind="psi").cpu().numpy()
+    e = e[:, 0] + 1j * e[:, 1]
+    ref = z["c1_eloc_c128"]
+    assert np.max(np.abs(e - ref) / np.maximum(1, np.abs(ref))) < 1e-10
+
+
+@pytest.mark.parametrize("fix", ["CH2_noampsym", "CH2_fullmask_noampsym"])
+def test_open_shell_sampler_matches_psi_squared(fix):
+    """The tree sampler with n_alpha != n_beta electron budgets (PARTIAL and FULL masking): only states of the (5, 3)
+    sector come out, in ascending key order, and their counts follow the exact |psi|^2 of the same network."""
+    mol, z, hil, wf = _wf(fix)
+    assert (hil.N_alpha, hil.N_beta) == (5, 3) and hil.size == 735
+    fused = wf.fused()
+    n = 2_000_000
+    keys, counts, probs = fused.sample(n, seed=31, max_unique=100000)
+    k, c = keys.cpu().numpy(), counts.cpu().numpy()
+    assert np.all(np.diff(k) > 0) and hil.is_physical(k).all()
+    all_keys = np.sort(hil._all_keys())
+    with torch.no_grad():
+        lp = wf.log_psi(hil.idx2state(torch.as_tensor(all_keys, device="cuda"))).reshape(-1, 2)
+    p = np.exp(2.0 * lp[:, 0].double().cpu().numpy())
+    pos = np.searchsorted(all_keys, k)
+    assert np.allclose(probs.cpu().numpy(), p[pos], rtol=2e-4, atol=1e-12)
+    total, p_phys = c.sum(), p.sum()
+    if "fullmask" in fix:
+        assert total == n and abs(p_phys - 1) < 1e-4                         # FULL masking: every draw is physical
+    else:
+        assert abs(total - n * p_phys) < 6 * np.sqrt(n * p_phys * (1 - p_phys)) + 1
+    obs = np.zeros(len(all_keys))
+    obs[pos] = c
+    expect = p / p_phys * total
+    m = expect >= 5
+    chi2 = ((obs[m] - expect[m]) ** 2 / expect[m]).sum()
+    assert stats.chi2.sf(chi2, m.sum()) > 1e-4, (chi2, m.sum())
+
+
+def test_open_shell_cli_run(tmp_path, capsys):
+    """`python -m experiments.run -m molecules/CH2 -single_phase ...`: the guard is gone — amplitude symmetry is switched
+    off like the reference does (experiments/_base.py:109-114) and the run descends towards the sector's ground state."""
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    from experiments import _base
+    res = _base.run(n_hid=64, n_samps=1e6, n_unq_samps_min=10, n_unq_samps_max=1e5,
+                    argv=["-m", os.path.join(GOLDEN, "ham_CH2.npz"), "-o", str(tmp_path / "run"), "-single_phase", "-n_hid_phase", "64",
+                          "-n_layer_phase", "2", "-n_train", "400", "-output_freq", "200", "-s", "111"])
+    txt = capsys.readouterr().out
+    assert "turning off use_amp_spin_sym" in txt and "fused HIP network kernels not available" not in txt
+    r = res[0]
+    assert r["fci"] is not None and r["final"] > r["fci"] - 1e-3 and r["final"] < r["fci"] + 0.15, r
+    assert r["eig"] >= r["fci"] - 1e-7
 
 
 def test_sampler_without_amp_symmetry_matches_psi_squared():

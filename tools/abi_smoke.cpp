@@ -46,7 +46,10 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(got.data(), d_e, M * 16, hipMemcpyDeviceToHost));
     double err = 0;
     for (int64_t i = 0; i < 2 * M; ++i) err = std::fmax(err, std::fabs(got[i] - want[i]) / std::fmax(1.0, std::fabs(want[i])));
-    std::printf("max rel err vs expected = %.3e\n", err);
+    char kname[128] = {0};
+    NQ(naqs_ham_last_kernel(h, kname, (int)sizeof(kname)));
+    std::printf("max rel err vs expected = %.3e  (%s, ABI %d, sources %s) -> %s\n", err, kname, naqs_abi_version(), naqs_source_hash(),
+                err < 1e-10 ? "OK" : "MISMATCH");
     NQ(naqs_ham_destroy(h));
     return err < 1e-10 ? 0 : 4;
 }
