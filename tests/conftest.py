@@ -31,6 +31,12 @@ def _gpu_unavailable():
 def pytest_collection_modifyitems(config, items):
     """``-m gpu`` tests need a real MI355X: on a host without one a plain
     ``pytest tests`` skips them (with the reason) instead of failing one by one."""
+    # no test may hang a run (the GPU box is charged by the minute and a wedged suite is killed without a report): a
+    # per-test limit through pytest-timeout where it is installed (it is, here and on the GPU box)
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in items:
+            if not it.get_closest_marker("timeout"):
+                it.add_marker(pytest.mark.timeout(300))
     gpu_items = [it for it in items if it.get_closest_marker("gpu")]
     if not gpu_items:
         return

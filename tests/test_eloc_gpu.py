@@ -337,9 +337,12 @@ def test_hamiltonian_shapes_beyond_baseline_vs_oracle(env, mol):
     28 393 strings: the term tables no longer fit the LDS budget -> STAGE 1), C2 (20 qubits), and the open-shell
     triplets CH2 (5 alpha / 3 beta) and O2 (9 / 7) whose sectors have n_alpha != n_beta.  Packing of each is pinned to
     the reference's by tests/test_packing.py; E_loc at M = 2 000 against the pinned oracle."""
+    from math import comb
     h = golden(f"ham_{mol}.npz")
     ham = dev_ham(env, mol)
-    keys = clustered_keys(h, 2000, 21)
+    n_orb = int(h["n_qubits"]) // 2
+    sector = comb(n_orb, int(h["n_alpha"])) * comb(n_orb, int(h["n_beta"]))          # CH2: 735 states, O2: 1 200
+    keys = clustered_keys(h, min(2000, sector * 3 // 4), 21)
     lp = synth_logpsi(len(keys), 12)
     psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
     e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)
