@@ -289,10 +289,13 @@ def dry_run(args, world, rank):
 # ------------------------------------------------------------------------------------------------------------------
 # the row-sharded table (config 4 / north_star's split)
 # ------------------------------------------------------------------------------------------------------------------
-def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup, depth=2, streams=None):
+def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup, depth=2, streams=None, emulate=False):
     """-> dict with ms_per_step, samples/s and the kernel durations of one sharded table of M keys.  `depth` evaluations
     of the table are in flight (one HIP stream and one handle pair each, as in the default mode): the E_loc kernel and the
-    collectives of one overlap the log-psi kernel of the next."""
+    collectives of one overlap the log-psi kernel of the next.
+    emulate (--emulate-world, single process): this process plays rank `rank` of `world` WITHOUT the others — it evaluates
+    log psi for its own padded row shard and E_loc for its own rows against the WHOLE table, which is evaluated once up
+    front outside the timed region and stands in for what the all-gather would deliver; no collective is issued."""
     import torch
     import torch.distributed as dist
     from naqs_amd import hamiltonian, packing
@@ -327,6 +330,7 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup, dept
     acc = torch.zeros((warmup + steps, 4), dtype=torch.float64, device=dev)
     for h_ in hams:
         h_.reserve(M)
+    full_table = nets[0].log_psi(keys_pad).clone() if emulate and world > 1 else None
     torch.cuda.synchronize()
     pending, to_reduce = [], []
 
@@ -338,7 +342,7 @@ def run_row_sharded(dev, world, rank, use_dist, molecule, M, steps, warmup, dept
                 dist.all_gather_into_tensor(table[d], lp_mine[d])             # the exchange step: M x 8 B in all
                 lp_table = table[d]
             else:
-                lp_table = lp_mine[d]
+                lp_table = lp_mine[d] if full_table is None else full_table
             hams[d].local_energy(keys, lp_table[:M], kind="log_psi", row_begin=b, n_rows=e - b, weights=w_mine, out=eloc[d],
                                  sums_out=acc[i])
         # the all-reduce of a step is issued one step late: torch runs a communicator's collectives in issue order on one
@@ -546,6 +550,8 @@ def worker(args):
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.emulate_world:
+        return emulate_main(args, dev)
     if args.shard == "rows":
         return sharded_main(args, dev, world, rank, use_dist)
 
@@ -768,6 +774,52 @@ def sharded_main(args, dev, world, rank, use_dist):
     return 0
 
 
+# what a collective of this size costs on the node is NOT measured here (one GPU): the model carries an explicit, labelled
+# assumption instead — a latency-bound RCCL collective over xGMI (the all-gather moves M x 8 B in all, the all-reduce 32 B)
+ASSUMED_COLLECTIVE_US = {"all_gather_table": 25.0, "all_reduce_accumulators": 20.0}
+
+
+def emulate_main(args, dev):
+    """--emulate-world: rank 0's share of ONE row-sharded table at every requested world size, on one GPU.  The table's
+    strong-scaling ceiling is t(1) / t(W) of these per-rank times (kernels only); with the assumed collective latencies
+    added per step it becomes the curve SCALE_rNN.json can be held against.  Everything here is single-GPU evidence:
+    "unmeasured on hardware" for W > 1."""
+    worlds = sorted({int(w) for w in args.emulate_world.split(",")})
+    rows = []
+    for depth, label in ((1, "one evaluation at a time"), (max(1, args.pipeline), f"{max(1, args.pipeline)} evaluations in flight")):
+        for W in worlds:
+            res, _ = run_row_sharded(dev, W, 0, False, args.molecule, args.samples, args.steps, args.warmup, depth=depth, emulate=True)
+            rows.append({"world": W, "pipeline": depth, "mode": label, "rank0_ms_per_step": res["ms_per_step"],
+                         "rows_per_rank": res["rows_per_rank"], "logpsi_rows_per_rank": res["logpsi_rows_per_rank"],
+                         "eloc_kernel_us": res["eloc_kernel_us"], "logpsi_kernel_us": res["logpsi_kernel_us"],
+                         "eloc_kernel": res["eloc_kernel_name"], "logpsi_kernel": res["logpsi_kernel_name"]})
+    coll = sum(ASSUMED_COLLECTIVE_US.values()) * 1e-3
+    for r in rows:
+        base = next(x for x in rows if x["world"] == worlds[0] and x["pipeline"] == r["pipeline"])
+        r["kernel_only_speedup"] = base["rank0_ms_per_step"] * (worlds[0] / 1.0) / r["rank0_ms_per_step"] if worlds[0] == 1 else None
+        # serial step: the collectives' latency adds to every step; pipelined: it overlaps the next evaluation's kernels
+        # (bench.py issues the all-reduce one step late for exactly that), so the kernel-only time is the model
+        t_model = r["rank0_ms_per_step"] + (coll if (r["world"] > 1 and r["pipeline"] == 1) else 0.0)
+        r["model_ms_per_step"] = t_model
+        r["model_samples_per_s"] = args.samples / (t_model * 1e-3)
+        if worlds[0] == 1:
+            r["model_speedup"] = base["rank0_ms_per_step"] / t_model
+            r["model_efficiency"] = r["model_speedup"] / r["world"]
+    out = {"metric": f"scaling model of one row-sharded table ({args.molecule}, {args.samples} unique samples): rank 0's share per "
+                     f"world size, measured on ONE GPU",
+           "value": rows[-1]["model_samples_per_s"], "unit": "unique samples/s (model, largest world, pipelined)", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": rows[-1]["model_ms_per_step"], "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": dtype_label(), "data": "synthetic",
+           "emulated_worlds": worlds, "unmeasured_on_hardware": True,
+           "assumed_collective_latency_us": ASSUMED_COLLECTIVE_US,
+           "config": {"workload": f"{args.molecule} STO-3G, ONE table of {args.samples} unique samples; rank 0 of W evaluates log psi for "
+                                  f"ceil(M/W) rows and E_loc for its rows against the whole table (stand-in for the all-gather: the "
+                                  f"table evaluated once up front), no collectives issued"},
+           "library_source_hash": library_source_hash(), "per_world": rows}
+    finish(out)
+    return 0
+
+
 def finish(out):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -799,6 +851,10 @@ def parse(argv=None):
                     help="skip the one-batch-at-a-time segment that precedes the timed region (`serial`, `roofline.isolated`)")
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the secondary row-sharded Li2O 50 000 table that follows the timed region (`config4_row_sharded`)")
+    ap.add_argument("--emulate-world", default=None, metavar="W[,W...]",
+                    help="scaling model without the node: on ONE GPU, time rank 0's share of the row-sharded table (log psi for "
+                         "ceil(M/W) rows, E_loc for its rows against the whole table, no collectives) for every W given, e.g. "
+                         "--emulate-world 1,2,4,8 --molecule Li2O --samples 50000; prints the implied strong-scaling ceiling")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="independent batches in flight (HIP streams, one Hamiltonian/network handle pair each); 1 = serial")
     return ap.parse_args(argv)

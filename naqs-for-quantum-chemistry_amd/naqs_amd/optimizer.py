@@ -65,8 +65,12 @@ def _dist():
 
 
 def shard_bounds(n, rank, world):
-    """Contiguous, balanced row shards: rank r gets [n*r//world, n*(r+1)//world)."""
-    return n * rank // world, n * (rank + 1) // world
+    """Contiguous row shards of equal padded size S = ceil(n / world): rank r owns [min(n, r S), min(n, (r + 1) S)).  Equal
+    padded shards are what an all-gather wants — the ranks' (log|psi|, phase) shards, each padded to S rows, land
+    back to back as the table of all n rows (``bench.py --shard rows`` uses the same split)."""
+    S = -(-n // world) if world > 0 else n
+    b = min(n, rank * S)
+    return b, min(n, b + S)
 
 
 def vmc_loss(log_psi, e_loc, weights, e_mean):
@@ -348,11 +352,20 @@ class OptimizerBase:
                 lp_mine = self.wavefunction.log_psi(states[b:e_]).reshape(-1, 2)
             if world == 1:
                 lp_all = lp_mine
-            elif fused is not None:
-                lp_all = fused.log_psi(keys)
             else:
-                with torch.no_grad():
-                    lp_all = self.wavefunction.log_psi(states).reshape(-1, 2)
+                # the table every rank's E_loc rows look psi_j up in: ONE all-gather of the ranks' own (log|psi|, phase)
+                # shards — no rank evaluates the network on rows it does not own (what `bench.py --shard rows`
+                # measures).  The contribution has a size every rank computes WITHOUT looking at its table (rows for the
+                # largest table the sampler may return, n_unq_samples_max): ranks whose samplers diverged then still meet in
+                # a well-formed collective and the key-checksum proof below reports them, instead of a size mismatch
+                # wedging the communicator.  The bytes are cheap (100 KB per rank at the published settings; latency-bound).
+                S = -(-M // world)
+                S_pad = max(S, -(-int(self.n_unq_samples_max) // world)) if getattr(self, "n_unq_samples_max", None) else S
+                mine = torch.zeros((S_pad, 2), dtype=torch.float32, device=self.device)
+                mine[:e_ - b] = lp_mine.detach()
+                table = torch.empty((S_pad * world, 2), dtype=torch.float32, device=self.device)
+                dist.all_gather_into_tensor(table, mine)
+                lp_all = table.view(world, S_pad, 2)[:, :S].reshape(-1, 2)[:M]
         if sample_weights is None:
             if not self.reweight_samples_by_psi:
                 raise NotImplementedError("Re-weighting by the number of samples is not yet implemented.")

@@ -90,7 +90,8 @@ def test_shard_bounds_tile():
         for world in (1, 2, 3, 8):
             b = [shard_bounds(n, r, world) for r in range(world)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
-            assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+            S = -(-n // world)                      # equal padded shards (what the all-gather of the psi table wants)
+            assert all(e - s == S for s, e in b if e < n) and all(e - s <= S for s, e in b)
 
 
 def _worker(rank, world, port, tmp, out):
