@@ -784,11 +784,16 @@ def emulate_main(args, dev):
     strong-scaling ceiling is t(1) / t(W) of these per-rank times (kernels only); with the assumed collective latencies
     added per step it becomes the curve SCALE_rNN.json can be held against.  Everything here is single-GPU evidence:
     "unmeasured on hardware" for W > 1."""
+    import torch
     worlds = sorted({int(w) for w in args.emulate_world.split(",")})
     rows = []
+    # ONE pair of streams for every world size: the runtime multiplexes HIP streams onto a few hardware queues, and fresh
+    # streams per measurement can land on one queue (then nothing overlaps — seen as W = 2 reading its serial time)
+    shared = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.pipeline))]
     for depth, label in ((1, "one evaluation at a time"), (max(1, args.pipeline), f"{max(1, args.pipeline)} evaluations in flight")):
         for W in worlds:
-            res, _ = run_row_sharded(dev, W, 0, False, args.molecule, args.samples, args.steps, args.warmup, depth=depth, emulate=True)
+            res, _ = run_row_sharded(dev, W, 0, False, args.molecule, args.samples, args.steps, args.warmup, depth=depth, emulate=True,
+                                     streams=shared[:depth] if depth > 1 else None)
             rows.append({"world": W, "pipeline": depth, "mode": label, "rank0_ms_per_step": res["ms_per_step"],
                          "rows_per_rank": res["rows_per_rank"], "logpsi_rows_per_rank": res["logpsi_rows_per_rank"],
                          "eloc_kernel_us": res["eloc_kernel_us"], "logpsi_kernel_us": res["logpsi_kernel_us"],

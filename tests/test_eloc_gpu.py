@@ -314,20 +314,32 @@ def test_li2o_subset_vs_oracle(env):
 
 
 def clustered_keys(h, M, seed):
-    """M physical keys grown from one determinant by the Hamiltonian's own flip masks, so that couplings do hit."""
+    """Up to M physical keys grown from one determinant by the Hamiltonian's own flip masks, so that couplings do hit.
+    (A molecule's point-group symmetry splits a sector into components the Hamiltonian does not connect — CH2's (5, 3)
+    sector of 735 states has components of ~390 — so fewer than M come back when the component is smaller.)"""
     N, na, nb = int(h["n_qubits"]), int(h["n_alpha"]), int(h["n_beta"])
     am = sum(1 << q for q in range(0, N, 2))
     bm = sum(1 << q for q in range(1, N, 2))
     rs = np.random.RandomState(seed)
     base = int(random_physical_keys(N, na, nb, 1, seed)[0])
+    uxy = [int(x) for x in np.unique(h["xy"]) if x]
     keys, frontier = {base}, [base]
-    uxy = np.unique(h["xy"])
-    while len(keys) < M:
-        k = frontier[rs.randint(len(frontier))]
-        j = k ^ int(uxy[rs.randint(len(uxy))])
-        if bin(j & am).count("1") == na and bin(j & bm).count("1") == nb and j not in keys:
-            keys.add(j)
-            frontier.append(j)
+    while frontier and len(keys) < M:
+        k = frontier.pop(rs.randint(len(frontier)))
+        for x in rs.permutation(uxy)[:64]:                      # a random subset of the neighbours keeps the cluster ragged
+            j = k ^ int(x)
+            if len(keys) < M and j not in keys and bin(j & am).count("1") == na and bin(j & bm).count("1") == nb:
+                keys.add(j)
+                frontier.append(j)
+        if len(frontier) == 0 and len(keys) < M:                # walk exhausted its random subsets: full neighbourhoods
+            for k2 in list(keys):
+                for x in uxy:
+                    j = k2 ^ x
+                    if len(keys) < M and j not in keys and bin(j & am).count("1") == na and bin(j & bm).count("1") == nb:
+                        keys.add(j)
+                        frontier.append(j)
+            if len(frontier) == 0:
+                break
     return np.sort(np.array(list(keys), np.uint64))
 
 
@@ -337,12 +349,10 @@ def test_hamiltonian_shapes_beyond_baseline_vs_oracle(env, mol):
     28 393 strings: the term tables no longer fit the LDS budget -> STAGE 1), C2 (20 qubits), and the open-shell
     triplets CH2 (5 alpha / 3 beta) and O2 (9 / 7) whose sectors have n_alpha != n_beta.  Packing of each is pinned to
     the reference's by tests/test_packing.py; E_loc at M = 2 000 against the pinned oracle."""
-    from math import comb
     h = golden(f"ham_{mol}.npz")
     ham = dev_ham(env, mol)
-    n_orb = int(h["n_qubits"]) // 2
-    sector = comb(n_orb, int(h["n_alpha"])) * comb(n_orb, int(h["n_beta"]))          # CH2: 735 states, O2: 1 200
-    keys = clustered_keys(h, min(2000, sector * 3 // 4), 21)
+    keys = clustered_keys(h, 2000, 21)
+    assert len(keys) >= 250, len(keys)
     lp = synth_logpsi(len(keys), 12)
     psi = np.exp(lp[:, 0] + 1j * lp[:, 1])
     e = run_eloc(env, ham, keys, np.stack([psi.real, psi.imag], -1), dtype=torch.float64)

@@ -80,11 +80,15 @@ def build():
 
 
 rows = []
+train_first = int(os.environ.get("NAQS_SCALING_TRAIN_FIRST", "1000"))
+wf, opt = build()
+with contextlib.redirect_stdout(io.StringIO()):
+    opt.run(train_first, output_freq=10 ** 9)          # a network part-way into training: peaked distribution, M ~ 10^3
+for g in opt.optimizer.param_groups:                 # ... then frozen (lr = 0), so that every world size times the SAME workload
+    g["lr"] = 0.0
+real_dist, real_step = O._dist, opt._SGD_step
 for W in (1, 2, 4, 8):
-    wf, opt = build()
     fake = FakeDist(W, lambda: wf.fused(need_phase=True)) if W > 1 else None
-    real_dist = O._dist
-    real_step = opt._SGD_step
     if fake is not None:
         O._dist = lambda: fake
 
@@ -99,11 +103,10 @@ for W in (1, 2, 4, 8):
         with contextlib.redirect_stdout(io.StringIO()):
             opt.run(steps, output_freq=10 ** 9)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-        n_unq = opt.log[O.LogKey.N_UNIQUE_SAMP][-1][1]
+        n_unq = float(np.mean([x[1] for x in opt.log[O.LogKey.N_UNIQUE_SAMP][-steps:]]))
         # the stand-in's table evaluation (inference kernel on all M rows + the copies), timed alone on the same table size
         t_tab = 0.0
         if fake is not None:
-            fused = wf.fused(need_phase=True)
             keys = fake.keys
             mine = torch.zeros((-(-len(keys) // W), 2), dtype=torch.float32, device=dev)
             out = torch.empty((mine.shape[0] * W, 2), dtype=torch.float32, device=dev)
@@ -114,10 +117,11 @@ for W in (1, 2, 4, 8):
                 fake.all_gather_into_tensor(out, mine)
             torch.cuda.synchronize(); t_tab = (time.perf_counter() - t1) / 200
     finally:
-        O._dist = real_dist
+        O._dist, opt._SGD_step = real_dist, real_step
     rows.append({"world": W, "wall_ms_per_step_incl_standin": dt * 1e3, "standin_table_ms": t_tab * 1e3,
-                 "rank0_ms_per_step": (dt - t_tab) * 1e3, "unique_samples_last_step": int(n_unq),
-                 "E_loc_last": float(opt.log[O.LogKey.E_LOC][-1][1])})
+                 "rank0_ms_per_step": (dt - t_tab) * 1e3, "mean_unique_samples": n_unq,
+                 "path": "single-process step (forward + E_loc in one library call)" if W == 1 else
+                         "sharded step (forward of my rows, all-gather, E_loc of my rows, two all-reduces)"})
     print(rows[-1], flush=True)
 base = rows[0]["rank0_ms_per_step"]
 coll = sum(ASSUMED_US.values()) * 1e-3
