@@ -293,6 +293,18 @@ int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev
  * activations for naqs_net_train_backward): the single-GPU training step's forward half, three launches. */
 int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev, const double *w_dev,
                                 float *logpsi_dev, double *eloc_dev, double *out4_dev, void *stream);
+
+/* One VMC step's first half in ONE call: naqs_net_sample_weighted, then — after the only host synchronisation of the step,
+ * inside the library (the host has to learn M to size the launches) — naqs_net_train_forward_eloc of the sampled table.
+ * Replaces wavefunction.sample + hilbert.state2idx + calculate_local_energy of PartialSamplingOptimizer.run
+ * (src/optimizer/energy.py:975-998) as a sequence.  All `*_dev` outputs hold max_unique rows; rows >= M are unspecified.
+ * info_host[0] = M, info_host[1] = overflow flag (then nothing was evaluated: MaxBatchSizeExceededError).  Between the
+ * sampler's last kernel and the forward kernel the GPU waits for one stream synchronisation instead of for a return to
+ * the caller's interpreter and a second library call. */
+int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique,
+                                 uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
+                                 float *logpsi_dev, double *eloc_dev, double *out4_dev, int64_t *info_dev,
+                                 int64_t info_host[2], void *stream);
 /* One Adam step on a flat float32 parameter vector (device pointers): torch.optim.Adam's rule without amsgrad —
  * the reference's optimiser, experiments/_base.py:228 (betas (0.9, 0.99), eps 1e-15).  `step` is the 1-based count
  * after this update (bias corrections 1 - beta^step are formed on the host in float64). */

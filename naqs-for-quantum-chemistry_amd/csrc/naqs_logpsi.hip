@@ -1023,17 +1023,20 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_h(const NetDims d, co
     }
 }
 
-// the weight maxima the f16x2 scales are derived from: per phase layer max |W|, max_j sum_k |W[j][k]|, max |b|
-// (atomicMax on the bit patterns of non-negative floats; the buffer was zeroed by the previous pack_net_kernel)
+// the weight maxima the f16x2 scales are derived from: per phase layer max |W|, max_j sum_k |W[j][k]|, max |b| — one wave per
+// row (a 512 x 512 layer: 512 waves, one load round trip each), per-workgroup partials stored plainly
 struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
-__global__ __launch_bounds__(256) void net_bounds_kernel(const float *__restrict__ flat, const PhasePackJobs jobs,
-                                                         naqs::PhaseRaw *__restrict__ raw) {
+constexpr int BOUNDS_WAVES = 8;
+__global__ __launch_bounds__(BOUNDS_WAVES * 64) void net_bounds_kernel(const float *__restrict__ flat, const PhasePackJobs jobs,
+                                                                       naqs::PhaseRaw *__restrict__ raw) {
+    __shared__ float s_red[3][BOUNDS_WAVES];
     const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = jobs.K[l], N = jobs.N[l];
     const float *W = flat + jobs.src_off[l], *b = W + (size_t)N * K;
     float mw = 0.0f, mr = 0.0f, mb = 0.0f;
-    for (int j = blockIdx.x * 4 + wave; j < N; j += gridDim.x * 4) {            // a wave per row
+    for (int j = blockIdx.x * BOUNDS_WAVES + wave; j < N; j += gridDim.x * BOUNDS_WAVES) {
         float sum = 0.0f;
+#pragma unroll 8
         for (int k = lane; k < K; k += 64) { const float v = fabsf(W[(size_t)j * K + k]); sum += v; mw = fmaxf(mw, v); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -1042,22 +1045,31 @@ __global__ __launch_bounds__(256) void net_bounds_kernel(const float *__restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
-    if (lane == 0) {
-        atomicMax(&raw->max_w[l], __float_as_uint(mw));
-        atomicMax(&raw->max_rowsum[l], __float_as_uint(mr));
-        atomicMax(&raw->max_b[l], __float_as_uint(mb));
+    if (lane == 0) { s_red[0][wave] = mw; s_red[1][wave] = mr; s_red[2][wave] = mb; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float m = 0.0f;
+        for (int w = 0; w < BOUNDS_WAVES; ++w) m = fmaxf(m, s_red[threadIdx.x][w]);
+        float *dst = threadIdx.x == 0 ? raw->max_w[l] : (threadIdx.x == 1 ? raw->max_rowsum[l] : raw->max_b[l]);
+        dst[blockIdx.x] = m;
     }
+}
+
+__device__ __forceinline__ float bounds_max(const float (&part)[naqs::BOUNDS_WG]) {
+    float m = 0.0f;
+    for (int i = 0; i < naqs::BOUNDS_WG; ++i) m = fmaxf(m, part[i]);     // uniform addresses: scalar loads
+    return m;
 }
 
 // weight scale of layer l: max |W| sw in [2^13, 2^14)
 __device__ __forceinline__ float phase_weight_scale(const naqs::PhaseRaw &raw, int l) {
-    return pow2_clamped(13 - exp_of(__uint_as_float(raw.max_w[l])));
+    return pow2_clamped(13 - exp_of(bounds_max(raw.max_w[l])));
 }
 // all scales of the network (one thread): activation bound chain |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
 __device__ __forceinline__ void phase_scales_fill(const naqs::PhaseRaw &raw, int n_lin, naqs::PhaseScales *out) {
     float bound = 1.0f, s_in = 1.0f;
     for (int l = 0; l < n_lin; ++l) {
-        bound = __uint_as_float(raw.max_rowsum[l]) * bound + __uint_as_float(raw.max_b[l]);
+        bound = bounds_max(raw.max_rowsum[l]) * bound + bounds_max(raw.max_b[l]);
         const float sw = phase_weight_scale(raw, l);
         const float sn = l + 1 < n_lin ? pow2_clamped(14 - exp_of(bound)) : 1.0f;          // bound sn < 2^15
         out->sw[l] = sw;
@@ -1229,13 +1241,13 @@ __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, 
 // naqs_net_set_weights of the single-phase network in ONE launch (it runs once per training step, and every launch of a
 // few thousand elements costs its 4-5 us): blockIdx.y walks the amplitude rows (P jobs), the amplitude fragments (P), the
 // phase layers (n_lin) and the row-major copies the backward GEMMs read (naqs::WbPackJobs, from naqs_phase_grad.hip).
-// fmt 2: raw holds the weight maxima of net_bounds_kernel (launched just before); the first phase job also writes the
-// scales the phase kernel reads and zeroes the maxima buffer of the NEXT call (raw_next).
+// fmt 2: raw holds the partial weight maxima of net_bounds_kernel (launched just before); the first phase job also writes
+// the scales the phase kernel reads.
 __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
                                                        const PhasePackJobs jobs, const naqs::WbPackJobs wb, float *__restrict__ w,
                                                        ushort_t *__restrict__ wh, ushort_t *__restrict__ wamp, const int with_f32,
                                                        const int fmt, const naqs::PhaseRaw *__restrict__ raw,
-                                                       naqs::PhaseRaw *__restrict__ raw_next, naqs::PhaseScales *__restrict__ scales) {
+                                                       naqs::PhaseScales *__restrict__ scales) {
     int y = blockIdx.y;
     if (y < d.P) { pack_amp_body(flat, d, so, w, y); return; }
     y -= d.P;
@@ -1246,7 +1258,6 @@ __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__
     if (y < d.n_lin) {
         if (fmt == 2 && y == 0 && blockIdx.x == 0) {
             if (threadIdx.x == 0) phase_scales_fill(*raw, d.n_lin, scales);
-            if (threadIdx.x < 3 * MAXL) reinterpret_cast<unsigned int *>(raw_next)[threadIdx.x] = 0u;
         }
         pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw);
         return;
@@ -1411,9 +1422,9 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
 #undef NAQS_PH_ATTR
             (void)hipGetLastError();            // a refused attribute must not stay behind as the runtime's "last error"
         }
-        if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, 2 * sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMalloc((void **)&net->d_scales, sizeof(naqs::PhaseScales)) != hipSuccess) st = NAQS_ERR_NOMEM;
-        if (st == NAQS_OK && hipMemset(net->d_raw, 0, 2 * sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_HIP;
+        if (st == NAQS_OK && hipMemset(net->d_raw, 0, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_HIP;
     }
     if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
     *out = net;
@@ -1541,16 +1552,14 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
         const int gx = std::min(256, (biggest + 255) / 256);
         const int gy = d.P + (net->d_wamp ? d.P : 0) + d.n_lin + wb.n;
         net->wamp_fresh = false;
-        naqs::PhaseRaw *raw = net->d_raw + (net->pack_seq & 1u), *raw_next = net->d_raw + ((net->pack_seq + 1u) & 1u);
+        naqs::PhaseRaw *raw = net->d_raw;
         if (fmt == 2) {
-            // weight maxima -> scales (device side; no host round trip).  The buffer of this parity was zeroed at creation
-            // or by the pack kernel of the previous f16x2 call on this handle's stream.
-            hipLaunchKernelGGL(net_bounds_kernel, dim3(32, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw);
+            // weight maxima -> scales (device side; no host round trip)
+            hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(BOUNDS_WAVES * 64), 0, s, flat_dev, jobs, raw);
             HIP_TRY(hipGetLastError());
-            net->pack_seq++;
         }
         hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
-                           with_f32, fmt, raw, raw_next, net->d_scales);
+                           with_f32, fmt, raw, net->d_scales);
         HIP_TRY(hipGetLastError());
         net->wamp_fresh = net->d_wamp != nullptr;
         net->have_wb = true;

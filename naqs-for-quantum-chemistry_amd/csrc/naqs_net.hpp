@@ -42,7 +42,10 @@ struct NetDims {
 // c = sn / (s_in sw) takes an accumulator to the scaled output, isn = 1 / sn.  Written by pack_net_kernel from the
 // weight-derived bounds of net_bounds_kernel (|h_l| <= rowsum_l * bound_{l-1} + max|b_l| < 2^15 / sn: no overflow).
 struct PhaseScales { float sw[MAXL], c[MAXL], sn[MAXL], isn[MAXL]; };
-struct PhaseRaw { unsigned int max_w[MAXL], max_rowsum[MAXL], max_b[MAXL]; };    // float bits of non-negative maxima (atomicMax)
+// per-workgroup partial maxima of net_bounds_kernel: plain stores, every consumer reduces the BOUNDS_WG entries itself (no
+// atomics — ~10^3 atomic maxima on nine addresses were 13 of the kernel's 14 us — and nothing to zero between calls)
+constexpr int BOUNDS_WG = 64;
+struct PhaseRaw { float max_w[MAXL][BOUNDS_WG], max_rowsum[MAXL][BOUNDS_WG], max_b[MAXL][BOUNDS_WG]; };
 
 // one packed row [W1[j][0..NIN) | b1[j] | W2[0..5)[j] | pad] from LDS as 16-byte reads (rows are 16-byte multiples);
 // element-wise `row[k]` reads compile to one ds_read_b32 each and those, not the FMAs, were the time of this loop
@@ -180,9 +183,8 @@ struct naqs_net {
     bool have_weights = false;              // amplitude AND phase layers packed from the current parameters
     bool packed_f32 = false;                // the f32-MFMA weight tiles are current (only packed when phase_kernel will run)
     int packed_fmt = 0;                     // split format of d_wh: 1 = three bf16 planes, 2 = two scaled f16 planes
-    naqs::PhaseRaw *d_raw = nullptr;        // [2] weight maxima of the phase layers (parity = set_weights calls & 1)
+    naqs::PhaseRaw *d_raw = nullptr;        // partial weight maxima of the phase layers (net_bounds_kernel -> pack_net_kernel)
     naqs::PhaseScales *d_scales = nullptr;  // the f16x2 scales of the current weights
-    uint32_t pack_seq = 0;
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)

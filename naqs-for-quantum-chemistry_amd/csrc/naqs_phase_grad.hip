@@ -350,6 +350,24 @@ NAQS_API int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64
     return naqs::eloc_main(ham, M, feed, eloc_dev, w_dev, out4_dev, s);
 }
 
+NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique,
+                                          uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
+                                          float *logpsi_dev, double *eloc_dev, double *out4_dev, int64_t *info_dev,
+                                          int64_t info_host[2], void *stream) {
+    if (!net || !ham || !weights_dev || !logpsi_dev || !eloc_dev || !out4_dev || !info_dev || !info_host) return NAQS_ERR_INVALID;
+    if (!net->have_weights) return NAQS_ERR_INVALID;              // the forward needs the phase layers packed too
+    int st = naqs_net_sample_weighted(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, info_dev, stream);
+    if (st != NAQS_OK) return st;
+    DeviceGuard guard;
+    st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(info_host, info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));                              // the step's one host synchronisation: M
+    if (info_host[1] != 0 || info_host[0] <= 0) return NAQS_OK;
+    return naqs_net_train_forward_eloc(net, ham, info_host[0], keys_dev, weights_dev, logpsi_dev, eloc_dev, out4_dev, stream);
+}
+
 NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
                                      float *grad_dev, void *stream) {
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;

@@ -329,6 +329,36 @@ class FusedLogPsi:
             out = tuple(t.clone() for t in out)
         return out
 
+    @torch.no_grad()
+    def sample_forward_local_energy(self, ham, n_samples, seed, max_unique):
+        """``sample(with_weights=True)`` and ``forward_saved_with_local_energy`` of the sampled table in ONE library call
+        (``naqs_vmc_sample_forward_eloc``): the host synchronisation that learns M happens inside the library, directly
+        followed by the forward / E_loc launches, instead of a return to the interpreter in between (the GPU idles for
+        that long).  -> (keys, counts, probs, weights, (log psi, saved token, E_loc, sums))."""
+        from .nade import MaxBatchSizeExceededError
+        cap = int(max_unique)
+        dev = self.device
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        counts = torch.empty(cap, dtype=torch.int64, device=dev)
+        probs = torch.empty(cap, dtype=torch.float32, device=dev)
+        weights = torch.empty(cap, dtype=torch.float64, device=dev)
+        log_psi = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        eloc = torch.empty((cap, 2), dtype=torch.float64, device=dev)
+        sums = torch.empty(4, dtype=torch.float64, device=dev)
+        if self._samp is None:
+            self._samp = torch.empty(2, dtype=torch.int64, device=dev)
+        info_host = (ctypes.c_int64 * 2)(0, 0)
+        st = self._lib.naqs_vmc_sample_forward_eloc(self._h, ham._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, keys.data_ptr(),
+                                                    counts.data_ptr(), probs.data_ptr(), weights.data_ptr(), log_psi.data_ptr(),
+                                                    eloc.data_ptr(), sums.data_ptr(), self._samp.data_ptr(), info_host,
+                                                    _stream_ptr(dev))
+        _lib.check(st, "naqs_vmc_sample_forward_eloc")
+        m, overflow = int(info_host[0]), int(info_host[1])
+        if overflow:
+            raise MaxBatchSizeExceededError
+        k = keys[:m]
+        return k, counts[:m], probs[:m], weights[:m], (log_psi[:m], (k, None, None), eloc[:m], sums)
+
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")
         _lib.check(self._lib.naqs_net_prof_stride(self._h, int(stride)), "naqs_net_prof_stride")

@@ -340,8 +340,14 @@ class OptimizerBase:
             if (fused is not None and regularisation_loss is None and not self.normalize_grads and world == 1
                     and fused.train_mode == "hip" and sample_weights is not None and not quirk
                     and os.environ.get("NAQS_TRAIN_FUSED_ELOC", "1") == "1"):
-                # single GPU: forward (activations kept) + E_loc + weighted sums in one library call
-                pre = fused.forward_saved_with_local_energy(self.pauli_hamiltonian, keys, sample_weights.reshape(-1))
+                # single GPU: forward (activations kept) + E_loc + weighted sums in one library call — or already done by
+                # the sampler's call for exactly these keys and weights (get_samples, training loop)
+                pf = getattr(self, "_prefused", None)
+                self._prefused = None
+                if pf is not None and pf[0] is states_idx and sample_weights is self._sample_weights:
+                    pre = pf[1]
+                else:
+                    pre = fused.forward_saved_with_local_energy(self.pauli_hamiltonian, keys, sample_weights.reshape(-1))
                 lp_mine, saved = pre[0], pre[1]
             elif fused is not None and regularisation_loss is None and not self.normalize_grads:
                 # HIP amplitude forward/backward + explicit chain rule of the phase MLP: no autograd graph at all
@@ -424,6 +430,10 @@ class OptimizerBase:
         self._clip_grads()
         self.optimizer.step()
         self.wavefunction.parameters_changed()
+        if self.use_fused and saved is not None:
+            # re-pack the kernels' weight layouts NOW, behind the optimiser launch, instead of at the start of the next
+            # sampling call: the host gets there tens of microseconds later and the GPU would wait for it
+            self.wavefunction.fused(need_phase=True)
         self.optimizer.zero_grad()
         if self.scheduler is not None:
             self.scheduler.step()
@@ -523,6 +533,16 @@ class PartialSamplingOptimizer(OptimizerBase):
         if n_epochs:
             raise NotImplementedError("pre_flatten with n_epochs > 0 (unused: n_pretrain=0, experiments/run.py:14)")
 
+    def _can_prefuse(self):
+        """The conditions under which _SGD_step takes its single-GPU fused branch (forward + E_loc in one call) — known
+        before sampling, so that the sampler's call can include them."""
+        if not self.use_fused or _dist() is not None or self.normalize_grads or self.bug_compat_full_sample_order:
+            return False
+        if os.environ.get("NAQS_TRAIN_FUSED_ELOC", "1") != "1" or os.environ.get("NAQS_TRAIN_PREFUSE", "1") != "1":
+            return False
+        fused = self.wavefunction.fused(need_phase=True)
+        return fused is not None and fused.train_mode == "hip"
+
     def get_samples(self, last_action=0, lazy=False):
         """Adaptive sample count (energy.py:936-971): x10 while too few unique samples, /10 when too many
         or when the unique-prefix tree exceeds ``n_unq_samples_max``.  -> (states, counts, probs); the keys and the
@@ -533,10 +553,18 @@ class PartialSamplingOptimizer(OptimizerBase):
             # one full re-pack of the parameters now (sampler, forward and backward all read it) instead of an
             # amplitude-only one here and a full one before the forward pass
             self.wavefunction.fused(need_phase=True)
+        self._prefused = None
         try:
-            states, counts, probs, self._sample_keys, self._sample_weights = self.wavefunction.sample(
-                self.n_samples, ret_log_psi=False, max_batch_size=self.n_unq_samples_max, generator=self.generator,
-                ret_keys=True, lazy_states=lazy, ret_weights=True)
+            if lazy and self._can_prefuse():
+                # training loop, single GPU, HIP forward/backward: sampling, forward and E_loc in one library call — what
+                # _SGD_step would compute first for these keys is already on its way when the host learns M
+                states, counts, probs, self._sample_keys, self._sample_weights, pre = self.wavefunction.sample_with_local_energy(
+                    self.pauli_hamiltonian, self.n_samples, self.n_unq_samples_max, generator=self.generator)
+                self._prefused = (self._sample_keys, pre)
+            else:
+                states, counts, probs, self._sample_keys, self._sample_weights = self.wavefunction.sample(
+                    self.n_samples, ret_log_psi=False, max_batch_size=self.n_unq_samples_max, generator=self.generator,
+                    ret_keys=True, lazy_states=lazy, ret_weights=True)
             n_unq, completed = len(states), True
         except MaxBatchSizeExceededError:
             print("MaxBatchSizeExceededError")

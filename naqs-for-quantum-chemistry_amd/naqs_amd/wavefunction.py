@@ -256,6 +256,25 @@ class NAQSComplex_NADE_orbitals:
         version counters (the multi-tensor fused optimisers write through raw pointers)."""
         self._param_epoch += 1
 
+    def _next_sample_seed(self, generator=None):
+        """One 64-bit seed per sampling call: splitmix64 of the generator's seed and a call counter."""
+        base = int(generator.initial_seed()) if generator is not None else int(torch.initial_seed())
+        self._sample_calls += 1
+        x = (base + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return x ^ (x >> 31)
+
+    def sample_with_local_energy(self, ham, num_samples, max_batch_size, generator=None):
+        """The training loop's ``sample(..., ret_keys, lazy_states, ret_weights)`` followed by the forward pass (activations
+        kept for the backward) and the local energies of the sampled table, as ONE library call on the fused HIP path
+        (``FusedLogPsi.sample_forward_local_energy``).  -> (states, counts, probs, keys, weights, pre) with ``pre`` what
+        ``forward_saved_with_local_energy`` would have returned for these keys."""
+        fused = self.fused(need_phase=True)
+        seed = self._next_sample_seed(generator)
+        keys, counts, probs, weights, pre = fused.sample_forward_local_energy(ham, int(num_samples), seed, int(max_batch_size))
+        return LazyStates(self.hilbert, keys), counts, probs, keys, weights, pre
+
     def sample(self, num_samples=1, ret_probs=True, ret_log_psi=True, ret_norm_reg=False, eval_mode=False,
                max_batch_size=None, generator=None, use_fused=None, ret_keys=False, lazy_states=False, ret_weights=False):
         """wavefunction.py:488-521.  On a HIP device the draw is ``naqs_net_sample`` (one library call for the
@@ -273,12 +292,7 @@ class NAQSComplex_NADE_orbitals:
         if fused is not None:
             # one 64-bit seed per call, derived on the host (splitmix64 of the generator's seed and a call counter):
             # drawing it from a device generator would cost a queue-draining read-back before the sampler is queued
-            base = int(generator.initial_seed()) if generator is not None else int(torch.initial_seed())
-            self._sample_calls += 1
-            x = (base + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF
-            x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-            x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-            seed = x ^ (x >> 31)
+            seed = self._next_sample_seed(generator)
             if max_batch_size is not None:
                 cap = int(max_batch_size)
             else:       # live prefixes are bounded by the physical space unless no conditional is masked
