@@ -1445,6 +1445,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_gpart) (void)hipFree(net->d_gpart);
     if (net->d_train) (void)hipFree(net->d_train);
     if (net->d_wb) (void)hipFree(net->d_wb);
+    if (net->h_info) (void)hipHostFree(net->h_info);
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_scales) (void)hipFree(net->d_scales);
     delete net;

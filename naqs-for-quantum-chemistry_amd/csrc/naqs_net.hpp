@@ -194,6 +194,7 @@ struct naqs_net {
     bool grad_attr_set = false;
     naqs::EventRing prof;
     char last_kernel[96] = {0};             // naqs_net_last_kernel
+    int64_t *h_info = nullptr;              // pinned host words for the sampler's (M, overflow) read-back
 };
 
 namespace naqs {

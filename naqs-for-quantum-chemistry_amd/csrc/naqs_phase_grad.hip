@@ -65,14 +65,34 @@ __global__ __launch_bounds__(256) void split_g_kernel(const int64_t M, const flo
     if (i < M) g_amp[i] = g[i].x;
 }
 
-// Cpart[z][n][k] = sum_{i in slice z} P[i][n] Q[i][k];  Bpart[z][n] = sum_{i in slice z} P[i][n]
-__global__ __launch_bounds__(256) void grad_w_kernel(const float *__restrict__ P, const int ldp, const float *__restrict__ Q,
-                                                     const int ldq, const int64_t M, const int64_t rows_per_slice,
-                                                     float *__restrict__ Cpart, const int Np, const int Kp,
-                                                     float *__restrict__ Bpart) {
+// Weight gradients of ALL phase layers in one launch (they only need the deltas, which the grad_in chain has produced by
+// then): job l:  Cpart_l[z][n][k] = sum_{i in slice z} P_l[i][n] Q_l[i][k];  Bpart_l[z][n] = sum_{i in slice z} P_l[i][n].
+// (Three launches of 8-64 workgroups each, plus three reduce launches, were 8 + 13 + 9 + 3 x 5 us at M ~ 1 200.)
+struct GradWJobs {
+    int n;
+    const float *P[MAXL], *Q[MAXL];
+    int ldp[MAXL], ldq[MAXL], Np[MAXL], Kp[MAXL], N[MAXL], K[MAXL], slices[MAXL];
+    int64_t rows_per_slice[MAXL];
+    int block_end[MAXL];            // running total of (Np / TB) (Kp / TB) slices
+    int64_t cpart_off[MAXL], bpart_off[MAXL];
+    int64_t out_off[MAXL];          // dW_l in the flat gradient (db_l follows it)
+    int64_t elem_end[MAXL];         // running total of N K + N (reduce kernel)
+};
+
+__global__ __launch_bounds__(256) void grad_w_kernel(const GradWJobs J, const int64_t M, float *__restrict__ cpart_base,
+                                                     float *__restrict__ bpart_base) {
     __shared__ __attribute__((aligned(16))) float Ps[CH * LDT];
     __shared__ __attribute__((aligned(16))) float Qs[CH * LDT];
-    const int n0 = blockIdx.x * TB, k0 = blockIdx.y * TB, z = blockIdx.z;
+    int job = 0, bid = blockIdx.x;
+    while (job + 1 < J.n && bid >= J.block_end[job]) ++job;
+    if (job > 0) bid -= J.block_end[job - 1];
+    const int Np = J.Np[job], Kp = J.Kp[job], nbn = Np / TB, nbk = Kp / TB;
+    const int z = bid / (nbn * nbk), rem = bid - z * (nbn * nbk);
+    const int n0 = (rem / nbk) * TB, k0 = (rem % nbk) * TB;
+    const float *__restrict__ P = J.P[job], *__restrict__ Q = J.Q[job];
+    const int ldp = J.ldp[job], ldq = J.ldq[job];
+    float *__restrict__ Cpart = cpart_base + J.cpart_off[job], *__restrict__ Bpart = bpart_base + J.bpart_off[job];
+    const int64_t rows_per_slice = J.rows_per_slice[job];
     const int64_t i_beg = (int64_t)z * rows_per_slice, i_end = min(M, i_beg + rows_per_slice);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1, lm = lane & 15, lq = lane >> 4;
@@ -82,20 +102,31 @@ __global__ __launch_bounds__(256) void grad_w_kernel(const float *__restrict__ P
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum[2] = {0.f, 0.f};
-    for (int64_t i0 = i_beg; i0 < i_end; i0 += CH) {
+    // the next chunk's operands are fetched into registers while this chunk's MFMAs run (the kernel is a chain of
+    // load -> barrier -> 32 MFMAs -> barrier per chunk: latency, not throughput)
+    f32x4 vp[2], vq[2];
+    auto fetch = [&](int64_t i0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u, r = e >> 4, c4 = e & 15;
             const int64_t i = i0 + r;
-            f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f}, vq = vp;
+            vp[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; vq[u] = vp[u];
             if (i < i_end) {
-                vp = *reinterpret_cast<const f32x4 *>(P + i * ldp + n0 + 4 * c4);
-                vq = *reinterpret_cast<const f32x4 *>(Q + i * ldq + k0 + 4 * c4);
+                vp[u] = *reinterpret_cast<const f32x4 *>(P + i * ldp + n0 + 4 * c4);
+                vq[u] = *reinterpret_cast<const f32x4 *>(Q + i * ldq + k0 + 4 * c4);
             }
-            *reinterpret_cast<f32x4 *>(Ps + r * LDT + 4 * c4) = vp;
-            *reinterpret_cast<f32x4 *>(Qs + r * LDT + 4 * c4) = vq;
+        }
+    };
+    fetch(i_beg);
+    for (int64_t i0 = i_beg; i0 < i_end; i0 += CH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u, r = e >> 4, c4 = e & 15;
+            *reinterpret_cast<f32x4 *>(Ps + r * LDT + 4 * c4) = vp[u];
+            *reinterpret_cast<f32x4 *>(Qs + r * LDT + 4 * c4) = vq[u];
         }
         __syncthreads();
+        if (i0 + CH < i_end) fetch(i0 + CH);
 #pragma unroll
         for (int ks = 0; ks < CH / 4; ++ks) {
             const int kk = ks * 4 + lq;
@@ -120,7 +151,7 @@ __global__ __launch_bounds__(256) void grad_w_kernel(const float *__restrict__ P
                 const int n = n0 + wn * 32 + tn * 16 + 4 * lq + r, k = k0 + wk * 32 + tk * 16 + lm;
                 Cpart[((int64_t)z * Np + n) * Kp + k] = acc[tn][tk][r];
             }
-    if (blockIdx.y == 0 && wk == 0) {
+    if (k0 == 0 && wk == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float v = bsum[t];
@@ -131,22 +162,26 @@ __global__ __launch_bounds__(256) void grad_w_kernel(const float *__restrict__ P
     }
 }
 
-// slices -> dW [N][K] and db [N] (unpadded, state_dict layout)
-__global__ __launch_bounds__(256) void grad_w_reduce_kernel(const float *__restrict__ Cpart, const float *__restrict__ Bpart,
-                                                            const int slices, const int Np, const int Kp, const int N, const int K,
-                                                            float *__restrict__ dW, float *__restrict__ db) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < N * K) {
-        const int n = e / K, k = e - n * K;
-        float s = 0.0f;
+// slices -> dW_l [N][K] and db_l [N] of every layer (unpadded, state_dict layout), fixed order -> deterministic
+__global__ __launch_bounds__(256) void grad_w_reduce_kernel(const GradWJobs J, const float *__restrict__ cpart_base,
+                                                            const float *__restrict__ bpart_base, float *__restrict__ grad) {
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int job = 0;
+    while (job + 1 < J.n && e >= J.elem_end[job]) ++job;
+    if (e >= J.elem_end[job]) return;
+    if (job > 0) e -= J.elem_end[job - 1];
+    const int N = J.N[job], K = J.K[job], Np = J.Np[job], Kp = J.Kp[job], slices = J.slices[job];
+    const float *Cpart = cpart_base + J.cpart_off[job], *Bpart = bpart_base + J.bpart_off[job];
+    float *dW = grad + J.out_off[job];
+    float s = 0.0f;
+    if (e < (int64_t)N * K) {
+        const int n = (int)(e / K), k = (int)(e - (int64_t)n * K);
         for (int z = 0; z < slices; ++z) s += Cpart[((int64_t)z * Np + n) * Kp + k];
-        dW[e] = s;
-    } else if (e < N * K + N) {
-        const int n = e - N * K;
-        float s = 0.0f;
+    } else {
+        const int n = (int)(e - (int64_t)N * K);
         for (int z = 0; z < slices; ++z) s += Bpart[(int64_t)z * Np + n];
-        db[n] = s;
     }
+    dW[e] = s;                       // db_l follows dW_l in the flat gradient: element N K + n
 }
 
 // Dout[i][k] = [In[i][k] > 0] * sum_n D[i][n] W[n][k]
@@ -164,26 +199,38 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // next chunk's tiles in registers while this chunk's MFMAs run (see grad_w_kernel)
+    f32x4 vd[2], vw[2];
+    auto fetch = [&](int nn0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            const int r = e >> 3, c4 = e & 7;
+            const int64_t i = i0 + r;
+            vd[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i < M) vd[u] = *reinterpret_cast<const f32x4 *>(D + i * Np + nn0 + 4 * c4);
+            const int rw = e >> 4, cw = e & 15;
+            vw[u] = *reinterpret_cast<const f32x4 *>(W + (int64_t)(nn0 + rw) * Kp + k0 + 4 * cw);
+        }
+    };
+    fetch(0);
     for (int nn0 = 0; nn0 < Np; nn0 += CH) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
             {   // delta tile: 64 samples x 32 n
                 const int r = e >> 3, c4 = e & 7;
-                const int64_t i = i0 + r;
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (i < M) v = *reinterpret_cast<const f32x4 *>(D + i * Np + nn0 + 4 * c4);
                 float2 *dst = reinterpret_cast<float2 *>(Ds + r * LDD + 4 * c4);     // LDD even: 8-byte aligned
-                dst[0] = make_float2(v[0], v[1]);
-                dst[1] = make_float2(v[2], v[3]);
+                dst[0] = make_float2(vd[u][0], vd[u][1]);
+                dst[1] = make_float2(vd[u][2], vd[u][3]);
             }
             {   // weight tile: 32 n x 64 k
                 const int r = e >> 4, c4 = e & 15;
-                *reinterpret_cast<f32x4 *>(Ws + r * LDT + 4 * c4) =
-                    *reinterpret_cast<const f32x4 *>(W + (int64_t)(nn0 + r) * Kp + k0 + 4 * c4);
+                *reinterpret_cast<f32x4 *>(Ws + r * LDT + 4 * c4) = vw[u];
             }
         }
         __syncthreads();
+        if (nn0 + CH < Np) fetch(nn0 + CH);
 #pragma unroll
         for (int ks = 0; ks < CH / 4; ++ks) {
             const int kk = ks * 4 + lq;
@@ -209,7 +256,7 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
 }
 
 struct TrainLayout {            // carve-up of net->d_train for `cap` rows
-    size_t x, act[MAXL], delta[2], top, g_amp, cpart, bpart, total;
+    size_t x, act[MAXL], delta[MAXL], top, g_amp, cpart, bpart, total;
     int x_ld, act_ld[MAXL], top_ld, max_ld;
     int64_t cpart_floats;
 };
@@ -229,21 +276,22 @@ TrainLayout train_layout(const naqs_net *net, int64_t cap) {
         L.max_ld = std::max(L.max_ld, L.act_ld[l]);
         L.act[l] = off; off = up256(off + (size_t)cap * L.act_ld[l] * sizeof(float));
     }
-    for (int b = 0; b < 2; ++b) { L.delta[b] = off; off = up256(off + (size_t)cap * L.max_ld * sizeof(float)); }
+    for (int b = 0; b < H; ++b) { L.delta[b] = off; off = up256(off + (size_t)cap * L.max_ld * sizeof(float)); }   // delta of hidden layer b
     L.top_ld = pad64(net->phase_N[(size_t)H]);
     L.top = off; off = up256(off + (size_t)cap * L.top_ld * sizeof(float));
     L.g_amp = off; off = up256(off + (size_t)cap * sizeof(float));
     // GEMM partials: at most ~2 x CU-count workgroups per launch -> slices * blocks <= 512 (+ one slice minimum)
-    int64_t worst = 0;
+    int64_t worst = 0, worst_b = 0;                 // all layers' partials live at once (one launch computes them all)
     for (int l = 0; l <= H; ++l) {
         const int64_t Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
         const int64_t blocks = (Np / TB) * (Kp / TB);
         const int64_t slices = std::max<int64_t>(1, 512 / blocks);
-        worst = std::max(worst, slices * Np * Kp);
+        worst += slices * Np * Kp;
+        worst_b += slices * Np;
     }
     L.cpart_floats = worst;
     L.cpart = off; off = up256(off + (size_t)worst * sizeof(float));
-    L.bpart = off; off = up256(off + (size_t)512 * 64 * sizeof(float) * 8);
+    L.bpart = off; off = up256(off + (size_t)worst_b * sizeof(float));
     L.total = off;
     return L;
 }
@@ -362,8 +410,11 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
     st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(info_host, info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (!net->h_info) HIP_TRY(hipHostMalloc((void **)&net->h_info, 2 * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(net->h_info, info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));   // pinned: a plain async copy
     HIP_TRY(hipStreamSynchronize(s));                              // the step's one host synchronisation: M
+    info_host[0] = net->h_info[0];
+    info_host[1] = net->h_info[1];
     if (info_host[1] != 0 || info_host[0] <= 0) return NAQS_OK;
     return naqs_net_train_forward_eloc(net, ham, info_host[0], keys_dev, weights_dev, logpsi_dev, eloc_dev, out4_dev, stream);
 }
@@ -398,7 +449,6 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     const TrainLayout L = train_layout(net, net->train_cap);
     char *base = static_cast<char *>(net->d_train);
     float *x = reinterpret_cast<float *>(base + L.x);
-    float *delta[2] = {reinterpret_cast<float *>(base + L.delta[0]), reinterpret_cast<float *>(base + L.delta[1])};
     float *top = reinterpret_cast<float *>(base + L.top);
     float *g_amp = reinterpret_cast<float *>(base + L.g_amp);
     float *cpart = reinterpret_cast<float *>(base + L.cpart), *bpart = reinterpret_cast<float *>(base + L.bpart);
@@ -410,36 +460,48 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     st = naqs_net_amp_backward(net, M, keys_dev, g_amp, grad_dev, stream);
     if (st != NAQS_OK) return st;
 
-    // phase block, output layer first
+    // phase block.  First the chain of deltas, output layer down (the critical path: each needs the one above) ...
     const int H = d.n_lin - 1;
     hipLaunchKernelGGL(top_delta_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, g2, top, L.top_ld);
     HIP_TRY(hipGetLastError());
-    const float *dcur = top;
-    int flip = 0;
-    for (int l = H; l >= 0; --l) {
+    const float *dl[MAXL];                            // delta of linear layer l's output
+    dl[H] = top;
+    for (int l = H; l > 0; --l) {
+        const int Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
+        const float *in = reinterpret_cast<const float *>(base + L.act[l - 1]);
+        float *dnext = reinterpret_cast<float *>(base + L.delta[l - 1]);
+        hipLaunchKernelGGL(grad_in_kernel, dim3((unsigned)((M + TB - 1) / TB), Kp / TB), dim3(256), 0, s, dl[l],
+                           net->d_wb + wb_offset(net, l), in, M, Np, Kp, dnext);
+        HIP_TRY(hipGetLastError());
+        dl[l - 1] = dnext;
+    }
+    // ... then every layer's weight gradient in one launch and one fixed-order reduction
+    GradWJobs J{};
+    J.n = H + 1;
+    int blocks_total = 0;
+    int64_t c_off = 0, b_off = 0, elems = 0;
+    for (int l = 0; l <= H; ++l) {
         const int N = net->phase_N[(size_t)l], K = net->phase_K[(size_t)l], Np = pad64(N), Kp = pad64(K);
-        const float *in = l == 0 ? x : reinterpret_cast<const float *>(base + L.act[l - 1]);
-        const int ld_in = l == 0 ? L.x_ld : L.act_ld[l - 1];          // == Kp
         const int blocks = (Np / TB) * (Kp / TB);
         int slices = (int)std::min<int64_t>(std::max(1, 512 / blocks), (M + 127) / 128);
         slices = std::max(1, slices);
         const int64_t rows = ((M + slices - 1) / slices + CH - 1) / CH * CH;
         slices = (int)((M + rows - 1) / rows);
-        hipLaunchKernelGGL(grad_w_kernel, dim3(Np / TB, Kp / TB, slices), dim3(256), 0, s, dcur, Np, in, ld_in, M, rows, cpart, Np, Kp,
-                           bpart);
-        HIP_TRY(hipGetLastError());
-        float *dW = grad_dev + net->phase_src_off[(size_t)l];
-        hipLaunchKernelGGL(grad_w_reduce_kernel, dim3((N * K + N + 255) / 256), dim3(256), 0, s, cpart, bpart, slices, Np, Kp, N, K, dW,
-                           dW + (int64_t)N * K);
-        HIP_TRY(hipGetLastError());
-        if (l > 0) {
-            float *dnext = delta[flip];
-            flip ^= 1;
-            hipLaunchKernelGGL(grad_in_kernel, dim3((unsigned)((M + TB - 1) / TB), Kp / TB), dim3(256), 0, s, dcur,
-                               net->d_wb + wb_offset(net, l), in, M, Np, Kp, dnext);
-            HIP_TRY(hipGetLastError());
-            dcur = dnext;
-        }
+        J.P[l] = dl[l]; J.ldp[l] = Np;
+        J.Q[l] = l == 0 ? x : reinterpret_cast<const float *>(base + L.act[l - 1]);
+        J.ldq[l] = l == 0 ? L.x_ld : L.act_ld[l - 1];                  // == Kp
+        J.Np[l] = Np; J.Kp[l] = Kp; J.N[l] = N; J.K[l] = K; J.slices[l] = slices; J.rows_per_slice[l] = rows;
+        blocks_total += blocks * slices;
+        J.block_end[l] = blocks_total;
+        J.cpart_off[l] = c_off; c_off += (int64_t)slices * Np * Kp;
+        J.bpart_off[l] = b_off; b_off += (int64_t)slices * Np;
+        J.out_off[l] = net->phase_src_off[(size_t)l];
+        elems += (int64_t)N * K + N;
+        J.elem_end[l] = elems;
     }
+    hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grad_w_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, J, cpart, bpart, grad_dev);
+    HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }

@@ -430,7 +430,7 @@ class OptimizerBase:
         self._clip_grads()
         self.optimizer.step()
         self.wavefunction.parameters_changed()
-        if self.use_fused and saved is not None:
+        if self.use_fused and saved is not None and os.environ.get("NAQS_TRAIN_EARLY_REFRESH", "1") == "1":
             # re-pack the kernels' weight layouts NOW, behind the optimiser launch, instead of at the start of the next
             # sampling call: the host gets there tens of microseconds later and the GPU would wait for it
             self.wavefunction.fused(need_phase=True)

@@ -10,7 +10,7 @@ mkdir -p "$obj"
 echo "#define NAQS_SRC_HASH \"$(cat $src/*.hip $src/*.hpp | sha256sum | cut -c1-12)-var\"" > "$obj/naqs_src_hash.h"
 pids=()
 for f in naqs_hip naqs_logpsi naqs_sample naqs_grad naqs_phase_grad; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Iinclude -I"$obj" "$@" -c -o "$obj/$f.o" "$src/$f.hip" &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -I"$src" -Iinclude -I"$obj" "$@" -c -o "$obj/$f.o" "$src/$f.hip" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
