@@ -178,18 +178,25 @@ def test_staging_variants_agree_bitwise(env):
 @pytest.mark.parametrize("mol,tag", [("LiH", "c1"), ("H2O", "c1"), ("N2", "c2")])
 def test_single_and_double_compaction_kernels_agree(env, mol, tag):
     """NAQS_ELOC_V=1 (one compaction: a lane owns a group through filter, probe and push; heavy hits summed by the whole
-    wave) and the default eloc_kernel2 (filter pass queue -> dense probe passes, heavy groups as <= 8-term chunks) are
-    the same sums in a different order: 1e-12 relative, and both within the golden tolerance."""
+    wave) and eloc_kernel2 / the default eloc_kernel3 (filter pass queue -> dense probe passes, heavy groups as <= 8-term
+    chunks) are the same sums in a different order: 1e-12 relative, and all within the golden tolerance.  eloc_kernel3 is
+    eloc_kernel2 with the loads of each stage issued together — the same sums in the SAME order: bit-identical."""
     z = golden(f"eloc_{mol}.npz")
     ham = dev_ham(env, mol)
-    os.environ["NAQS_ELOC_V"] = "1"
-    try:
-        e1 = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
-    finally:
-        del os.environ["NAQS_ELOC_V"]
-    e2 = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
-    assert rel_err(e1, e2) < 1e-12
-    assert rel_err(e1, z[f"{tag}_eloc_c128"]) < 1e-10 and rel_err(e2, z[f"{tag}_eloc_c128"]) < 1e-10
+    e = {}
+    for v in ("1", "2"):
+        os.environ["NAQS_ELOC_V"] = v
+        try:
+            e[v] = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+            assert f"eloc_kernel{'' if v == '1' else v}<" in ham.last_kernel()
+        finally:
+            del os.environ["NAQS_ELOC_V"]
+    e["3"] = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+    assert "eloc_kernel3<" in ham.last_kernel()
+    assert rel_err(e["1"], e["3"]) < 1e-12
+    assert np.array_equal(e["2"], e["3"])
+    for v in e:
+        assert rel_err(e[v], z[f"{tag}_eloc_c128"]) < 1e-10, v
 
 
 def test_eloc_against_dense_pauli_algebra(env):
