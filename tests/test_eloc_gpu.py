@@ -180,7 +180,7 @@ def test_single_and_double_compaction_kernels_agree(env, mol, tag):
     """NAQS_ELOC_V=1 (one compaction: a lane owns a group through filter, probe and push; heavy hits summed by the whole
     wave) and eloc_kernel2 / the default eloc_kernel3 (filter pass queue -> dense probe passes, heavy groups as <= 8-term
     chunks) are the same sums in a different order: 1e-12 relative, and all within the golden tolerance.  eloc_kernel3 is
-    eloc_kernel2 with the loads of each stage issued together — the same sums in the SAME order: bit-identical."""
+    eloc_kernel2 with a leaner instruction stream — the same sums in the SAME order: bit-identical."""
     z = golden(f"eloc_{mol}.npz")
     ham = dev_ham(env, mol)
     e = {}
