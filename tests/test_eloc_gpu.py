@@ -178,21 +178,21 @@ def test_staging_variants_agree_bitwise(env):
 @pytest.mark.parametrize("mol,tag", [("LiH", "c1"), ("H2O", "c1"), ("N2", "c2")])
 def test_single_and_double_compaction_kernels_agree(env, mol, tag):
     """NAQS_ELOC_V=1 (one compaction: a lane owns a group through filter, probe and push; heavy hits summed by the whole
-    wave) and eloc_kernel2 / the default eloc_kernel3 (filter pass queue -> dense probe passes, heavy groups as <= 8-term
+    wave) and the default eloc_kernel2 / eloc_kernel3 (filter pass queue -> dense probe passes, heavy groups as <= 8-term
     chunks) are the same sums in a different order: 1e-12 relative, and all within the golden tolerance.  eloc_kernel3 is
     eloc_kernel2 with a leaner instruction stream — the same sums in the SAME order: bit-identical."""
     z = golden(f"eloc_{mol}.npz")
     ham = dev_ham(env, mol)
     e = {}
-    for v in ("1", "2"):
+    for v in ("1", "3"):
         os.environ["NAQS_ELOC_V"] = v
         try:
             e[v] = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
             assert f"eloc_kernel{'' if v == '1' else v}<" in ham.last_kernel()
         finally:
             del os.environ["NAQS_ELOC_V"]
-    e["3"] = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
-    assert "eloc_kernel3<" in ham.last_kernel()
+    e["2"] = run_eloc(env, ham, z[f"{tag}_keys"], z[f"{tag}_psi_f32"])
+    assert "eloc_kernel2<" in ham.last_kernel()
     assert rel_err(e["1"], e["3"]) < 1e-12
     assert np.array_equal(e["2"], e["3"])
     for v in e:
