@@ -30,9 +30,16 @@ __device__ __forceinline__ void split3t_pair(float lo, float hi, uint32_t &w1, u
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t &w1, uint32_t &w2) {
+    // hi: one packed conversion.  The residuals x - hi as v_fma_mix_f32 (hi read as the f16 half it is, times -1, plus x:
+    // exact): one instruction per value instead of a conversion back to f32 and a subtraction — the write-back of a
+    // 512-wide layer is VALU-bound (6 -> 4 instructions per value).  hipcc folds the equivalent C++ (fmaf(float(h), -1, x))
+    // back into cvt + sub, hence the asm; its operands are plain VALU results (no MFMA / transcendental hazard applies).
     const f16x2 h = {(_Float16)x0, (_Float16)x1};
-    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
     w1 = __builtin_bit_cast(uint32_t, h);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w1), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w1), "v"(x1));
+    const f16x2 l = {(_Float16)r0, (_Float16)r1};
     w2 = __builtin_bit_cast(uint32_t, l);
 }
 __device__ __forceinline__ void split2(float x, ushort_t &h1, ushort_t &h2) {
