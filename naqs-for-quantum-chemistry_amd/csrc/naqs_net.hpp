@@ -195,6 +195,8 @@ struct naqs_net {
     naqs::EventRing prof;
     char last_kernel[96] = {0};             // naqs_net_last_kernel
     int64_t *h_info = nullptr;              // pinned host words for the sampler's (M, overflow) read-back
+    hipStream_t side_stream = nullptr;      // the amplitude blocks' backward runs here, beside the phase MLP's (naqs_phase_grad.hip)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace naqs {

@@ -454,11 +454,26 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     float *cpart = reinterpret_cast<float *>(base + L.cpart), *bpart = reinterpret_cast<float *>(base + L.bpart);
     const float2 *g2 = reinterpret_cast<const float2 *>(g_dev);
 
-    // amplitude blocks
-    hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, g2, g_amp);
+    // amplitude blocks — on a second stream: they and the phase MLP's backward are independent (disjoint parts of the
+    // gradient, own scratch) and each is a chain of latency-bound launches that leaves most of the chip idle (37 us and
+    // 59 us at M ~ 1 200).  NAQS_TRAIN_SIDE_STREAM=0: one after the other on the caller's stream.
+    const bool side = naqs::env_int("NAQS_TRAIN_SIDE_STREAM", 1) == 1;
+    hipStream_t sa = s;
+    if (side) {
+        if (!net->side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&net->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+        }
+        sa = net->side_stream;
+        HIP_TRY(hipEventRecord(net->ev_fork, s));                 // g (and the keys) are ready on the caller's stream
+        HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0));
+    }
+    hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
     HIP_TRY(hipGetLastError());
-    st = naqs_net_amp_backward(net, M, keys_dev, g_amp, grad_dev, stream);
+    st = naqs_net_amp_backward(net, M, keys_dev, g_amp, grad_dev, sa);
     if (st != NAQS_OK) return st;
+    if (side) HIP_TRY(hipEventRecord(net->ev_join, sa));
 
     // phase block.  First the chain of deltas, output layer down (the critical path: each needs the one above) ...
     const int H = d.n_lin - 1;
@@ -503,5 +518,6 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(grad_w_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, J, cpart, bpart, grad_dev);
     HIP_TRY(hipGetLastError());
+    if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the caller's stream owns the whole gradient again
     return NAQS_OK;
 }
