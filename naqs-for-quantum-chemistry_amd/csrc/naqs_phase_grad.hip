@@ -454,10 +454,11 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     float *cpart = reinterpret_cast<float *>(base + L.cpart), *bpart = reinterpret_cast<float *>(base + L.bpart);
     const float2 *g2 = reinterpret_cast<const float2 *>(g_dev);
 
-    // amplitude blocks — on a second stream: they and the phase MLP's backward are independent (disjoint parts of the
-    // gradient, own scratch) and each is a chain of latency-bound launches that leaves most of the chip idle (37 us and
-    // 59 us at M ~ 1 200).  NAQS_TRAIN_SIDE_STREAM=0: one after the other on the caller's stream.
-    const bool side = naqs::env_int("NAQS_TRAIN_SIDE_STREAM", 1) == 1;
+    // amplitude blocks.  NAQS_TRAIN_SIDE_STREAM=1 runs them on a second stream beside the phase MLP's backward (independent:
+    // disjoint parts of the gradient, own scratch; 37 us and 59 us of latency-bound launches at M ~ 1 200).  Measured, three
+    // interleaved rounds on one box: N2 0.466 / 0.462 / 0.493 ms per step with it, 0.440 / 0.469 / 0.450 without; H2O 0.395 vs
+    // 0.387-0.399 — the fork / join events cost what the overlap wins, as they did for the forward pass in round 1.  Off.
+    const bool side = naqs::env_int("NAQS_TRAIN_SIDE_STREAM", 0) == 1;
     hipStream_t sa = s;
     if (side) {
         if (!net->side_stream) {
