@@ -1,9 +1,9 @@
 #!/bin/bash
 # BASELINE config 5: the N2 bond-dissociation sweep with the reference's batch_train_full_mask.sh flags, one geometry
 # after the other on ONE GPU, seeds 111 / 222 / 333 (the reference runs five per geometry and reports the best).
-# usage (GPU box): bash tools/n2_sweep.sh  ->  gpurun_out/r02_n2_sweep.txt
-R=$PWD
-OUT=$R/gpurun_out/r02_n2_sweep.txt
+# usage (GPU box): bash tools/n2_sweep.sh  ->  gpurun_out/${ROUND:-r03}/n2_sweep.txt
+R=$PWD; mkdir -p $R/gpurun_out/${ROUND:-r03}
+OUT=$R/gpurun_out/${ROUND:-r03}/n2_sweep.txt
 echo "r(A) seed time(s) final_E(Ha) FCI(Ha) error(mHa)" > $OUT
 cd naqs-for-quantum-chemistry_amd
 for r in 0.75 0.9 1.05 1.2 1.35 1.5 1.65 1.8 1.95 2.1 2.25; do
