@@ -1055,9 +1055,14 @@ __global__ __launch_bounds__(BOUNDS_WAVES * 64) void net_bounds_kernel(const flo
     }
 }
 
+// maximum of the BOUNDS_WG (= 64) per-workgroup partials: one load per lane + a wave reduction, every lane gets the result.
+// (A serial loop over the 64 entries — by one thread for the scale chain, by every workgroup for its weight scale — made
+// the packing launch 36 us instead of 8.)  Must be called by whole waves.
+static_assert(naqs::BOUNDS_WG == 64, "one partial per lane");
 __device__ __forceinline__ float bounds_max(const float (&part)[naqs::BOUNDS_WG]) {
-    float m = 0.0f;
-    for (int i = 0; i < naqs::BOUNDS_WG; ++i) m = fmaxf(m, part[i]);     // uniform addresses: scalar loads
+    float m = part[threadIdx.x & 63];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     return m;
 }
 
@@ -1065,17 +1070,20 @@ __device__ __forceinline__ float bounds_max(const float (&part)[naqs::BOUNDS_WG]
 __device__ __forceinline__ float phase_weight_scale(const naqs::PhaseRaw &raw, int l) {
     return pow2_clamped(13 - exp_of(bounds_max(raw.max_w[l])));
 }
-// all scales of the network (one thread): activation bound chain |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
+// all scales of the network (called by one whole wave; lane 0 writes): activation bound chain
+// |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
 __device__ __forceinline__ void phase_scales_fill(const naqs::PhaseRaw &raw, int n_lin, naqs::PhaseScales *out) {
     float bound = 1.0f, s_in = 1.0f;
     for (int l = 0; l < n_lin; ++l) {
         bound = bounds_max(raw.max_rowsum[l]) * bound + bounds_max(raw.max_b[l]);
         const float sw = phase_weight_scale(raw, l);
         const float sn = l + 1 < n_lin ? pow2_clamped(14 - exp_of(bound)) : 1.0f;          // bound sn < 2^15
-        out->sw[l] = sw;
-        out->sn[l] = sn;
-        out->isn[l] = 1.0f / sn;
-        out->c[l] = (sn / s_in) / sw;                // powers of two: exact
+        if ((threadIdx.x & 63) == 0) {
+            out->sw[l] = sw;
+            out->sn[l] = sn;
+            out->isn[l] = 1.0f / sn;
+            out->c[l] = (sn / s_in) / sw;            // powers of two: exact
+        }
         s_in = sn;
     }
 }
@@ -1260,7 +1268,7 @@ __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__
     }
     if (y < d.n_lin) {
         if (fmt == 2 && y == 0 && blockIdx.x == 0) {
-            if (threadIdx.x == 0) phase_scales_fill(*raw, d.n_lin, scales);
+            if (threadIdx.x < 64) phase_scales_fill(*raw, d.n_lin, scales);
         }
         pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw);
         return;
