@@ -326,6 +326,13 @@ int naqs_vmc_loss_grad(int64_t M, const double *eloc_dev, const double *w_dev, c
 int naqs_vmc_loss_grad_ev(int64_t M, const double *eloc_dev, const double *w_dev, const double *sums_dev, float *g_dev,
                           double *ev_dev, void *stream);
 
+/* Multi-GPU step: the payload of the accumulator all-reduce, assembled in one launch — ext_dev[8] (float64) =
+ * { sums_dev[0..4), M, M^2, c, c^2 } with c = (sum of the M keys) mod 2^20.  After a SUM over W ranks,
+ * W * sum(x^2) == (sum x)^2 for x = M and x = c holds iff every rank contributed the same table (all values are exact
+ * integers in float64): the per-step proof that the ranks row-sharded ONE table (the reference is single-process; the
+ * counterpart is the `weights` / `sampled_idxs` bookkeeping of src/optimizer/energy.py:300, :993). */
+int naqs_shard_proof(int64_t M, const uint64_t *keys_dev, const double *sums_dev, double *ext_dev, void *stream);
+
 /* Host evaluation of the sampler's generators, for known-answer and statistical tests (no device needed):
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */
 int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out);

@@ -367,6 +367,33 @@ NAQS_API int naqs_vmc_loss_grad_ev(int64_t M, const double *eloc_dev, const doub
     return vmc_loss_grad_impl(M, eloc_dev, w_dev, sums_dev, g_dev, ev_dev, stream);
 }
 
+namespace {
+__global__ __launch_bounds__(1024) void shard_proof_kernel(const int64_t M, const uint64_t *__restrict__ keys,
+                                                           const double *__restrict__ sums, double *__restrict__ ext) {
+    __shared__ unsigned long long s_part[16];
+    unsigned long long acc = 0ull;
+    for (int64_t i = threadIdx.x; i < M; i += 1024) acc += keys[i];          // modulo 2^64: order-independent
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0ull;
+        for (int w = 0; w < 16; ++w) t += s_part[w];
+        const double c = (double)(t & 0xFFFFFull), m = (double)M;
+        ext[0] = sums[0]; ext[1] = sums[1]; ext[2] = sums[2]; ext[3] = sums[3];
+        ext[4] = m; ext[5] = m * m; ext[6] = c; ext[7] = c * c;
+    }
+}
+}  // namespace
+
+NAQS_API int naqs_shard_proof(int64_t M, const uint64_t *keys_dev, const double *sums_dev, double *ext_dev, void *stream) {
+    if (M < 0 || (M > 0 && !keys_dev) || !sums_dev || !ext_dev) return NAQS_ERR_INVALID;
+    hipLaunchKernelGGL(shard_proof_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), M, keys_dev, sums_dev, ext_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
 NAQS_API int naqs_net_amp_param_count(const naqs_net_t *net, int64_t *count) {
     if (!net || !count) return NAQS_ERR_INVALID;
     *count = net->amp_params;

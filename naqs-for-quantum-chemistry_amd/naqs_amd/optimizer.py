@@ -367,9 +367,12 @@ class OptimizerBase:
                 # wedging the communicator.  The bytes are cheap (100 KB per rank at the published settings; latency-bound).
                 S = -(-M // world)
                 S_pad = max(S, -(-int(self.n_unq_samples_max) // world)) if getattr(self, "n_unq_samples_max", None) else S
-                mine = torch.zeros((S_pad, 2), dtype=torch.float32, device=self.device)
+                gb = getattr(self, "_gather_bufs", None)
+                if gb is None or gb[0].shape[0] != S_pad or gb[1].shape[0] != S_pad * world:
+                    gb = self._gather_bufs = (torch.zeros((S_pad, 2), dtype=torch.float32, device=self.device),
+                                             torch.empty((S_pad * world, 2), dtype=torch.float32, device=self.device))
+                mine, table = gb                       # rows past my shard keep old values: they are never looked at (>= M)
                 mine[:e_ - b] = lp_mine.detach()
-                table = torch.empty((S_pad * world, 2), dtype=torch.float32, device=self.device)
                 dist.all_gather_into_tensor(table, mine)
                 lp_all = table.view(world, S_pad, 2)[:, :S].reshape(-1, 2)[:M]
         if sample_weights is None:
@@ -391,9 +394,18 @@ class OptimizerBase:
             # one collective for the accumulators AND a proof that every rank sharded the same table: with
             # (M, M^2, c, c^2) appended (c = 20 low bits of the key sum), W * sum x^2 == (sum x)^2 holds iff all
             # ranks contributed the same x (Cauchy-Schwarz; everything is an exact integer in float64)
-            c = (keys.sum() & 0xFFFFF).double()
-            m = torch.tensor(float(M), dtype=torch.float64, device=self.device)
-            ext = torch.cat([sums, torch.stack([m, m * m, c, c * c])])
+            if self.device.type == "cuda":
+                # (one launch of the library instead of eight tiny torch kernels and a host-to-device copy of M: at
+                # M ~ 10^3 the sharded step is bound by its launches)
+                from . import _lib
+                from .fused import _stream_ptr
+                ext = torch.empty(8, dtype=torch.float64, device=self.device)
+                _lib.check(_lib.load_library().naqs_shard_proof(M, keys.data_ptr(), sums.data_ptr(), ext.data_ptr(),
+                                                                 _stream_ptr(self.device)), "naqs_shard_proof")
+            else:
+                c = (keys.sum() & 0xFFFFF).double()
+                m = torch.tensor(float(M), dtype=torch.float64, device=self.device)
+                ext = torch.cat([sums, torch.stack([m, m * m, c, c * c])])
             dist.all_reduce(ext)
             sums = ext[:4]
             shard_ok = (world * ext[5] == ext[4] * ext[4]) & (world * ext[7] == ext[6] * ext[6])
