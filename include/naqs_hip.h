@@ -289,6 +289,12 @@ int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, 
 int naqs_net_train_forward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream);
 int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev,
                             void *stream);
+/* naqs_vmc_loss_grad_ev + naqs_net_train_backward in ONE call (single-phase networks): the loss gradient g, its amplitude
+ * column and the output layer's delta are written by one launch instead of three (vmc_grad, split, top-delta), then the backward
+ * pass proper.  g_dev [M][2] and ev_dev [2] are outputs like naqs_vmc_loss_grad_ev's; grad_dev like naqs_net_train_backward's.
+ * = loss.backward() of _SGD_step (src/optimizer/energy.py:328-343) given E_loc, the weights and the accumulators. */
+int naqs_net_train_backward_vmc(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev, const double *w_dev,
+                                const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev, void *stream);
 /* naqs_net_train_forward and the local energies of the same table in one call (= naqs_logpsi_eloc that also keeps the
  * activations for naqs_net_train_backward): the single-GPU training step's forward half, three launches. */
 int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t *keys_dev, const double *w_dev,

@@ -194,7 +194,8 @@ struct naqs_net {
     bool grad_attr_set = false;
     naqs::EventRing prof;
     char last_kernel[96] = {0};             // naqs_net_last_kernel
-    int64_t *h_info = nullptr;              // pinned host words for the sampler's (M, overflow) read-back
+    int64_t *h_info = nullptr;              // mapped host words the sampler's last launch writes (M, overflow) to
+    int64_t *d_info_alias = nullptr;        // their device address
     hipStream_t side_stream = nullptr;      // the amplitude blocks' backward runs here, beside the phase MLP's (naqs_phase_grad.hip)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

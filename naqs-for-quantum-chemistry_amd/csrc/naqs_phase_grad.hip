@@ -53,6 +53,33 @@ __global__ __launch_bounds__(256) void top_delta_kernel(const NetDims d, const i
     delta[e] = c == occ ? g[i].y : 0.0f;
 }
 
+// vmc_grad + split_g + top_delta of the single-phase backward as ONE launch: element e = (sample i, output column c) of the
+// output layer's delta; column 0 also writes g_i, its amplitude component and (i == 0) the pair (<E>, Var).  Same float32
+// arithmetic as vmc_grad_kernel (naqs_grad.hip): g = (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>)), energy.py:328-329.
+__global__ __launch_bounds__(256) void vmc_seed_kernel(const NetDims d, const int64_t M, const uint64_t *__restrict__ keys,
+                                                       const double2 *__restrict__ eloc, const double *__restrict__ w,
+                                                       const double *__restrict__ sums, float2 *__restrict__ g,
+                                                       float *__restrict__ g_amp, float *__restrict__ delta, const int ld,
+                                                       double *__restrict__ ev) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) {
+        const double e_mean = sums[0] / sums[3];
+        ev[0] = e_mean;
+        ev[1] = sums[2] / sums[3] - e_mean * e_mean;
+    }
+    if (e >= M * ld) return;
+    const int64_t i = e / ld;
+    const int c = (int)(e - i * ld);
+    const float m_re = (float)sums[0], m_im = (float)sums[1];
+    const double2 el = eloc[i];
+    const float two_w = 2.0f * (float)w[i];
+    const float gx = ((float)el.x - m_re) * two_w, gy = -(((float)el.y - m_im) * two_w);
+    const uint64_t key = keys[i];
+    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    delta[e] = c == occ ? gy : 0.0f;
+    if (c == 0) { g[i] = make_float2(gx, gy); g_amp[i] = gx; }
+}
+
 // both columns of g [M][2] as contiguous vectors (aggregate-phase backward: one per set of blocks)
 __global__ __launch_bounds__(256) void split_g2_kernel(const int64_t M, const float2 *__restrict__ g, float *__restrict__ g_amp,
                                                        float *__restrict__ g_ph) {
@@ -404,23 +431,33 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
                                           int64_t info_host[2], void *stream) {
     if (!net || !ham || !weights_dev || !logpsi_dev || !eloc_dev || !out4_dev || !info_dev || !info_host) return NAQS_ERR_INVALID;
     if (!net->have_weights) return NAQS_ERR_INVALID;              // the forward needs the phase layers packed too
-    int st = naqs_net_sample_weighted(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, info_dev, stream);
-    if (st != NAQS_OK) return st;
     DeviceGuard guard;
-    st = guard.init(net->device);
+    int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (!net->h_info) HIP_TRY(hipHostMalloc((void **)&net->h_info, 2 * sizeof(int64_t), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(net->h_info, info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));   // pinned: a plain async copy
+    // (M, overflow) land in host memory the sampler's last launch writes to directly (mapped, coherent): no copy launch
+    // between the sampler and the synchronisation, nothing but the synchronisation between the sampler and the forward pass
+    if (!net->h_info) {
+        HIP_TRY(hipHostMalloc((void **)&net->h_info, 2 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
+    }
+    net->h_info[0] = net->h_info[1] = -1;
+    st = naqs_net_sample_weighted(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info_alias, stream);
+    if (st != NAQS_OK) return st;
     HIP_TRY(hipStreamSynchronize(s));                              // the step's one host synchronisation: M
     info_host[0] = net->h_info[0];
     info_host[1] = net->h_info[1];
+    if (info_host[0] < 0) return NAQS_ERR_HIP;                      // the launch never wrote them
+    (void)info_dev;
     if (info_host[1] != 0 || info_host[0] <= 0) return NAQS_OK;
     return naqs_net_train_forward_eloc(net, ham, info_host[0], keys_dev, weights_dev, logpsi_dev, eloc_dev, out4_dev, stream);
 }
 
-NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
-                                     float *grad_dev, void *stream) {
+// seeds: nullptr = g_dev holds the loss gradient (naqs_net_train_backward); else the loss gradient is formed here from
+// (E_loc, w, sums) together with its amplitude column and the output delta (naqs_net_train_backward_vmc, single-phase only)
+struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; };
+static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, void *stream,
+                               const VmcSeeds *seeds) {
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
     if (!net->have_weights || !net->have_wb) return NAQS_ERR_INVALID;
     if (!net->aggregate && (M > net->train_cap || !net->d_train)) return NAQS_ERR_INVALID;   // naqs_net_train_forward of the same batch comes first
@@ -470,16 +507,27 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
         HIP_TRY(hipEventRecord(net->ev_fork, s));                 // g (and the keys) are ready on the caller's stream
         HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0));
     }
-    hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
-    HIP_TRY(hipGetLastError());
+    const int H = d.n_lin - 1;
+    if (seeds != nullptr) {
+        // (on the caller's stream, before the fork: both halves of the backward pass read what it writes)
+        hipLaunchKernelGGL(vmc_seed_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+                           reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
+                           g_amp, top, L.top_ld, seeds->ev);
+        HIP_TRY(hipGetLastError());
+        if (side) { HIP_TRY(hipEventRecord(net->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0)); }
+    } else {
+        hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
+        HIP_TRY(hipGetLastError());
+    }
     st = naqs_net_amp_backward(net, M, keys_dev, g_amp, grad_dev, sa);
     if (st != NAQS_OK) return st;
     if (side) HIP_TRY(hipEventRecord(net->ev_join, sa));
 
     // phase block.  First the chain of deltas, output layer down (the critical path: each needs the one above) ...
-    const int H = d.n_lin - 1;
-    hipLaunchKernelGGL(top_delta_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, g2, top, L.top_ld);
-    HIP_TRY(hipGetLastError());
+    if (seeds == nullptr) {
+        hipLaunchKernelGGL(top_delta_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, g2, top, L.top_ld);
+        HIP_TRY(hipGetLastError());
+    }
     const float *dl[MAXL];                            // delta of linear layer l's output
     dl[H] = top;
     for (int l = H; l > 0; --l) {
@@ -521,4 +569,22 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     HIP_TRY(hipGetLastError());
     if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the caller's stream owns the whole gradient again
     return NAQS_OK;
+}
+
+NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
+                                     float *grad_dev, void *stream) {
+    return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr);
+}
+
+NAQS_API int naqs_net_train_backward_vmc(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
+                                         const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
+                                         void *stream) {
+    if (!net || !sums_dev || !ev_dev || !g_dev || (M > 0 && (!eloc_dev || !w_dev))) return NAQS_ERR_INVALID;
+    if (net->aggregate || M == 0) {                   // per-pair phase blocks (or nothing to do): the two separate calls
+        int st = naqs_vmc_loss_grad_ev(M, eloc_dev, w_dev, sums_dev, g_dev, ev_dev, stream);
+        if (st != NAQS_OK) return st;
+        return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr);
+    }
+    const VmcSeeds seeds{eloc_dev, w_dev, sums_dev, g_dev, ev_dev};
+    return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, &seeds);
 }

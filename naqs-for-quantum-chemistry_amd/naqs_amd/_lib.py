@@ -59,6 +59,7 @@ SIGNATURES = {
     "naqs_net_amp_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_train_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "naqs_net_train_forward_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_net_train_backward_vmc": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_shard_proof": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_sample_forward_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                     c_vp, ctypes.POINTER(c_i64), c_vp]),

@@ -210,6 +210,35 @@ class FusedLogPsi:
         return g
 
     @torch.no_grad()
+    def backward_from_local_energy(self, saved, e_loc, weights, sums):
+        """``vmc_loss_grad(..., with_energy=True)`` + ``backward_saved`` as ONE library call
+        (``naqs_net_train_backward_vmc``): the loss gradient, its amplitude column and the output layer's delta come out of
+        one launch instead of three.  -> (g [M, 2] f32, ev f64 [2]); the parameters' ``.grad`` are set like
+        ``backward_saved`` does.  Needs the token of ``forward_saved*`` in HIP mode and parameters without gradients."""
+        keys = saved[0]
+        M = keys.shape[0]
+        params = self.wf.param_list()
+        if saved[1] is not None or not all(p.grad is None for p in params):
+            g, ev = self.vmc_loss_grad(e_loc, weights, sums, with_energy=True)
+            self.backward_saved(saved, g)
+            return g, ev
+        if self._grad_flat is None:
+            self._grad_flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            self._grad_views, off = [], 0
+            for p in params:
+                n = p.numel()
+                self._grad_views.append(self._grad_flat[off:off + n].view(p.shape))
+                off += n
+        g = torch.empty((M, 2), dtype=torch.float32, device=self.device)
+        ev = torch.empty(2, dtype=torch.float64, device=self.device)
+        st = self._lib.naqs_net_train_backward_vmc(self._h, M, keys.data_ptr(), e_loc.data_ptr(), weights.data_ptr(), sums.data_ptr(),
+                                                   g.data_ptr(), ev.data_ptr(), self._grad_flat.data_ptr(), _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_train_backward_vmc")
+        for p, gv in zip(params, self._grad_views):
+            p.grad = gv
+        return g, ev
+
+    @torch.no_grad()
     def backward_saved(self, saved, g):
         """Accumulate d/d theta sum_i (g[i, 0] log|psi_i| + g[i, 1] phase_i) into the ``.grad`` of every network
         parameter: ``naqs_net_amp_backward`` for the amplitude blocks, the phase MLP's chain rule as plain GEMMs

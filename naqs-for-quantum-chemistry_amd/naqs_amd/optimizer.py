@@ -415,9 +415,8 @@ class OptimizerBase:
         if saved is not None:
             # d loss / d log psi of vmc_loss, written out: (2 w Re(E_loc - <E>), -2 w Im(E_loc - <E>)); the same launch
             # leaves (<E>, Var) of energy.py:372-375 on the device
-            g, ev = fused.vmc_loss_grad(e_loc, w[b:e_].contiguous(), sums, with_energy=True)
+            g, ev = fused.backward_from_local_energy(saved, e_loc, w[b:e_].contiguous(), sums)
             self._loss_terms, self._last_loss = (g, lp_mine), None
-            fused.backward_saved(saved, g)
         else:
             e_mean = torch.stack([sums[0], sums[1]])                    # (sum w E_loc), like energy.py:328 (w not renormalised)
             loss = vmc_loss(lp_mine, e_loc.to(lp_mine.dtype), w[b:e_].to(lp_mine.dtype), e_mean.to(lp_mine.dtype))
