@@ -71,98 +71,7 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// Binomial(n, p) drawn by a group of G consecutive lanes (G = 4: a quad, G = 2: half of one).  The lanes of a group pass
-// the same arguments and all return the same variate — the one naqs::binomial() returns for the stream (k0, k1, c0, c1).
-// What the group buys is latency: a tree level lasts as long as its slowest wave, and a wave's BTRS rejection loop as
-// long as its unluckiest lane (~3 rounds of 16-32 concurrent draws, each round through the log-heavy exact test).
-// Here lane j of the group evaluates attempt round * G + j of the SAME draw and the first accepted attempt in attempt
-// order wins, so a draw needs a second round with probability 0.13^G instead of 0.13.  Must be called by all 64 lanes
-// (wave-uniform control flow: it votes and shuffles); lanes with nothing to draw pass need = false.
-// Round 3: the exact acceptance test is shared out too.  A level's time is its slowest wave's two dependent binomial calls,
-// and every call ran the exact test (three float64 logs + the mode's, one after the other, on whichever lanes fell outside
-// the squeeze: practically always somebody among a wave's 16-32 draws).  Now every lane only CLASSIFIES its attempt (squeeze
-// accept / out of range / needs the exact test), the group resolves its attempts in order, and an attempt that needs the
-// exact test gets it from the whole group: its four logarithms — log v-term, log1p (as log(1 + x) x / ((1 + x) - 1): one
-// uniform log call for every lane), the k-term and the mode's — are evaluated by different lanes at once (a quad: one log
-// call deep; a pair: two) and exchanged, and the test is assembled with the arithmetic of naqs::btrs_attempt.  Attempts
-// behind an accepted one are never tested.
-template <int G>
-__device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, const double p, const uint32_t k0,
-                                                  const uint32_t k1, const uint32_t c0, const uint32_t c1) {
-    static_assert(G == 2 || G == 4, "a pair or a quad");
-    const int lane = threadIdx.x & 63, j = lane & (G - 1), base = lane & ~(G - 1);
-    int64_t fixed = 0;
-    if (need && (n <= 0 || !(p > 0.0))) need = false;
-    if (need && p >= 1.0) { fixed = n; need = false; }
-    const bool flip = p > 0.5;
-    const double pp = flip ? 1.0 - p : p, nd = (double)n;
-    const bool inv = need && nd * pp < 10.0, bt = need && !inv;
-    double k = 0.0;
-    if (inv) {                                                  // short sequential search: every lane of the group runs it
-        naqs::RngStream g{k0, k1, c0, c1, 0u, 0u};
-        k = naqs::binomial_inversion(nd, pp, g);
-    }
-    naqs::Btrs t;
-    if (bt) naqs::btrs_setup(t, nd, pp);
-    bool pending = bt;
-    for (int round = 0; round < naqs::BTRS_MAX_ATTEMPTS / G && __ballot(pending) != 0ull; ++round) {
-        // my attempt, classified: 0 accepted by the squeeze, 1 needs the exact test, 2 rejected (out of range) / nothing
-        int cls = 2;
-        double us = 0.5, v = 0.0, kk = 0.0;
-        if (pending) {
-            naqs::RngStream g{k0, k1, c0, c1, 0u, (uint32_t)(round * G + j)};
-            double u;
-            g.pair(u, v);
-            u -= 0.5;
-            us = 0.5 - fabs(u);
-            kk = floor((2.0 * t.a * naqs::rcp_fast(us) + t.b) * u + t.c);
-            cls = (us >= 0.07 && v <= t.vr) ? 0 : ((kk < 0.0 || kk > t.n) ? 2 : 1);
-        }
-#pragma unroll
-        for (int jj = 0; jj < G; ++jj) {                        // the group's attempts, in attempt order
-            const int src = base + jj;
-            int cls_j = __shfl(cls, src, 64);
-            const bool exact = pending && cls_j == 1;           // uniform within a group
-            if (__ballot(exact) != 0ull) {
-                if (exact) {
-                    const double us_j = __shfl(us, src, 64), v_j = __shfl(v, src, 64), k_j = __shfl(kk, src, 64);
-                    const double alpha = (2.83 + 5.1 * t.rb) * t.spq;
-                    const double r = t.p * naqs::rcp_fast(1.0 - t.p);
-                    // arguments of the four logarithms; term 1 (log1p) goes through log(1 + x) with Kahan's correction
-                    const double x1 = (k_j - t.m) * naqs::rcp_fast(t.n - k_j + 1.0);
-                    const double a0 = v_j * alpha * naqs::rcp_fast(t.a * naqs::rcp_fast(us_j * us_j) + t.b);
-                    const double a1 = 1.0 + x1;
-                    const double a2 = r * (t.n - k_j + 1.0) * naqs::rcp_fast(k_j + 1.0);
-                    const double a3 = (t.m + 1.0) * naqs::rcp_fast(r * (t.n - t.m + 1.0));
-                    double T[4];
-                    if (G == 4) {
-                        const double mine = log(j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)));
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) T[q] = __shfl(mine, base + q, 64);
-                    } else {
-                        const double m0 = log(j == 0 ? a0 : a1), m1 = log(j == 0 ? a2 : a3);
-                        T[0] = __shfl(m0, base, 64); T[1] = __shfl(m0, base + 1, 64);
-                        T[2] = __shfl(m1, base, 64); T[3] = __shfl(m1, base + 1, 64);
-                    }
-                    const double l1p = a1 == 1.0 ? x1 : T[1] * x1 * naqs::rcp_fast(a1 - 1.0);      // log1p(x1)
-                    const double h_m = (t.m + 0.5) * T[3] + naqs::stirling_tail(t.m) + naqs::stirling_tail(t.n - t.m);
-                    const double ub = h_m + (t.n + 1.0) * l1p + (k_j + 0.5) * T[2] - naqs::stirling_tail(k_j) -
-                                      naqs::stirling_tail(t.n - k_j);
-                    cls_j = T[0] <= ub ? 0 : 2;
-                }
-            }
-            if (pending && cls_j == 0) {
-                k = __shfl(kk, src, 64);
-                pending = false;
-            }
-        }
-    }
-    if (pending) k = t.m;                                       // unreachable in practice
-    if (!need) return fixed;
-    int64_t ki = (int64_t)k;
-    ki = ki < 0 ? 0 : (ki > n ? n : ki);
-    return flip ? n - ki : ki;
-}
+using naqs::binomial_group;
 
 // One prefix, one quad of lanes (q = lane & 3): the hidden units of block n are split four ways, then the quad draws the
 // first-level binomial of the multinomial split together and its two halves the two independent second-level ones.  Weights of pair n are in s_w (staged and
