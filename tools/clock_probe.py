@@ -11,7 +11,7 @@ from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
 from naqs_amd.fused import FusedLogPsi
 dev = torch.device("cuda", 0)
 ham_p = packing.load_packed(os.path.join(ROOT, "tests", "golden", "ham_N2.npz"))
-keys_np, _, _ = bench.make_batch(ham_p, 10000, 0)
+keys_np, _, _ = bench.make_batch(ham_p, int(os.environ.get("NAQS_PROBE_M", "10000")), 0)
 keys = hamiltonian.keys_to_device(keys_np, dev)
 hil = Hilbert.get(20, 7, 7, encoding=Encoding.SIGNED)
 wf = NAQSComplex_NADE_orbitals(hil, device=dev, qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512], use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=False, n_alpha_electrons=7, n_beta_electrons=7)
