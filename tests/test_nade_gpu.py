@@ -329,3 +329,47 @@ def test_graph_free_training_step_matches_autograd(mol, mode):
         assert float((p.grad - ref).abs().max()) < 2e-5 * scale + 1e-10, (name, float((p.grad - ref).abs().max()), scale)
     fused.backward_saved(saved, g)                               # accumulates like autograd does
     assert torch.allclose(params[-1].grad, 2 * grads_ref[-1], rtol=1e-5, atol=1e-10)
+
+
+def test_fused_step_calls_equal_their_parts():
+    """The training loop's combined library calls against the separate ones they replace, same inputs, bit for bit:
+    naqs_vmc_sample_forward_eloc == naqs_net_sample_weighted + naqs_net_train_forward_eloc; naqs_net_train_backward_vmc ==
+    naqs_vmc_loss_grad_ev + naqs_net_train_backward; naqs_shard_proof == its definition."""
+    import ctypes
+    from test_nade import make_wf
+    from naqs_amd import _lib, hamiltonian, packing
+    from naqs_amd.fused import _stream_ptr
+    z = golden("nade_LiH.npz")
+    hil, wf = make_wf("LiH", z, device="cuda")
+    fused = wf.fused()
+    ham = hamiltonian.DevicePauliHamiltonian(packing.load_packed(os.path.join(GOLDEN, "ham_LiH.npz")), device="cuda:0")
+    # sampling + forward + E_loc
+    keys, counts, probs, weights, pre = fused.sample_forward_local_energy(ham, 10 ** 6, 77, 1000)
+    lp, saved, eloc, sums = pre
+    k2, c2, p2, w2 = fused.sample(10 ** 6, 77, 1000, with_weights=True)
+    assert torch.equal(keys, k2) and torch.equal(counts, c2) and torch.equal(probs, p2) and torch.equal(weights, w2)
+    lp2, saved2, eloc2, sums2 = fused.forward_saved_with_local_energy(ham, k2, w2)
+    torch.cuda.synchronize()
+    assert torch.equal(lp, lp2) and torch.equal(eloc, eloc2) and torch.equal(sums, sums2)
+    # loss gradient + backward
+    for p in wf.model.parameters():
+        p.grad = None
+    g, ev = fused.backward_from_local_energy(saved2, eloc2, w2.contiguous(), sums2)
+    grads = [p.grad.clone() for p in wf.model.parameters()]
+    for p in wf.model.parameters():
+        p.grad = None
+    fused._grad_flat = None
+    lp3, saved3 = fused.forward_saved(k2)
+    g_ref, ev_ref = fused.vmc_loss_grad(eloc2, w2.contiguous(), sums2, with_energy=True)
+    fused.backward_saved(saved3, g_ref)
+    torch.cuda.synchronize()
+    assert torch.equal(g, g_ref) and torch.equal(ev, ev_ref)
+    for a, p in zip(grads, wf.model.parameters()):
+        assert torch.equal(a, p.grad)
+    # the accumulator payload of the multi-GPU step
+    lib = _lib.load_library()
+    ext = torch.empty(8, dtype=torch.float64, device="cuda")
+    _lib.check(lib.naqs_shard_proof(len(k2), k2.data_ptr(), sums2.data_ptr(), ext.data_ptr(), _stream_ptr(k2.device)), "naqs_shard_proof")
+    c = float((k2.sum() & 0xFFFFF).item())
+    want = torch.cat([sums2, torch.tensor([len(k2), len(k2) ** 2, c, c * c], dtype=torch.float64, device="cuda")])
+    assert torch.equal(ext, want)
