@@ -335,7 +335,8 @@ def test_fused_step_calls_equal_their_parts():
     """The training loop's combined library calls against the separate ones they replace, same inputs, bit for bit:
     naqs_vmc_sample_forward_eloc == naqs_net_sample_weighted + naqs_net_train_forward_eloc; naqs_net_train_backward_vmc ==
     naqs_vmc_loss_grad_ev + naqs_net_train_backward; naqs_shard_proof == its definition."""
-    import ctypes
+    import os
+    from conftest import GOLDEN
     from test_nade import make_wf
     from naqs_amd import _lib, hamiltonian, packing
     from naqs_amd.fused import _stream_ptr
