@@ -80,6 +80,28 @@ __global__ __launch_bounds__(256) void vmc_seed_kernel(const NetDims d, const in
     if (c == 0) { g[i] = make_float2(gx, gy); g_amp[i] = gx; }
 }
 
+// delta of the LAST hidden layer without a GEMM: the output layer's delta has one non-zero column per sample (the realised
+// outcome's phase), so  delta[i][k] = [act[i][k] > 0] * g_i.y * W_top[occ_i][k]  — the single surviving term of the product
+// grad_in_kernel would form over a 64-wide zero-padded delta (bit-identical: the other terms add +0.0).  Four columns per thread.
+__global__ __launch_bounds__(256) void delta_below_top_kernel(const NetDims d, const int64_t M, const uint64_t *__restrict__ keys,
+                                                              const float2 *__restrict__ g, const float *__restrict__ Wtop,
+                                                              const float *__restrict__ act, const int Kp, float *__restrict__ dout) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k4 = Kp >> 2;
+    if (e >= M * k4) return;
+    const int64_t i = e / k4;
+    const int k = (int)(e - i * k4) << 2;
+    const uint64_t key = keys[i];
+    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    const float gy = g[i].y;
+    const f32x4 w = *reinterpret_cast<const f32x4 *>(Wtop + (int64_t)occ * Kp + k);
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(act + i * Kp + k);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = a[c] > 0.0f ? gy * w[c] : 0.0f;
+    *reinterpret_cast<f32x4 *>(dout + i * Kp + k) = o;
+}
+
 // both columns of g [M][2] as contiguous vectors (aggregate-phase backward: one per set of blocks)
 __global__ __launch_bounds__(256) void split_g2_kernel(const int64_t M, const float2 *__restrict__ g, float *__restrict__ g_amp,
                                                        float *__restrict__ g_ph) {
@@ -534,6 +556,14 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         const int Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
         const float *in = reinterpret_cast<const float *>(base + L.act[l - 1]);
         float *dnext = reinterpret_cast<float *>(base + L.delta[l - 1]);
+        if (l == H) {                                     // below the output layer: one term per element, no GEMM
+            const float2 *gsrc = seeds != nullptr ? reinterpret_cast<const float2 *>(seeds->g_out) : g2;
+            hipLaunchKernelGGL(delta_below_top_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, gsrc,
+                               net->d_wb + wb_offset(net, l), in, Kp, dnext);
+            HIP_TRY(hipGetLastError());
+            dl[l - 1] = dnext;
+            continue;
+        }
         hipLaunchKernelGGL(grad_in_kernel, dim3((unsigned)((M + TB - 1) / TB), Kp / TB), dim3(256), 0, s, dl[l],
                            net->d_wb + wb_offset(net, l), in, M, Np, Kp, dnext);
         HIP_TRY(hipGetLastError());
