@@ -311,6 +311,20 @@ int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t n_sam
                                  uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
                                  float *logpsi_dev, double *eloc_dev, double *out4_dev, int64_t *info_dev,
                                  int64_t info_host[2], void *stream);
+/* ONE VMC training step in ONE call (single GPU, single-phase or aggregate-phase fused network):
+ *   naqs_net_sample_weighted  ->  host learns (M, overflow)  ->  [accept M?]  ->  naqs_net_train_forward_eloc  ->
+ *   naqs_net_train_backward_vmc  ->  naqs_adam_step on the flat parameter vector  ->  naqs_net_set_weights (re-pack).
+ * = wavefunction.sample + calculate_local_energy + loss.backward() + optimizer.step() of PartialSamplingOptimizer.run /
+ * _SGD_step (src/optimizer/energy.py:975-1008, :273-377).  The reference's adaptive sample count (energy.py:936-971) stays
+ * with the caller: the step is abandoned after sampling — nothing evaluated, nothing updated — when the tree overflowed or
+ * M is outside [m_lo, m_hi]; info_host[0] = M, [1] = overflow, [2] = 1 iff the step was taken.  adam_step < 1: stop after the
+ * backward pass (the caller owns the optimiser).  The point of one call: between the sampler's last kernel and the re-pack
+ * the GPU never waits for the caller's interpreter (measured: ~0.1 ms per step between the forward and the backward pass). */
+int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
+                  int64_t m_hi, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
+                  float *logpsi_dev, double *eloc_dev, double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
+                  float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int64_t adam_step, int64_t info_host[3], void *stream);
 /* One Adam step on a flat float32 parameter vector (device pointers): torch.optim.Adam's rule without amsgrad —
  * the reference's optimiser, experiments/_base.py:228 (betas (0.9, 0.99), eps 1e-15).  `step` is the 1-based count
  * after this update (bias corrections 1 - beta^step are formed on the host in float64). */

@@ -601,6 +601,50 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     return NAQS_OK;
 }
 
+NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
+                           int64_t m_hi, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
+                           float *logpsi_dev, double *eloc_dev, double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
+                           float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, double lr, double beta1, double beta2,
+                           double eps, double weight_decay, int64_t adam_step, int64_t info_host[3], void *stream) {
+    if (!net || !info_host || !g_dev || !ev_dev || !grad_dev) return NAQS_ERR_INVALID;
+    if (adam_step >= 1 && (!param_dev || !exp_avg_dev || !exp_avg_sq_dev)) return NAQS_ERR_INVALID;
+    info_host[2] = 0;
+    int64_t info2[2] = {0, 0};
+    // sampler, the step's one host synchronisation, forward pass + E_loc of the sampled table
+    // (an abandoned step must not have evaluated anything: sample first, look at M, then go on)
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!net->have_weights) return NAQS_ERR_INVALID;
+    if (!net->h_info) {
+        HIP_TRY(hipHostMalloc((void **)&net->h_info, 2 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
+    }
+    net->h_info[0] = net->h_info[1] = -1;
+    st = naqs_net_sample_weighted(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info_alias, stream);
+    if (st != NAQS_OK) return st;
+    HIP_TRY(hipStreamSynchronize(s));
+    info2[0] = net->h_info[0]; info2[1] = net->h_info[1];
+    info_host[0] = info2[0]; info_host[1] = info2[1];
+    if (info2[0] < 0) return NAQS_ERR_HIP;
+    const int64_t M = info2[0];
+    if (info2[1] != 0 || M <= 0 || M < m_lo || M > m_hi) return NAQS_OK;        // abandoned: the caller adapts n_samples
+    st = naqs_net_train_forward_eloc(net, ham, M, keys_dev, weights_dev, logpsi_dev, eloc_dev, sums_dev, stream);
+    if (st != NAQS_OK) return st;
+    st = naqs_net_train_backward_vmc(net, M, keys_dev, eloc_dev, weights_dev, sums_dev, g_dev, ev_dev, grad_dev, stream);
+    if (st != NAQS_OK) return st;
+    if (adam_step >= 1) {
+        st = naqs_adam_step(net->n_params, param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay,
+                            adam_step, stream);
+        if (st != NAQS_OK) return st;
+        st = naqs_net_set_weights(net, param_dev, net->n_params, stream);           // the next sampling call reads these
+        if (st != NAQS_OK) return st;
+    }
+    info_host[2] = 1;
+    return NAQS_OK;
+}
+
 NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
                                      float *grad_dev, void *stream) {
     return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr);

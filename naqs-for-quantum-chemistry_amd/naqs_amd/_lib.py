@@ -60,6 +60,8 @@ SIGNATURES = {
     "naqs_net_train_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "naqs_net_train_forward_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_net_train_backward_vmc": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "naqs_vmc_step": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_i64] + [c_vp] * 13 +
+                      [ctypes.c_double] * 5 + [c_i64, ctypes.POINTER(c_i64), c_vp]),
     "naqs_shard_proof": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_sample_forward_eloc": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_uint64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                     c_vp, ctypes.POINTER(c_i64), c_vp]),

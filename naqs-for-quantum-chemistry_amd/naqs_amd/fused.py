@@ -388,6 +388,59 @@ class FusedLogPsi:
         k = keys[:m]
         return k, counts[:m], probs[:m], weights[:m], (log_psi[:m], (k, None, None), eloc[:m], sums)
 
+    @torch.no_grad()
+    def vmc_step(self, ham, n_samples, seed, max_unique, m_lo, m_hi, adam=None):
+        """One whole VMC training step as ONE library call (``naqs_vmc_step``): sampling, the host's look at (M, overflow),
+        forward + E_loc, loss gradient + backward, Adam on the flat parameter vector and the re-pack of the kernels' weight
+        layouts — the interpreter is not on the GPU's critical path between the first and the last launch of the step.
+        ``adam``: a ``FlatAdam`` whose flat vector is this network's (its step counter is advanced here), or None to stop
+        after the backward pass (gradients in ``self._grad_flat``).  The step is abandoned after sampling when the tree
+        overflowed or M is outside [m_lo, m_hi].  -> (taken, M, overflow, (keys, counts, probs, weights, log psi, E_loc,
+        sums, g, ev)) — the tensors are views of length M (None when not taken)."""
+        cap = int(max_unique)
+        dev = self.device
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        counts = torch.empty(cap, dtype=torch.int64, device=dev)
+        probs = torch.empty(cap, dtype=torch.float32, device=dev)
+        weights = torch.empty(cap, dtype=torch.float64, device=dev)
+        log_psi = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        eloc = torch.empty((cap, 2), dtype=torch.float64, device=dev)
+        g = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        small = torch.empty(6, dtype=torch.float64, device=dev)
+        sums, ev = small[:4], small[4:]
+        if self._grad_flat is None:
+            self._grad_flat = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+            self._grad_views, off = [], 0
+            for p in self.wf.param_list():
+                n = p.numel()
+                self._grad_views.append(self._grad_flat[off:off + n].view(p.shape))
+                off += n
+        info = (ctypes.c_int64 * 3)(0, 0, 0)
+        if adam is not None:
+            grp = next(g_ for g_ in adam.param_groups if g_['params'])
+            flat, m1, m2, t = adam._flat, adam._m, adam._v, adam._t + 1
+            if flat.numel() != self.n_params:
+                raise ValueError("vmc_step: the optimiser's flat vector is not this network's")
+            hyper = (float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']))
+            ptrs = (flat.data_ptr(), m1.data_ptr(), m2.data_ptr())
+        else:
+            hyper, ptrs, t = (0.0, 0.0, 0.0, 0.0, 0.0), (None, None, None), 0
+        st = self._lib.naqs_vmc_step(self._h, ham._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, int(m_lo), int(m_hi),
+                                     keys.data_ptr(), counts.data_ptr(), probs.data_ptr(), weights.data_ptr(), log_psi.data_ptr(),
+                                     eloc.data_ptr(), sums.data_ptr(), g.data_ptr(), ev.data_ptr(), self._grad_flat.data_ptr(),
+                                     ptrs[0], ptrs[1], ptrs[2], *hyper, t, info, _stream_ptr(dev))
+        _lib.check(st, "naqs_vmc_step")
+        m, overflow, taken = int(info[0]), bool(info[1]), bool(info[2])
+        if not taken:
+            return False, m, overflow, None
+        if adam is not None:
+            if not adam.state:
+                adam._bind_state()
+            adam._t = t
+            adam._opt_called = True          # (what torch's LR schedulers look at to see that a step preceded theirs)
+            self._flat = adam._flat
+        return True, m, False, (keys[:m], counts[:m], probs[:m], weights[:m], log_psi[:m], eloc[:m], sums, g[:m], ev)
+
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")
         _lib.check(self._lib.naqs_net_prof_stride(self._h, int(stride)), "naqs_net_prof_stride")

@@ -554,6 +554,66 @@ class PartialSamplingOptimizer(OptimizerBase):
         fused = self.wavefunction.fused(need_phase=True)
         return fused is not None and fused.train_mode == "hip"
 
+    def _can_onecall(self):
+        """The conditions under which a whole training step is ONE library call (``FusedLogPsi.vmc_step``): the single-GPU
+        fused branch of _SGD_step, followed by FlatAdam on the network's own flat parameter vector with nothing in between
+        (no gradient clipping: experiments/_base.py:224 runs with grad_clip_factor=None)."""
+        from .flat_adam import FlatAdam
+        if os.environ.get("NAQS_TRAIN_ONECALL", "1") != "1" or not self._can_prefuse():
+            return False
+        if self.grad_clip_factor is not None or not isinstance(self.optimizer, FlatAdam):
+            return False
+        wf = self.wavefunction
+        flat = getattr(wf, "_flat_params", None)
+        return (flat is not None and flat.data_ptr() == self.optimizer._flat.data_ptr() and wf._views_of(flat, wf.param_list())
+                and all(p.grad is None for p in wf.param_list()))
+
+    def _onecall_step(self):
+        """get_samples (adaptive sample count, energy.py:936-971) + _SGD_step (energy.py:273-377) through
+        ``FusedLogPsi.vmc_step``: the library abandons a step right after sampling when get_samples would have re-sampled
+        (tree overflow, or too few unique samples while the count may still grow), and this loop then adapts n_samples with
+        the reference's rules and messages.  -> (counts, weights, ev) of the step that was taken."""
+        wf = self.wavefunction
+        fused = wf.fused(need_phase=True)
+        last_action = 0
+        while True:
+            free = (self.n_samples != self.n_unq_samples_min) and (self.n_samples != self.n_samples_max)
+            m_lo = self.n_unq_samples_min if (free and last_action >= 0) else 0
+            seed = wf._next_sample_seed(self.generator)
+            taken, n_unq, overflow, out = fused.vmc_step(self.pauli_hamiltonian, self.n_samples, seed, self.n_unq_samples_max,
+                                                          m_lo, self.n_unq_samples_max, adam=self.optimizer)
+            if taken:
+                break
+            action = 0
+            if overflow:
+                print("MaxBatchSizeExceededError")
+                n_unq, action = self.n_unq_samples_max + 1, -1
+            if free or overflow:
+                if n_unq < self.n_unq_samples_min and last_action >= 0:
+                    action = 1
+                    self.n_samples = int(min(self.n_samples * 10, self.n_samples_max))
+                    print(f"\t...{n_unq} unique samples generated --> increasing batch size to "
+                          f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
+                elif n_unq > self.n_unq_samples_max and last_action <= 0:
+                    action = -1
+                    self.n_samples = int(max(self.n_samples / 10, self.n_unq_samples_min))
+                    print(f"\t...{n_unq} unique samples generated --> decreasing batch size to "
+                          f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
+            if action == 0:
+                raise RuntimeError(f"VMC step abandoned without a reason to re-sample (M={n_unq})")
+            last_action = action
+        keys, counts, probs, weights, lp, e_loc, sums, g, ev = out
+        wf.fused_repacked()
+        self._sample_keys, self._sample_weights, self._prefused = keys, weights, None
+        if self.track_sampled_idxs:
+            self._sampled_pending.append(keys)
+            if len(self._sampled_pending) >= 256:
+                self._flush_sampled_idxs()
+        self._loss_terms, self._last_loss = (g, lp), None
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return counts, weights, ev
+
     def get_samples(self, last_action=0, lazy=False):
         """Adaptive sample count (energy.py:936-971): x10 while too few unique samples, /10 when too many
         or when the unique-prefix tree exceeds ``n_unq_samples_max``.  -> (states, counts, probs); the keys and the
@@ -636,14 +696,18 @@ class PartialSamplingOptimizer(OptimizerBase):
         print("Training NAQS energy.  Samples will be weighted by their frequency.")
         if self.n_steps == 0:
             self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=False)
+        onecall = self._can_onecall()
         for _ in range(n_epochs):
             t0 = time.time()
-            states, counts, probs = self.get_samples(lazy=True)
-            weights = self._sample_weights                                            # counts / sum(counts), energy.py:993
-            keys = self._sample_keys                                                  # = hilbert.state2idx(states)
-            # <E>, Var stay on the device until they are printed or saved: reading them here would drain the queue
-            # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU
-            ev = self._SGD_step(states, keys, None, sample_weights=weights, lazy=True)
+            if onecall:
+                counts, weights, ev = self._onecall_step()
+            else:
+                states, counts, probs = self.get_samples(lazy=True)
+                weights = self._sample_weights                                            # counts / sum(counts), energy.py:993
+                keys = self._sample_keys                                                  # = hilbert.state2idx(states)
+                # <E>, Var stay on the device until they are printed or saved: reading them here would drain the queue
+                # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU
+                ev = self._SGD_step(states, keys, None, sample_weights=weights, lazy=True)
             self.n_steps += 1
             self.run_time += time.time() - t0
             self._pending_log.append((self.n_steps, ev, len(weights), self.run_time))

@@ -256,6 +256,12 @@ class NAQSComplex_NADE_orbitals:
         version counters (the multi-tensor fused optimisers write through raw pointers)."""
         self._param_epoch += 1
 
+    def fused_repacked(self):
+        """The library has updated the parameters in place AND re-packed its weight layouts from them
+        (``FusedLogPsi.vmc_step``): move on to the new parameter version without packing again."""
+        self._param_epoch += 1
+        self._fused_version = self._fused_amp_version = self._param_version()
+
     def _next_sample_seed(self, generator=None):
         """One 64-bit seed per sampling call: splitmix64 of the generator's seed and a call counter."""
         base = int(generator.initial_seed()) if generator is not None else int(torch.initial_seed())

@@ -237,3 +237,32 @@ def test_fused_kernels_follow_parameter_changes(tmp_path):
     assert torch.equal(wf.fused().log_psi(keys), a)
     ref = wf.log_psi(hil.idx2state(keys)).reshape(-1, 2)
     assert torch.max(torch.abs(ref - a)).item() < 5e-5
+
+
+@pytest.mark.parametrize("mol,kw", [("N2", {}), ("LiH", dict(n_samples=100, n_unq_samples_min=20)),
+                                     ("H2O", dict(n_samples=1000000, n_unq_samples_max=120, n_unq_samples_min=5))])
+def test_one_call_training_step_equals_the_step_by_step_loop(mol, kw, tmp_path, monkeypatch, capsys):
+    """``naqs_vmc_step`` (sampling ... Adam ... re-pack in one library call) against get_samples + _SGD_step: the same
+    launches in the same order with the same seeds, so energies, sample counts and parameters agree bit for bit — also
+    through the adaptive sample count (too few unique samples: x10; tree overflow: /10) and an LR scheduler."""
+    from naqs_amd.optimizer import LogKey
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NAQS_TRAIN_ONECALL", mode)
+        z, hil, wf, opt = make_opt_gpu(mol, tmp_path / mode, scheduler=torch.optim.lr_scheduler.StepLR,
+                                       scheduler_args=dict(step_size=7, gamma=0.5), **kw)
+        assert opt._can_onecall() == (mode == "1")
+        opt.run(n_epochs=25, save_freq=None, save_final=False, output_freq=10)
+        out = capsys.readouterr().out
+        runs[mode] = dict(e=np.array(opt.log[LogKey.E_LOC]), v=np.array(opt.log[LogKey.E_LOC_VAR]),
+                          n=np.array(opt.log[LogKey.N_UNIQUE_SAMP]), p=wf.flatten_parameters().clone(), ns=opt.n_samples,
+                          t=opt.optimizer._t, lr=opt.optimizer.param_groups[0]['lr'], idx=dict(opt.sampled_idxs),
+                          msgs=[l for l in out.splitlines() if "unique samples generated" in l or "MaxBatch" in l],
+                          sd=opt.optimizer.state_dict()['state'][0]['exp_avg'].clone(), loss=float(opt.last_loss))
+    a, b = runs["1"], runs["0"]
+    assert np.array_equal(a["e"], b["e"]) and np.array_equal(a["v"], b["v"]) and np.array_equal(a["n"], b["n"])
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["sd"], b["sd"])
+    assert (a["ns"], a["t"], a["lr"], a["idx"], a["msgs"], a["loss"]) == (b["ns"], b["t"], b["lr"], b["idx"], b["msgs"], b["loss"])
+    assert a["t"] == 25 and np.isfinite(a["e"]).all()
+    if kw:
+        assert a["msgs"], "the adaptive sample count was meant to act in this case"
