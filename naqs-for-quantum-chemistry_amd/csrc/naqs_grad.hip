@@ -291,23 +291,11 @@ __global__ __launch_bounds__(256) void vmc_grad_kernel(const int64_t M, const do
     g[i] = make_float2(((float)e.x - m_re) * two_w, -(((float)e.y - m_im) * two_w));
 }
 
-// Adam (Kingma & Ba) on one flat parameter vector, torch.optim.Adam's update rule (no amsgrad):
-// m <- m + (1 - b1)(g - m); v <- b2 v + (1 - b2) g^2; p <- p - step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-__global__ __launch_bounds__(256) void adam_kernel(const int64_t n, float *__restrict__ p, const float *__restrict__ g,
-                                                   float *__restrict__ m, float *__restrict__ v, const float step_size,
-                                                   const float beta1, const float beta2, const float bc2_sqrt, const float eps,
-                                                   const float weight_decay) {
+// Adam on one flat parameter vector (naqs::adam_update, naqs_net.hpp)
+__global__ __launch_bounds__(256) void adam_kernel(const int64_t n, const float *__restrict__ g, const naqs::AdamArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float gi = g[i];
-    const float pi = p[i];
-    if (weight_decay != 0.0f) gi = fmaf(weight_decay, pi, gi);
-    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
-    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+    naqs::adam_update(a, i, g[i]);
 }
 
 // the amp kernel of naqs_logpsi.hip is reached through naqs::net_amp_forward
@@ -318,10 +306,8 @@ NAQS_API int naqs_adam_step(int64_t n, float *param_dev, const float *grad_dev, 
                             void *stream) {
     if (n < 0 || step < 1 || (n > 0 && (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev))) return NAQS_ERR_INVALID;
     if (n == 0) return NAQS_OK;
-    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, param_dev,
-                       grad_dev, exp_avg_dev, exp_avg_sq_dev, (float)(lr / bc1), (float)beta1, (float)beta2, (float)std::sqrt(bc2),
-                       (float)eps, (float)weight_decay);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, grad_dev,
+                       naqs::adam_args(param_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay, step));
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -415,17 +401,20 @@ NAQS_API int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_de
 // gradient of sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks: f = log|psi|; raw: the phase blocks
 // of an aggregate-phase network, f = phase): partial sums per workgroup, then a fixed-order reduction
 int naqs::net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const int64_t *src_off, int64_t n_block_params,
-                              int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s) {
+                              int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s,
+                              BlockReduceJob *defer, int slot) {
     if (d.Ha > 128 || (d.Ha & 15)) return NAQS_ERR_UNSUPPORTED;                 // a wave owns 16-unit hidden tiles
     if (M == 0) {
+        if (defer) return NAQS_ERR_INVALID;
         HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)n_block_params * sizeof(float), s));
         return NAQS_OK;
     }
     const int n_wg = (int)std::min<int64_t>(MAX_TILE_WGS, (M + GT - 1) / GT);
     const int64_t stride = (std::max(net->amp_params, net->ph_params) + 3) & ~3ll;
     if (!net->d_gpart) {
-        HIP_TRY(hipMalloc((void **)&net->d_gpart, (size_t)MAX_TILE_WGS * stride * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&net->d_gpart, 2 * (size_t)MAX_TILE_WGS * stride * sizeof(float)));
     }
+    float *gpart = net->d_gpart + (slot ? (size_t)MAX_TILE_WGS * stride : 0);
     const int nin_max = 2 * (d.P - 1);
     const int S_max = (nin_max + 1 + 5 + 3) & ~3;
     const int NW = d.Ha >> 4;
@@ -439,10 +428,14 @@ int naqs::net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, c
     AmpSrc src;
     for (int n = 0; n < MAXP; ++n) src.off[n] = src_off[n] - src_off[0];         // relative to this set's first parameter
     hipLaunchKernelGGL(amp_backward_kernel, dim3((unsigned)n_wg, (unsigned)d.P), dim3((unsigned)(NW * WAVE)), lds, s, d, w, M, keys_dev,
-                       g_dev, net->d_gpart, stride, src, raw);
+                       g_dev, gpart, stride, src, raw);
     HIP_TRY(hipGetLastError());
+    if (defer) {
+        defer->count = n_block_params; defer->stride = stride; defer->n_partials = n_wg; defer->partial = gpart;
+        return NAQS_OK;
+    }
     hipLaunchKernelGGL(amp_reduce_kernel, dim3((unsigned)((n_block_params + 255) / 256)), dim3(256), 0, s, n_block_params, n_wg,
-                       stride, net->d_gpart, grad_dev);
+                       stride, gpart, grad_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }

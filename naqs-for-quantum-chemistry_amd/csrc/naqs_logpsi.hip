@@ -1457,6 +1457,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_train) (void)hipFree(net->d_train);
     if (net->d_wb) (void)hipFree(net->d_wb);
     if (net->h_info) (void)hipHostFree(net->h_info);
+    if (net->d_info2) (void)hipFree(net->d_info2);
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
     if (net->side_stream) (void)hipStreamDestroy(net->side_stream);

@@ -3,6 +3,7 @@
 // (naqs_grad.hip) the orbital NADE.
 #pragma once
 #include <cstdint>
+#include <cmath>
 #include <vector>
 
 #include "naqs_common.hpp"
@@ -194,8 +195,10 @@ struct naqs_net {
     bool grad_attr_set = false;
     naqs::EventRing prof;
     char last_kernel[96] = {0};             // naqs_net_last_kernel
-    int64_t *h_info = nullptr;              // mapped host words the sampler's last launch writes (M, overflow) to
+    int64_t *h_info = nullptr;              // mapped host words the sampler publishes (M, overflow, call sequence number) to
     int64_t *d_info_alias = nullptr;        // their device address
+    int64_t *d_info2 = nullptr;             // device words for the sampler's plain (M, overflow) output of those calls
+    int64_t info_seq = 0;                   // sampling calls that published there
     hipStream_t side_stream = nullptr;      // the amplitude blocks' backward runs here, beside the phase MLP's (naqs_phase_grad.hip)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -224,8 +227,47 @@ struct WbPackJobs {
 int net_backward_pack_jobs(naqs_net *net, WbPackJobs *jobs);
 // naqs_grad.hip: d/d theta sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks, or the phase blocks of an
 // aggregate-phase network with raw = 1); grad_dev receives n_block_params floats in state_dict order
+// With `defer` the fixed-order reduction of the workgroups' partial sums is not launched but described there, for the
+// caller's one launch that finishes the whole gradient (naqs_phase_grad.hip: grad_finish_kernel); `slot` picks the half of
+// the partial-sum scratch (two block sets may be pending at once).
+struct BlockReduceJob {
+    int64_t count = 0, stride = 0;
+    int n_partials = 0;
+    const float *partial = nullptr;
+};
 int net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const int64_t *src_off, int64_t n_block_params,
-                        int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s);
+                        int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s,
+                        BlockReduceJob *defer = nullptr, int slot = 0);
+// Adam (Kingma & Ba) on element i of a flat parameter vector, torch.optim.Adam's update rule (no amsgrad):
+// m <- m + (1 - b1)(g - m); v <- b2 v + (1 - b2) g^2; p <- p - step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+struct AdamArgs {
+    float *p = nullptr, *m = nullptr, *v = nullptr;      // p == nullptr: no update
+    float step_size = 0, beta1 = 0, beta2 = 0, bc2_sqrt = 1, eps = 0, weight_decay = 0;
+};
+inline AdamArgs adam_args(float *p, float *m, float *v, double lr, double beta1, double beta2, double eps, double weight_decay,
+                          int64_t step) {
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    AdamArgs a;
+    a.p = p; a.m = m; a.v = v;
+    a.step_size = (float)(lr / bc1); a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.bc2_sqrt = (float)std::sqrt(bc2);
+    a.eps = (float)eps; a.weight_decay = (float)weight_decay;
+    return a;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void adam_update(const AdamArgs &a, const int64_t i, float gi) {
+    const float pi = a.p[i];
+    if (a.weight_decay != 0.0f) gi = fmaf(a.weight_decay, pi, gi);
+    const float mi = a.m[i] + (gi - a.m[i]) * (1.0f - a.beta1);
+    const float vi = a.beta2 * a.v[i] + (1.0f - a.beta2) * gi * gi;
+    a.m[i] = mi;
+    a.v[i] = vi;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    a.p[i] = pi - a.step_size * (mi / denom);
+}
+#endif
+// naqs_sample.hip
+int net_sample_early(naqs_net *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev, int64_t *counts_dev,
+                     float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream, int64_t *early, int64_t seq);
 // naqs_logpsi.hip: grow the [P][M] scratch and launch amp_kernel (feed == nullptr: no E_loc hand-over)
 int net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed = nullptr);
 }  // namespace naqs

@@ -12,7 +12,7 @@
 //
 //   grad_w_kernel    dW_l[n][k] = sum_i delta_l[i][n] * in_l[i][k]  (+ db_l[n] = sum_i delta_l[i][n]): 64 x 64 output
 //                    block per workgroup, the sample axis split into slices (one per blockIdx.z) whose partial
-//                    blocks are added in fixed order by grad_w_reduce_kernel -> deterministic, no float atomics.
+//                    blocks are added in fixed order by grad_finish_kernel -> deterministic, no float atomics.
 //   grad_in_kernel   delta_{l-1}[i][k] = [in_l[i][k] > 0] * sum_n delta_l[i][n] * W_l[n][k]: 64 samples x 64 columns per
 //                    workgroup, ReLU mask fused into the write-back.
 //
@@ -100,6 +100,42 @@ __global__ __launch_bounds__(256) void delta_below_top_kernel(const NetDims d, c
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = a[c] > 0.0f ? gy * w[c] : 0.0f;
     *reinterpret_cast<f32x4 *>(dout + i * Kp + k) = o;
+}
+
+// vmc_seed_kernel and delta_below_top_kernel as ONE launch (the training step's usual case: a hidden layer below the output
+// layer): thread (sample i, column quad q) forms g_i itself from (E_loc_i, w_i, sums) — the same float32 expressions, so
+// every value is the one the two launches produce — writes its four columns of the last hidden layer's delta, and the
+// first threads of a sample's row also write the output layer's delta, g_i, its amplitude component and (<E>, Var).
+__global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, const int64_t M, const uint64_t *__restrict__ keys,
+                                                             const double2 *__restrict__ eloc, const double *__restrict__ w,
+                                                             const double *__restrict__ sums, float2 *__restrict__ g,
+                                                             float *__restrict__ g_amp, float *__restrict__ delta, const int ld,
+                                                             double *__restrict__ ev, const float *__restrict__ Wtop,
+                                                             const float *__restrict__ act, const int Kp, float *__restrict__ dout) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) {
+        const double e_mean = sums[0] / sums[3];
+        ev[0] = e_mean;
+        ev[1] = sums[2] / sums[3] - e_mean * e_mean;
+    }
+    const int k4 = Kp >> 2;
+    if (e >= M * k4) return;
+    const int64_t i = e / k4;
+    const int q = (int)(e - i * k4), k = q << 2;
+    const float m_re = (float)sums[0], m_im = (float)sums[1];
+    const double2 el = eloc[i];
+    const float two_w = 2.0f * (float)w[i];
+    const float gx = ((float)el.x - m_re) * two_w, gy = -(((float)el.y - m_im) * two_w);
+    const uint64_t key = keys[i];
+    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    const f32x4 wt = *reinterpret_cast<const f32x4 *>(Wtop + (int64_t)occ * Kp + k);
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(act + i * Kp + k);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = a[c] > 0.0f ? gy * wt[c] : 0.0f;
+    *reinterpret_cast<f32x4 *>(dout + i * Kp + k) = o;
+    for (int c = q; c < ld; c += k4) delta[i * ld + c] = c == occ ? gy : 0.0f;
+    if (q == 0) { g[i] = make_float2(gx, gy); g_amp[i] = gx; }
 }
 
 // both columns of g [M][2] as contiguous vectors (aggregate-phase backward: one per set of blocks)
@@ -211,26 +247,63 @@ __global__ __launch_bounds__(256) void grad_w_kernel(const GradWJobs J, const in
     }
 }
 
-// slices -> dW_l [N][K] and db_l [N] of every layer (unpadded, state_dict layout), fixed order -> deterministic
-__global__ __launch_bounds__(256) void grad_w_reduce_kernel(const GradWJobs J, const float *__restrict__ cpart_base,
-                                                            const float *__restrict__ bpart_base, float *__restrict__ grad) {
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int job = 0;
-    while (job + 1 < J.n && e >= J.elem_end[job]) ++job;
-    if (e >= J.elem_end[job]) return;
-    if (job > 0) e -= J.elem_end[job - 1];
-    const int N = J.N[job], K = J.K[job], Np = J.Np[job], Kp = J.Kp[job], slices = J.slices[job];
-    const float *Cpart = cpart_base + J.cpart_off[job], *Bpart = bpart_base + J.bpart_off[job];
-    float *dW = grad + J.out_off[job];
+// sum_{b < n} p[b * stride], added in the order b = 0, 1, ... (the result every reduction of this file has always had), the
+// loads issued eight at a time so that the chain is not one memory round trip per term
+__device__ __forceinline__ float ordered_sum(const float *__restrict__ p, const int64_t stride, const int n) {
     float s = 0.0f;
-    if (e < (int64_t)N * K) {
-        const int n = (int)(e / K), k = (int)(e - (int64_t)n * K);
-        for (int z = 0; z < slices; ++z) s += Cpart[((int64_t)z * Np + n) * Kp + k];
-    } else {
-        const int n = (int)(e - (int64_t)N * K);
-        for (int z = 0; z < slices; ++z) s += Bpart[(int64_t)z * Np + n];
+    for (int b0 = 0; b0 < n; b0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = b0 + j < n ? p[(int64_t)(b0 + j) * stride] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (b0 + j < n) s += v[j];
     }
-    dW[e] = s;                       // db_l follows dW_l in the flat gradient: element N K + n
+    return s;
+}
+
+// The whole gradient's fixed-order reductions in ONE launch — the per-pair block sets' workgroup partials (amp_reduce_kernel's
+// sums: amplitude blocks, and the phase blocks of an aggregate-phase network) and the phase MLP's slices
+// (grad_finish_kernel's sums), element by element in the flat state_dict layout — and, when asked, Adam's update of that
+// element straight from the register (naqs_vmc_step): three launches of ~5 us each at training sizes become one.
+struct GradFinish {
+    int n_sets = 0;
+    naqs::BlockReduceJob set[2];
+    int64_t set_end[2] = {0, 0};       // running totals of the sets' elements
+    int64_t set_out[2] = {0, 0};       // where each set starts in the flat gradient
+    int64_t total = 0;                 // sets + MLP elements
+};
+__global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, const GradWJobs J, const float *__restrict__ cpart_base,
+                                                          const float *__restrict__ bpart_base, float *__restrict__ grad,
+                                                          const naqs::AdamArgs A) {
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= F.total) return;
+    const int64_t sets_total = F.n_sets > 0 ? F.set_end[F.n_sets - 1] : 0;
+    float s = 0.0f;
+    int64_t o;
+    if (e < sets_total) {
+        const int k = (F.n_sets > 1 && e >= F.set_end[0]) ? 1 : 0;
+        if (k) e -= F.set_end[0];
+        s = ordered_sum(F.set[k].partial + e, F.set[k].stride, F.set[k].n_partials);
+        o = F.set_out[k] + e;
+    } else {
+        e -= sets_total;
+        int job = 0;
+        while (job + 1 < J.n && e >= J.elem_end[job]) ++job;
+        if (job > 0) e -= J.elem_end[job - 1];
+        const int N = J.N[job], K = J.K[job], Np = J.Np[job], Kp = J.Kp[job], slices = J.slices[job];
+        const float *Cpart = cpart_base + J.cpart_off[job], *Bpart = bpart_base + J.bpart_off[job];
+        if (e < (int64_t)N * K) {
+            const int n = (int)(e / K), k = (int)(e - (int64_t)n * K);
+            s = ordered_sum(Cpart + (int64_t)n * Kp + k, (int64_t)Np * Kp, slices);
+        } else {
+            const int n = (int)(e - (int64_t)N * K);
+            s = ordered_sum(Bpart + n, Np, slices);
+        }
+        o = J.out_off[job] + e;          // db_l follows dW_l in the flat gradient: element N K + n
+    }
+    grad[o] = s;
+    if (A.p != nullptr) naqs::adam_update(A, o, s);
 }
 
 // Dout[i][k] = [In[i][k] > 0] * sum_n D[i][n] W[n][k]
@@ -447,6 +520,46 @@ NAQS_API int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64
     return naqs::eloc_main(ham, M, feed, eloc_dev, w_dev, out4_dev, s);
 }
 
+// The training step's one host synchronisation: (M, overflow) of the sampler, published to mapped host memory together with
+// the call's sequence number as soon as the last level's size is known (naqs_sample.hip: publish_info).  The host polls
+// those words instead of waiting for the stream (hipStreamSynchronize goes to sleep on the queue's completion signal after a
+// short spin; waking up costs tens of microseconds during which the GPU has nothing to do): it sees them about a
+// microsecond after the store and queues the forward pass while the sampler's last launches are still running.
+// NAQS_SPIN_WAIT=0: wait for the stream instead.
+static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                           int64_t *counts_dev, float *probs_dev, double *weights_dev, hipStream_t s, int64_t out[2]) {
+    static const bool spin = [] { const char *e = getenv("NAQS_SPIN_WAIT"); return !e || atoi(e) != 0; }();
+    if (!net->h_info) {
+        HIP_TRY(hipHostMalloc((void **)&net->h_info, 4 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
+        HIP_TRY(hipMalloc((void **)&net->d_info2, 2 * sizeof(int64_t)));
+        net->h_info[0] = net->h_info[1] = -1;
+        net->h_info[2] = 0;
+    }
+    const int64_t seq = ++net->info_seq;
+    int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info2, s,
+                                    net->d_info_alias, seq);
+    if (st != NAQS_OK) return st;
+    volatile int64_t *h = net->h_info;
+    if (spin) {
+        for (uint64_t it = 1; h[2] != seq; ++it) {
+            if ((it & 0x3FFF) == 0) {                      // every ~0.2 ms: is the stream still alive?
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return NAQS_ERR_HIP;
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (h[2] != seq) return NAQS_ERR_HIP;                   // the stream drained and nothing was published
+    out[0] = h[0];
+    out[1] = h[1];
+    return NAQS_OK;
+}
+
 NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique,
                                           uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
                                           float *logpsi_dev, double *eloc_dev, double *out4_dev, int64_t *info_dev,
@@ -457,19 +570,10 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // (M, overflow) land in host memory the sampler's last launch writes to directly (mapped, coherent): no copy launch
-    // between the sampler and the synchronisation, nothing but the synchronisation between the sampler and the forward pass
-    if (!net->h_info) {
-        HIP_TRY(hipHostMalloc((void **)&net->h_info, 2 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
-    }
-    net->h_info[0] = net->h_info[1] = -1;
-    st = naqs_net_sample_weighted(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info_alias, stream);
+    // (M, overflow) land in host memory the sampler writes to directly (mapped, coherent): no copy launch between the sampler
+    // and the synchronisation, nothing but the synchronisation between the sampler and the forward pass
+    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info_host);
     if (st != NAQS_OK) return st;
-    HIP_TRY(hipStreamSynchronize(s));                              // the step's one host synchronisation: M
-    info_host[0] = net->h_info[0];
-    info_host[1] = net->h_info[1];
-    if (info_host[0] < 0) return NAQS_ERR_HIP;                      // the launch never wrote them
     (void)info_dev;
     if (info_host[1] != 0 || info_host[0] <= 0) return NAQS_OK;
     return naqs_net_train_forward_eloc(net, ham, info_host[0], keys_dev, weights_dev, logpsi_dev, eloc_dev, out4_dev, stream);
@@ -478,8 +582,17 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
 // seeds: nullptr = g_dev holds the loss gradient (naqs_net_train_backward); else the loss gradient is formed here from
 // (E_loc, w, sums) together with its amplitude column and the output delta (naqs_net_train_backward_vmc, single-phase only)
 struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; };
+static int launch_grad_finish(const GradFinish &F, const GradWJobs &J, const float *cpart, const float *bpart, float *grad_dev,
+                              const naqs::AdamArgs *adam, hipStream_t s) {
+    hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)((F.total + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
+                       adam ? *adam : naqs::AdamArgs{});
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+// adam: nullptr = the gradient only; else the launch that finishes the gradient also applies Adam's update (naqs_vmc_step)
 static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, void *stream,
-                               const VmcSeeds *seeds) {
+                               const VmcSeeds *seeds, const naqs::AdamArgs *adam = nullptr) {
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
     if (!net->have_weights || !net->have_wb) return NAQS_ERR_INVALID;
     if (!net->aggregate && (M > net->train_cap || !net->d_train)) return NAQS_ERR_INVALID;   // naqs_net_train_forward of the same batch comes first
@@ -488,9 +601,11 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) {
+        if (adam) return NAQS_ERR_INVALID;
         HIP_TRY(hipMemsetAsync(grad_dev, 0, (size_t)net->n_params * sizeof(float), s));
         return NAQS_OK;
     }
+    GradFinish F;
     if (net->aggregate) {
         // both sets of per-pair blocks through the same backward kernel: amplitude blocks on g[:, 0], phase blocks (raw
         // outputs, no conditional) on g[:, 1]; the forward scratch ([2 P][cap] floats, free by now) holds the two columns
@@ -499,10 +614,17 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         hipLaunchKernelGGL(split_g2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, reinterpret_cast<const float2 *>(g_dev),
                            g_amp, g_ph);
         HIP_TRY(hipGetLastError());
-        st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, s);
+        st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, s,
+                                       &F.set[0], 0);
         if (st != NAQS_OK) return st;
-        return naqs::net_blocks_backward(net, net->dph, net->d_wph, net->ph_src_off, net->ph_params, M, keys_dev, g_ph,
-                                         grad_dev + net->amp_params, 1, s);
+        st = naqs::net_blocks_backward(net, net->dph, net->d_wph, net->ph_src_off, net->ph_params, M, keys_dev, g_ph,
+                                       grad_dev + net->amp_params, 1, s, &F.set[1], 1);
+        if (st != NAQS_OK) return st;
+        F.n_sets = 2;
+        F.set_end[0] = net->amp_params; F.set_end[1] = net->amp_params + net->ph_params;
+        F.set_out[0] = 0; F.set_out[1] = net->amp_params;
+        F.total = F.set_end[1];
+        return launch_grad_finish(F, GradWJobs{}, nullptr, nullptr, grad_dev, adam, s);
     }
     const NetDims &d = net->dims;
     const TrainLayout L = train_layout(net, net->train_cap);
@@ -530,7 +652,16 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0));
     }
     const int H = d.n_lin - 1;
-    if (seeds != nullptr) {
+    const bool seed_delta = seeds != nullptr && H >= 1;   // the seeds and the last hidden layer's delta from one launch
+    if (seed_delta) {
+        const int Kp = pad64(net->phase_K[(size_t)H]);
+        hipLaunchKernelGGL(vmc_seed_delta_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+                           reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
+                           g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
+                           reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]));
+        HIP_TRY(hipGetLastError());
+        if (side) { HIP_TRY(hipEventRecord(net->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0)); }
+    } else if (seeds != nullptr) {
         // (on the caller's stream, before the fork: both halves of the backward pass read what it writes)
         hipLaunchKernelGGL(vmc_seed_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
                            reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
@@ -541,8 +672,11 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
         HIP_TRY(hipGetLastError());
     }
-    st = naqs_net_amp_backward(net, M, keys_dev, g_amp, grad_dev, sa);
+    st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, sa,
+                                   &F.set[0], 0);
     if (st != NAQS_OK) return st;
+    F.n_sets = 1;
+    F.set_end[0] = net->amp_params;
     if (side) HIP_TRY(hipEventRecord(net->ev_join, sa));
 
     // phase block.  First the chain of deltas, output layer down (the critical path: each needs the one above) ...
@@ -556,6 +690,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         const int Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
         const float *in = reinterpret_cast<const float *>(base + L.act[l - 1]);
         float *dnext = reinterpret_cast<float *>(base + L.delta[l - 1]);
+        if (l == H && seed_delta) { dl[l - 1] = dnext; continue; }
         if (l == H) {                                     // below the output layer: one term per element, no GEMM
             const float2 *gsrc = seeds != nullptr ? reinterpret_cast<const float2 *>(seeds->g_out) : g2;
             hipLaunchKernelGGL(delta_below_top_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, gsrc,
@@ -595,11 +730,14 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     }
     hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(grad_w_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, J, cpart, bpart, grad_dev);
-    HIP_TRY(hipGetLastError());
-    if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the caller's stream owns the whole gradient again
-    return NAQS_OK;
+    if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the amplitude blocks' partial sums are complete
+    F.total = F.set_end[0] + elems;
+    return launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, s);
 }
+
+static int train_backward_vmc_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
+                                   const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
+                                   void *stream, const naqs::AdamArgs *adam);
 
 NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
                            int64_t m_hi, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
@@ -617,27 +755,19 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!net->have_weights) return NAQS_ERR_INVALID;
-    if (!net->h_info) {
-        HIP_TRY(hipHostMalloc((void **)&net->h_info, 2 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
-    }
-    net->h_info[0] = net->h_info[1] = -1;
-    st = naqs_net_sample_weighted(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info_alias, stream);
+    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info2);
     if (st != NAQS_OK) return st;
-    HIP_TRY(hipStreamSynchronize(s));
-    info2[0] = net->h_info[0]; info2[1] = net->h_info[1];
     info_host[0] = info2[0]; info_host[1] = info2[1];
-    if (info2[0] < 0) return NAQS_ERR_HIP;
     const int64_t M = info2[0];
     if (info2[1] != 0 || M <= 0 || M < m_lo || M > m_hi) return NAQS_OK;        // abandoned: the caller adapts n_samples
     st = naqs_net_train_forward_eloc(net, ham, M, keys_dev, weights_dev, logpsi_dev, eloc_dev, sums_dev, stream);
     if (st != NAQS_OK) return st;
-    st = naqs_net_train_backward_vmc(net, M, keys_dev, eloc_dev, weights_dev, sums_dev, g_dev, ev_dev, grad_dev, stream);
+    naqs::AdamArgs adam;
+    if (adam_step >= 1) adam = naqs::adam_args(param_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay, adam_step);
+    st = train_backward_vmc_impl(net, M, keys_dev, eloc_dev, weights_dev, sums_dev, g_dev, ev_dev, grad_dev, stream,
+                                 adam_step >= 1 ? &adam : nullptr);
     if (st != NAQS_OK) return st;
     if (adam_step >= 1) {
-        st = naqs_adam_step(net->n_params, param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay,
-                            adam_step, stream);
-        if (st != NAQS_OK) return st;
         st = naqs_net_set_weights(net, param_dev, net->n_params, stream);           // the next sampling call reads these
         if (st != NAQS_OK) return st;
     }
@@ -650,15 +780,21 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
     return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr);
 }
 
-NAQS_API int naqs_net_train_backward_vmc(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
-                                         const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
-                                         void *stream) {
+static int train_backward_vmc_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
+                                   const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
+                                   void *stream, const naqs::AdamArgs *adam) {
     if (!net || !sums_dev || !ev_dev || !g_dev || (M > 0 && (!eloc_dev || !w_dev))) return NAQS_ERR_INVALID;
     if (net->aggregate || M == 0) {                   // per-pair phase blocks (or nothing to do): the two separate calls
         int st = naqs_vmc_loss_grad_ev(M, eloc_dev, w_dev, sums_dev, g_dev, ev_dev, stream);
         if (st != NAQS_OK) return st;
-        return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr);
+        return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr, adam);
     }
     const VmcSeeds seeds{eloc_dev, w_dev, sums_dev, g_dev, ev_dev};
-    return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, &seeds);
+    return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, &seeds, adam);
+}
+
+NAQS_API int naqs_net_train_backward_vmc(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
+                                         const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
+                                         void *stream) {
+    return train_backward_vmc_impl(net, M, keys_dev, eloc_dev, w_dev, sums_dev, g_dev, ev_dev, grad_dev, stream, nullptr);
 }

@@ -64,6 +64,16 @@ __global__ void sample_init_kernel(SampleBufs b, int64_t n_samples) {
     }
 }
 
+// (M, overflow) for a host that polls mapped memory (naqs_vmc_step): system-scope stores, the call's sequence number last —
+// the host waits for ITS number, so words left by an earlier call are never mistaken for this one's.  Written as soon as the
+// size of the last level is known (the workgroup that closes the look-back chain), i.e. while the rest of that launch and the
+// weights launch are still running, and again by sample_finish_kernel (the paths that do not end in the fused level kernel).
+__device__ __forceinline__ void publish_info(int64_t *early, const int64_t M, const int64_t overflow, const int64_t seq) {
+    __hip_atomic_store(&early[0], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&early[1], overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&early[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // quad (4 consecutive lanes) sum: every lane of the quad gets the total
 __device__ __forceinline__ float quad_sum(float v) {
     v += __shfl_xor(v, 1, 64);
@@ -223,7 +233,8 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
                                                           const uint32_t k1, const uint32_t tag, const int64_t cap,
                                                           const int last, uint64_t *__restrict__ keys_out,
                                                           int64_t *__restrict__ counts_out, float *__restrict__ probs_out,
-                                                          long long *__restrict__ clk, const naqs::ushort_t *__restrict__ wamp) {
+                                                          long long *__restrict__ clk, const naqs::ushort_t *__restrict__ wamp,
+                                                          int64_t *__restrict__ early, const int64_t seq) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_wave[SB / WAVE];
     __shared__ long long s_base;
@@ -319,6 +330,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
         const int64_t all = base + total;
         b.U[n + 1] = all < cap ? all : cap;
         if (all > cap) b.U[MAXP + 1] = 1;
+        if (last && early != nullptr) publish_info(early, all > cap ? 0 : all, all > cap ? 1 : 0, seq);
     }
     SMARK(5);
 #undef SMARK
@@ -473,13 +485,15 @@ __global__ __launch_bounds__(SB) void sample_scatter_kernel(const NetDims d, con
 constexpr int FIN_THREADS = 1024;
 __global__ __launch_bounds__(FIN_THREADS) void sample_finish_kernel(SampleBufs b, int P, int64_t *__restrict__ info,
                                                                      const int64_t *__restrict__ counts,
-                                                                     double *__restrict__ weights) {
+                                                                     double *__restrict__ weights, int64_t *__restrict__ early,
+                                                                     const int64_t seq) {
     __shared__ int64_t s_part[FIN_THREADS / WAVE];
     const int64_t overflow = b.U[MAXP + 1];
     const int64_t M = overflow ? 0 : b.U[P];
     if (threadIdx.x == 0) {
         info[0] = M;
         info[1] = overflow;
+        if (early != nullptr) publish_info(early, M, overflow, seq);
     }
     if (weights == nullptr) return;
     int64_t part = 0;
@@ -499,7 +513,8 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
-                           int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream) {
+                           int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream,
+                           int64_t *early = nullptr, int64_t seq = 0) {
     if (!net || n_samples < 0 || max_unique <= 0 || !keys_dev || !counts_dev || !info_dev) return NAQS_ERR_INVALID;
     if (!net->have_amp_weights) return NAQS_ERR_INVALID;
     if (n_samples > (1ll << 44) || max_unique >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
@@ -602,7 +617,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         if (fused_levels && (int64_t)grid_e <= resident_wg) {
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
             hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
-                               keys_dev, counts_dev, probs_dev, clk_dev, wamp);
+                               keys_dev, counts_dev, probs_dev, clk_dev, wamp, early, seq);
             HIP_TRY(hipGetLastError());
         } else {
             hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, wamp);
@@ -614,7 +629,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         bound = bound > cap ? bound : bound * 4;
     }
     hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
-                       weights_dev);
+                       weights_dev, early, seq);
     HIP_TRY(hipGetLastError());
     if (clk_dev) {
         long long h[MAXP * 12];
@@ -645,6 +660,14 @@ NAQS_API int naqs_net_sample_weighted(naqs_net_t *net, int64_t n_samples, uint64
                                       void *stream) {
     if (!weights_dev) return NAQS_ERR_INVALID;
     return net_sample_impl(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, info_dev, stream);
+}
+
+// naqs_phase_grad.hip (naqs_vmc_step, naqs_vmc_sample_forward_eloc): the weighted draw whose (M, overflow, seq) also go to
+// the mapped host words `early` as early as they are known
+int naqs::net_sample_early(naqs_net *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev, int64_t *counts_dev,
+                           float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream, int64_t *early, int64_t seq) {
+    if (!weights_dev || !early) return NAQS_ERR_INVALID;
+    return net_sample_impl(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, info_dev, stream, early, seq);
 }
 
 NAQS_API int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out) {
