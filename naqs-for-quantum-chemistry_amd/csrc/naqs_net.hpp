@@ -266,6 +266,7 @@ __device__ __forceinline__ void adam_update(const AdamArgs &a, const int64_t i, 
 }
 #endif
 // naqs_sample.hip
+int net_info_alloc(naqs_net *net);
 int net_sample_early(naqs_net *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev, int64_t *counts_dev,
                      float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream, int64_t *early, int64_t seq);
 // naqs_logpsi.hip: grow the [P][M] scratch and launch amp_kernel (feed == nullptr: no E_loc hand-over)

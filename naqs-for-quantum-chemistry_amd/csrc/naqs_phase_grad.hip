@@ -529,13 +529,8 @@ NAQS_API int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64
 static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
                            int64_t *counts_dev, float *probs_dev, double *weights_dev, hipStream_t s, int64_t out[2]) {
     static const bool spin = [] { const char *e = getenv("NAQS_SPIN_WAIT"); return !e || atoi(e) != 0; }();
-    if (!net->h_info) {
-        HIP_TRY(hipHostMalloc((void **)&net->h_info, 4 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
-        HIP_TRY(hipMalloc((void **)&net->d_info2, 2 * sizeof(int64_t)));
-        net->h_info[0] = net->h_info[1] = -1;
-        net->h_info[2] = 0;
-    }
+    int st0 = naqs::net_info_alloc(net);
+    if (st0 != NAQS_OK) return st0;
     const int64_t seq = ++net->info_seq;
     int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info2, s,
                                     net->d_info_alias, seq);

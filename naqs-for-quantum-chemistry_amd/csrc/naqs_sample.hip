@@ -336,6 +336,174 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
 #undef SMARK
 }
 
+// NL (2 or 3) tree levels in ONE launch.  A level kernel lasts ~16 us whatever its size — ~5 us of launch and drain around a
+// ~10 us chain (prefix load, block MLP, two dependent binomial rounds, look-back, scatter) that only a handful of CUs take
+// part in — so a workgroup here enters with E = 64 / 4^(NL-1) prefixes of level n, expands them, compacts the children in
+// LDS (sample_head_kernel's way; at most 4 E, 16 E, ... <= 64 of them) and goes on to the next level itself; only the last
+// level of the launch is compacted across workgroups (sample_level_kernel's look-back) and written to global memory.
+// Children stay in (prefix, outcome) order at every step and a draw is keyed by its prefix, so the samples are the ones
+// every other cut of the tree into launches produces (tests/test_sampler_gpu.py).
+// The look-back word of a workgroup carries, beside the survivors of the launch's last level (9 bits), its prefix counts
+// at the intermediate levels (7 bits each): the workgroup that closes the chain then knows those levels' total sizes too
+// (U[n + 1], ...; more than `cap` prefixes alive at ANY level is the overflow the reference raises, nade.py:710-712).
+// Every workgroup adds up ALL its predecessors' words (up to 256 loads in flight per round of its first wave): fine for
+// the ~10^2..10^3 active workgroups this kernel is chosen for (the host picks NL from the previous call's level sizes,
+// net_sample_impl), slow but correct beyond.
+template <int NL>
+__global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const float *__restrict__ w, const int n,
+                                                          const SampleBufs b, const int cur, const uint32_t k0,
+                                                          const uint32_t k1, const uint32_t tag, const int64_t cap,
+                                                          const int last, uint64_t *__restrict__ keys_out,
+                                                          int64_t *__restrict__ counts_out, float *__restrict__ probs_out,
+                                                          const naqs::ushort_t *__restrict__ wamp, int64_t *__restrict__ early,
+                                                          const int64_t seq) {
+    static_assert(NL == 2 || NL == 3, "two or three levels per launch");
+    constexpr int E = 64 >> (2 * (NL - 1));
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    __shared__ uint32_t s_ab[2][64];
+    __shared__ int64_t s_cnt[2][64];
+    __shared__ float s_prob[2][64];
+    __shared__ uint32_t s_wave[SB / WAVE];
+    __shared__ long long s_base[3];
+    const int64_t U = b.U[n];
+    if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * E >= U) return;                    // workgroup-uniform
+    const int64_t nwg = (U + E - 1) / E;
+    const int tid = threadIdx.x, u = tid >> 2, lane = tid & 63, wave = tid >> 6;
+    int U_loc = (int)min((int64_t)E, U - (int64_t)blockIdx.x * E);
+    uint32_t mid_a = 0u, mid_b = 0u;                       // this workgroup's prefixes at the launch's 2nd (and 3rd) level
+    for (int li = 0; li < NL; ++li) {
+        const int lev = n + li;
+        const bool active = u < U_loc;
+        uint32_t ab = 0u;
+        int64_t cnt = 0;
+        float pr = 0.0f;
+        if (li == 0) {
+            const int64_t gu = (int64_t)blockIdx.x * E + u;
+            if (active) { ab = b.ab[cur][gu]; cnt = b.cnt[cur][gu]; pr = b.prob[cur][gu]; }
+        } else {
+            __syncthreads();                               // the previous level's children are in LDS
+            if (active) { ab = s_ab[li & 1][u]; cnt = s_cnt[li & 1][u]; pr = s_prob[li & 1][u]; }
+        }
+        if (wamp == nullptr) {
+            __syncthreads();                               // everyone done with the previous pair's rows
+            stage_pair_weights(d, w, lev, s_w, SB);
+        }
+        __syncthreads();
+        int64_t out[4];
+        float p[4];
+        expand_quad(d, s_w, lev, ab, cnt, k0, k1, out, p, nullptr, wamp);
+        const bool owner = active && (tid & 3) == 0;
+        uint32_t mine = 0;
+        if (owner)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine += out[c] > 0 ? 1u : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < SB / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
+        if (li + 1 < NL) {
+            // next level of this launch: children -> LDS, in (prefix, outcome) order
+            if (owner && mine) {
+                int pos = (int)(before + (incl - mine));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (out[c] > 0) {
+                        s_ab[(li + 1) & 1][pos] = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
+                        s_cnt[(li + 1) & 1][pos] = out[c];
+                        s_prob[(li + 1) & 1][pos] = pr * p[c];
+                        ++pos;
+                    }
+                }
+            }
+            U_loc = (int)total;
+            if (li == 0) mid_a = total; else mid_b = total;
+            continue;
+        }
+        // last level of the launch: place among the other workgroups' children (look-back over their words)
+        if (wave == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&b.wg_state[blockIdx.x],
+                                   ((unsigned long long)tag << 32) | (unsigned long long)(total | (mid_a << 9) | (mid_b << 16)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long part = 0, part_a = 0, part_b = 0;
+            for (int64_t j0 = 0; j0 < (int64_t)blockIdx.x; j0 += 4 * WAVE) {
+                unsigned long long v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t j = j0 + q * WAVE + lane;
+                    v[q] = j < (int64_t)blockIdx.x ? __hip_atomic_load(&b.wg_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                  : ((unsigned long long)tag << 32);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t j = j0 + q * WAVE + lane;
+                    while ((uint32_t)(v[q] >> 32) != tag) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v[q] = __hip_atomic_load(&b.wg_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const uint32_t x = (uint32_t)v[q];
+                    part += (long long)(x & 0x1ffu);
+                    part_a += (long long)((x >> 9) & 0x7fu);
+                    part_b += (long long)((x >> 16) & 0x7fu);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                part += __shfl_down(part, off, 64);
+                part_a += __shfl_down(part_a, off, 64);
+                part_b += __shfl_down(part_b, off, 64);
+            }
+            if (lane == 0) { s_base[0] = part; s_base[1] = part_a; s_base[2] = part_b; }
+        }
+        __syncthreads();
+        const int64_t base = s_base[0];
+        int64_t pos = base + before + (incl - mine);
+        if (owner && mine) {
+            const int nxt = (cur + NL) & 1;                // the global ping-pong half NL levels on
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (out[c] > 0) {
+                    if (pos < cap) {
+                        const uint32_t child = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
+                        const float prc = pr * p[c];
+                        if (last) {
+                            uint64_t key = 0;
+                            for (int k = 0; k < d.P; ++k) {
+                                key |= (uint64_t)((child >> k) & 1u) << d.qa[k];
+                                key |= (uint64_t)((child >> (16 + k)) & 1u) << d.qb[k];
+                            }
+                            keys_out[pos] = key;
+                            counts_out[pos] = out[c];
+                            if (probs_out) probs_out[pos] = prc;
+                        } else {
+                            b.ab[nxt][pos] = child;
+                            b.cnt[nxt][pos] = out[c];
+                            b.prob[nxt][pos] = prc;
+                        }
+                    }
+                    ++pos;
+                }
+            }
+        }
+        if ((int64_t)blockIdx.x == nwg - 1 && tid == 0) {
+            const int64_t all = base + total, all_a = s_base[1] + mid_a, all_b = NL > 2 ? s_base[2] + mid_b : 0;
+            b.U[n + 1] = all_a < cap ? all_a : cap;
+            if (NL > 2) b.U[n + 2] = all_b < cap ? all_b : cap;
+            b.U[n + NL] = all < cap ? all : cap;
+            const bool over = all > cap || all_a > cap || all_b > cap;
+            if (over) b.U[MAXP + 1] = 1;
+            if (last && early != nullptr) publish_info(early, over ? 0 : all, over ? 1 : 0, seq);
+        }
+    }
+}
+
 // The first HL levels of the tree in ONE launch: level n has at most 4^n <= HT / 4 prefixes there, so a single
 // workgroup of HT threads (a quad of lanes per prefix) expands, compacts in LDS and moves on — these levels are pure
 // latency (~30 us each as separate expand + scatter launches whatever their size).  Leaves the level-HL prefixes
@@ -486,7 +654,7 @@ constexpr int FIN_THREADS = 1024;
 __global__ __launch_bounds__(FIN_THREADS) void sample_finish_kernel(SampleBufs b, int P, int64_t *__restrict__ info,
                                                                      const int64_t *__restrict__ counts,
                                                                      double *__restrict__ weights, int64_t *__restrict__ early,
-                                                                     const int64_t seq) {
+                                                                     const int64_t seq, int64_t *__restrict__ levels_out) {
     __shared__ int64_t s_part[FIN_THREADS / WAVE];
     const int64_t overflow = b.U[MAXP + 1];
     const int64_t M = overflow ? 0 : b.U[P];
@@ -495,6 +663,9 @@ __global__ __launch_bounds__(FIN_THREADS) void sample_finish_kernel(SampleBufs b
         info[1] = overflow;
         if (early != nullptr) publish_info(early, M, overflow, seq);
     }
+    // the level sizes of this draw, for the host's choice of launches in the NEXT call (a hint: mapped memory it reads
+    // without synchronising)
+    if (levels_out != nullptr && (int)threadIdx.x <= P) levels_out[threadIdx.x] = b.U[threadIdx.x];
     if (weights == nullptr) return;
     int64_t part = 0;
     for (int64_t i = threadIdx.x; i < M; i += FIN_THREADS) part += counts[i];
@@ -512,6 +683,19 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// mapped host words the sampler's launches write: [0..2] (M, overflow, call number) for a polling host (publish_info),
+// [4 .. 4 + P] the level sizes of the last draw
+int naqs::net_info_alloc(naqs_net *net) {
+    if (net->h_info) return NAQS_OK;
+    HIP_TRY(hipHostMalloc((void **)&net->h_info, (4 + U_SLOTS) * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostGetDevicePointer((void **)&net->d_info_alias, net->h_info, 0));
+    HIP_TRY(hipMalloc((void **)&net->d_info2, 2 * sizeof(int64_t)));
+    net->h_info[0] = net->h_info[1] = -1;
+    net->h_info[2] = 0;
+    for (int i = 0; i < U_SLOTS; ++i) net->h_info[4 + i] = -1;     // no draw yet
+    return NAQS_OK;
+}
+
 static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
                            int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream,
                            int64_t *early = nullptr, int64_t seq = 0) {
@@ -524,6 +708,8 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const NetDims &d = net->dims;
     const int64_t cap = max_unique;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    st = naqs::net_info_alloc(net);
+    if (st != NAQS_OK) return st;
     // carve the scratch: 2 x (ab, cnt, prob), children counts / probs, workgroup totals, level sizes.  The layout is a
     // function of the ALLOCATION's capacity, not of this call's: calls with a smaller cap (evaluation / solve_H next to
     // training) then find the look-back words (wg_state: "tag 0 = never written, never cleared") where the allocation
@@ -540,7 +726,8 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const size_t o_cc = off; off = align_up(off + (size_t)lay * 4 * sizeof(int64_t));
     const size_t o_cp = off; off = align_up(off + (size_t)lay * 4 * sizeof(float));
     const size_t o_wg = off; off = align_up(off + (size_t)nwg_cap * sizeof(uint32_t));
-    const size_t o_ws = off; off = align_up(off + (size_t)nwg_cap * sizeof(unsigned long long));
+    const int64_t nws_cap = (lay + 3) / 4;                  // look-back words: sample_multi_kernel<3> has a workgroup per 4 prefixes
+    const size_t o_ws = off; off = align_up(off + (size_t)nws_cap * sizeof(unsigned long long));
     const size_t o_U = off; off = align_up(off + (size_t)U_SLOTS * sizeof(int64_t));
     if (cap > net->samp_cap) {
         HIP_TRY(hipDeviceSynchronize());
@@ -548,7 +735,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         net->d_samp = nullptr; net->samp_cap = 0;
         HIP_TRY(hipMalloc(&net->d_samp, off));
         // tag 0 = never written; on the call's own stream (a null-stream memset is not ordered against a non-blocking one)
-        HIP_TRY(hipMemsetAsync(static_cast<char *>(net->d_samp) + o_ws, 0, (size_t)nwg_cap * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(static_cast<char *>(net->d_samp) + o_ws, 0, (size_t)nws_cap * sizeof(unsigned long long), s));
         net->samp_cap = cap;
         net->samp_seq = 0;
     }
@@ -599,7 +786,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const bool fused_levels = naqs::env_int("NAQS_SAMPLE_FUSED", 1) == 1;
     const int64_t resident_wg = (int64_t)net->cu_count * 8;
     if (net->samp_seq >= 0x00FFFFFFu) {                    // the 24-bit call tag is about to repeat: forget every old word
-        HIP_TRY(hipMemsetAsync(b.wg_state, 0, (size_t)nwg_cap * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(b.wg_state, 0, (size_t)nws_cap * sizeof(unsigned long long), s));
         net->samp_seq = 0;
     }
     ++net->samp_seq;
@@ -608,12 +795,43 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         HIP_TRY(hipMalloc((void **)&clk_dev, MAXP * 12 * sizeof(long long)));
         HIP_TRY(hipMemset(clk_dev, 0, MAXP * 12 * sizeof(long long)));
     }
-    for (int n = n_first; n < d.P; ++n) {
-        const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
-        const int nin = n == 0 ? 1 : 2 * n;
+    // Levels per launch beyond the head: one (sample_level_kernel; or an expand and a scatter launch) unless the PREVIOUS
+    // draw's size of the level a launch would start at says that few enough workgroups will be active for
+    // sample_multi_kernel (three levels while <= 2048 prefixes enter — 512 workgroups of 4 —, two while <= 16384).  The
+    // sizes are a hint read from mapped memory without synchronising (stale, or from another cap, at worst a slower cut);
+    // the samples do not depend on the cut.  NAQS_SAMPLE_MULTI=1: always one level per launch.
+    const int multi = fused_levels ? std::min(3, std::max(1, naqs::env_int("NAQS_SAMPLE_MULTI", 3))) : 1;
+    volatile const int64_t *hint = net->h_info + 4;
+    for (int n = n_first; n < d.P;) {
+        const int left = d.P - n;
+        int nl = 1;
+        if (multi > 1 && left >= 2) {
+            const int64_t h = hint[n];
+            const int want = left == 4 ? 2 : std::min(left, 3);                  // 6 -> 3 + 3, 5 -> 3 + 2, 4 -> 2 + 2
+            if (h > 0 && h <= 2048 && want == 3 && multi >= 3) nl = 3;
+            else if (h > 0 && h <= 16384) nl = 2;
+        }
+        const int n_end = n + nl - 1;                         // last level of this launch
+        const int nin = n_end == 0 ? 1 : 2 * n_end;
         const size_t lds = wamp ? (size_t)(SB / WAVE) * mf_wave_bytes : ((size_t)d.Ha * ((nin + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+        const int last = n_end == d.P - 1 ? 1 : 0;
+        if (nl > 1) {
+            const int E = 64 >> (2 * (nl - 1));
+            const unsigned grid_m = (unsigned)((std::min(bound, cap) + E - 1) / E);
+            const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
+            if (nl == 3)
+                hipLaunchKernelGGL((sample_multi_kernel<3>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
+                                   keys_dev, counts_dev, probs_dev, wamp, early, seq);
+            else
+                hipLaunchKernelGGL((sample_multi_kernel<2>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
+                                   keys_dev, counts_dev, probs_dev, wamp, early, seq);
+            HIP_TRY(hipGetLastError());
+            for (int i = 0; i < nl; ++i) bound = bound > cap ? bound : bound * 4;
+            n += nl;
+            continue;
+        }
+        const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const unsigned grid_e = (unsigned)((std::min(bound, cap) + EXP_PARENTS - 1) / EXP_PARENTS);
-        const int last = n == d.P - 1 ? 1 : 0;
         if (fused_levels && (int64_t)grid_e <= resident_wg) {
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
             hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
@@ -627,9 +845,10 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
             HIP_TRY(hipGetLastError());
         }
         bound = bound > cap ? bound : bound * 4;
+        ++n;
     }
     hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
-                       weights_dev, early, seq);
+                       weights_dev, early, seq, net->d_info_alias + 4);
     HIP_TRY(hipGetLastError());
     if (clk_dev) {
         long long h[MAXP * 12];

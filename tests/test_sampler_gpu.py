@@ -152,19 +152,42 @@ def test_launch_fusions_change_nothing(mol, monkeypatch):
     (sample_head_kernel: five levels / 1024 threads, four / 256, or none), and a level as ONE launch (expand + compaction
     with a look-back scan across workgroups, sample_level_kernel) or as an expand and a scatter launch."""
     hil, wf, fused = _setup(mol)
+    from naqs_amd.nade import MaxBatchSizeExceededError
     outs = []
-    for head, fuse in (("2", "1"), ("1", "1"), ("0", "1"), ("2", "0"), ("0", "0")):
+    for head, fuse, multi in (("2", "1", "1"), ("1", "1", "1"), ("0", "1", "1"), ("2", "0", "1"), ("0", "0", "1"), ("1", "1", "3"),
+                              ("1", "1", "2"), ("0", "1", "3"), ("2", "1", "2")):
         monkeypatch.setenv("NAQS_SAMPLE_HEAD", head)
         monkeypatch.setenv("NAQS_SAMPLE_FUSED", fuse)
+        monkeypatch.setenv("NAQS_SAMPLE_MULTI", multi)
+        # (several levels per launch are chosen from the previous draw's level sizes: the second call is the one that takes them)
+        fused.sample(10 ** 8, seed=76, max_unique=100000)
         outs.append(fused.sample(10 ** 8, seed=77, max_unique=100000))
     assert len(outs[0][0]) > 100
     for o in outs[1:]:
         assert all(torch.equal(x, y) for x, y in zip(outs[0], o))
-    monkeypatch.setenv("NAQS_SAMPLE_HEAD", "1")
-    monkeypatch.setenv("NAQS_SAMPLE_FUSED", "1")
-    from naqs_amd.nade import MaxBatchSizeExceededError
-    with pytest.raises(MaxBatchSizeExceededError):          # (live prefixes of a level may outnumber the final samples, never the reverse)
-        fused.sample(10 ** 8, seed=77, max_unique=len(outs[0][0]) - 1)
+    # a level with more live prefixes than max_unique is an overflow whichever launch it is cut into (under partial masking an
+    # inner level may outnumber the final samples, never the reverse): same outcome at caps around the final size
+    M = len(outs[0][0])
+    for cap in (M - 1, M, M + M // 8, 2 * M):
+        res = []
+        for multi in ("1", "2", "3"):
+            monkeypatch.setenv("NAQS_SAMPLE_HEAD", "1")
+            monkeypatch.setenv("NAQS_SAMPLE_FUSED", "1")
+            monkeypatch.setenv("NAQS_SAMPLE_MULTI", multi)
+            fused.sample(10 ** 8, seed=76, max_unique=100000)
+            try:
+                res.append(fused.sample(10 ** 8, seed=77, max_unique=cap))
+            except MaxBatchSizeExceededError:
+                res.append(None)
+        assert (res[0] is None) == (res[1] is None) == (res[2] is None), cap
+        if res[0] is not None:
+            assert all(torch.equal(x, y) for r in res[1:] for x, y in zip(res[0], r))
+        if cap == M - 1:
+            assert res[0] is None
+        if cap == 2 * M and mol == "N2":
+            assert res[0] is not None
+    for k in ("NAQS_SAMPLE_HEAD", "NAQS_SAMPLE_FUSED", "NAQS_SAMPLE_MULTI"):
+        monkeypatch.delenv(k)
 
 
 def test_sampler_weights_are_counts_over_total():
