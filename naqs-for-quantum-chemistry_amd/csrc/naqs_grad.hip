@@ -20,6 +20,7 @@
 
 #include "naqs_common.hpp"
 #include "naqs_net.hpp"
+#include "naqs_amp_backward.hpp"
 
 namespace {
 
@@ -29,9 +30,9 @@ using naqs::WAVE;
 using naqs::DeviceGuard;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MAX_TILE_WGS = 64;   // workgroups per pair (each walks tiles blockIdx.x, +gridDim.x, ...)
-
-struct AmpSrc { int64_t off[MAXP]; };     // flat (state_dict) offset of pair n's parameters
+using naqs::ampbw::MAX_TILE_WGS;
+using naqs::ampbw::AmpSrc;
+using naqs::ampbw::GT;
 
 // out[i] = sum_n scratch[n][i] in the order of the fused log-psi epilogue
 __global__ __launch_bounds__(256) void logamp_sum_kernel(int P, int64_t M, const float *__restrict__ scratch,
@@ -43,196 +44,6 @@ __global__ __launch_bounds__(256) void logamp_sum_kernel(int P, int64_t M, const
     out[i] = s;
 }
 
-// one orbital pair NB: all tiles of this workgroup.  Round 3: a tile is 64 samples and the workgroup has one wave per 16
-// hidden units (Ha / 16 waves: 4 for the published 64-unit blocks, 8 for the reference's default 128) — wave q owns hidden
-// units 16 q .. 16 q + 15 in BOTH stages, lane = sample:
-//   (1) forward of its 16 units from the key bits (weights staged in LDS), partial outputs -> LDS; barrier; every wave adds
-//       the partials in fixed order, forms d log-amp / d outputs (softmax residual through the symmetrisation,
-//       nade.py:585-586) scaled by g_i, and the d pre-activations of its own units; h and d-pre go to two LDS tiles
-//       [unit][sample];
-//   (2) the sums over the tile's samples are GEMMs with the sample axis as K — dW1^T[k][j] = sum_s x[s][k] dpre[s][j] (x =
-//       +-1 from the input bits, bias = an input that is always 1), dW2[c][j] = sum_s dout[s][c] h[s][j] — on the f32 matrix
-//       cores (v_mfma_f32_16x16x4_f32), accumulators living across all tiles of the workgroup.
-// (Rounds 1-2: 256-sample tiles with thread = sample walking ALL hidden units — a serial chain of Ha LDS-fed iterations per
-// thread, twice: 37 us for the one tile a workgroup gets at M ~ 1 200, whatever the tile size, and 2 x 67 us for 128-unit
-// blocks.  Splitting the units over the waves cuts the chain by Ha / 16 and gives four times as many workgroups.)
-// smem: weights | d-pre tile [Ha][65] | h tile [Ha][65] | d-out [5][64] | input bits [64] | partial outputs [Ha/16][5][64]
-// raw: phase blocks of an aggregate-phase network (d describes them: 4 outputs, no symmetry) — the differentiated
-// quantity is the raw output of the realised outcome, d out[c] = g_i [c == occ], no conditional in between.
-constexpr int GT = 64;                                    // samples per tile = lanes of a wave
-template <int NB>
-__device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float *__restrict__ w, const int64_t M,
-                                                  const uint64_t *__restrict__ keys, const float *__restrict__ g,
-                                                  float *__restrict__ out, float *smem, const int raw) {
-    constexpr int NIN = NB == 0 ? 1 : 2 * NB;
-    constexpr int S = (NIN + 1 + 5 + 3) & ~3;
-    constexpr int RT = (NIN + 1 + 15) / 16;               // 16-row tiles of the input axis (inputs + the bias input)
-    constexpr int LD = GT + 1;
-    const int Ha = d.Ha, nout = d.n_out_amp, NW = Ha >> 4, NT = NW * WAVE;
-    const int w_floats = (Ha * S + 8 + 3) & ~3;
-    float *s_w = smem;
-    float *s_dpre = s_w + w_floats;
-    float *s_h = s_dpre + Ha * LD;
-    float *s_do = s_h + Ha * LD;                          // [5][GT]
-    uint32_t *s_x = reinterpret_cast<uint32_t *>(s_do + 5 * GT);
-    float *s_part = reinterpret_cast<float *>(s_x + GT);  // [NW][5][GT]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, kq = lane >> 4;
-    {
-        const f32x4 *from = reinterpret_cast<const f32x4 *>(w + d.amp_off[NB]);
-        f32x4 *to = reinterpret_cast<f32x4 *>(s_w);
-        for (int e = tid; e < (Ha * S + 8) / 4; e += NT) to[e] = from[e];
-    }
-    const float *b2 = s_w + Ha * S;
-    const int j0 = wave * 16;                              // this wave's hidden units
-    f32x4 acc1[RT], acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc1[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float accb2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-
-    for (int64_t t0 = (int64_t)blockIdx.x * GT; t0 < M; t0 += (int64_t)gridDim.x * GT) {
-        const int64_t i = t0 + lane;
-        const bool valid = i < M;
-        const uint64_t key = valid ? keys[i] : 0ull;
-        uint32_t abits = 0, bbits = 0;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            abits |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
-            bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
-        }
-        const int occ = (int)((key >> d.qa[NB]) & 1ull) + 2 * (int)((key >> d.qb[NB]) & 1ull);
-        const bool swap = d.sym && abits > bbits;
-        const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
-        float x[NIN];
-        if (NB == 0) {
-            x[0] = 0.0f;                                   // pair 0 sees a constant-zero input (nade.py:509-511)
-        } else {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                x[k] = ((first >> k) & 1u) ? 1.0f : -1.0f;
-                x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
-            }
-        }
-        const float gi = valid ? g[i] : 0.0f;
-        // forward of this wave's 16 hidden units; the activations go to their tile, the partial outputs to LDS
-        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int jj = j0; jj < j0 + 16; ++jj) {
-            float rv[S];
-            naqs::load_row<S>(s_w + jj * S, rv);
-            float h0 = rv[NIN], h1 = 0.0f;
-#pragma unroll
-            for (int k = 0; k + 1 < NIN; k += 2) { h0 = fmaf(rv[k], x[k], h0); h1 = fmaf(rv[k + 1], x[k + 1], h1); }
-            if (NIN & 1) h0 = fmaf(rv[NIN - 1], x[NIN - 1], h0);
-            const float h = fmaxf(h0 + h1, 0.0f);
-            s_h[jj * LD + lane] = h;
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-                if (c < nout) o[c] = fmaf(rv[NIN + 1 + c], h, o[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 5; ++c) s_part[(wave * 5 + c) * GT + lane] = o[c];
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            float v = c < nout ? b2[c] : 0.0f;
-            for (int q = 0; q < NW; ++q) v += s_part[(q * 5 + c) * GT + lane];            // fixed order: wave 0 first
-            o[c] = v;
-        }
-        float da4[4];
-        if (raw) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) da4[c] = valid && c == occ ? gi : 0.0f;
-        } else {
-            float la[4];
-            bool ok[4];
-            naqs::amp_conditional(d, NB, o, abits, bbits, la, ok);
-            // d la[occ] / d a4[c] = [c == occ] - softmax(2 a4)[c] on the allowed outcomes
-            const bool live = valid && (occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3])));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float sm = ok[c] ? expf(2.0f * la[c]) : 0.0f;
-                da4[c] = live && ok[c] ? gi * ((c == occ ? 1.0f : 0.0f) - sm) : 0.0f;
-            }
-        }
-        float dout[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (d.sym) {                                       // transpose of amp_symmetrise
-            const int x_order = abits > bbits ? 0 : (abits == bbits ? 1 : 2);
-            dout[0] = da4[0];
-            dout[2] = da4[3];
-            dout[1] = 0.5f * (da4[1] + da4[2]);
-            if (x_order == 1) dout[1] += 0.5f * (da4[1] + da4[2]);
-            else if (x_order == 0) { dout[3] = 0.5f * da4[1]; dout[4] = 0.5f * da4[2]; }
-            else { dout[4] = 0.5f * da4[1]; dout[3] = 0.5f * da4[2]; }
-        } else {
-            dout[0] = da4[0]; dout[1] = da4[1]; dout[2] = da4[2]; dout[3] = da4[3];
-        }
-        if (wave == 0) {                                   // (every wave computed the same d-out; one copy for the GEMMs)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) { s_do[c * GT + lane] = dout[c]; accb2[c] += dout[c]; }
-            s_x[lane] = (NB == 0 ? 0u : (first | (second << NB))) | (1u << NIN);   // bit NIN: the bias input
-        }
-        // d pre-activations of this wave's units -> tile (h > 0 <=> pre > 0); W2[:][jj] sits at floats NIN+1.. of the packed row
-#pragma unroll 4
-        for (int jj = j0; jj < j0 + 16; ++jj) {
-            const float *row = s_w + jj * S + NIN + 1;
-            float dh = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-                if (c < nout) dh = fmaf(row[c], dout[c], dh);
-            s_dpre[jj * LD + lane] = s_h[jj * LD + lane] > 0.0f ? dh : 0.0f;
-        }
-        __syncthreads();
-        // sums over the tile's samples on the matrix cores: hidden tile ct = wave
-        {
-            const float *bd = s_dpre + (j0 + m) * LD + kq, *bh = s_h + (j0 + m) * LD + kq;
-            const float *ad = s_do + m * GT + kq;
-#pragma unroll 4
-            for (int s0 = 0; s0 < GT; s0 += 4) {
-                const uint32_t xb = s_x[s0 + kq];
-                const float vd = bd[s0], vh = bh[s0];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const int k = rt * 16 + m;
-                    const float a = k <= NIN ? (((xb >> k) & 1u) ? 1.0f : -1.0f) : 0.0f;
-                    acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vd, acc1[rt], 0, 0, 0);
-                }
-                const float a2 = m < 5 ? ad[s0] : 0.0f;
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, vh, acc2, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // partial sums of this workgroup in state_dict order: W1 [Ha][NIN], b1 [Ha], W2 [nout][Ha], b2 [nout]
-    {
-        const int j = j0 + m;                               // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + r
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = rt * 16 + 4 * kq + r;
-                if (k < NIN) out[j * NIN + k] = NB == 0 ? 0.0f : acc1[rt][r];
-                else if (k == NIN) out[Ha * NIN + j] = acc1[rt][r];
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 4 * kq + r;
-            if (c < nout) out[Ha * NIN + Ha + c * Ha + j] = acc2[r];
-        }
-    }
-    // db2[c] = sum over this workgroup's samples of d-out[c] (wave 0 holds them)
-    if (wave == 0) {
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            float v = accb2[c];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && c < nout) out[Ha * NIN + Ha + nout * Ha + c] = v;
-        }
-    }
-}
-
 __global__ __launch_bounds__(512) void amp_backward_kernel(const NetDims d, const float *__restrict__ w, const int64_t M,
                                                            const uint64_t *__restrict__ keys, const float *__restrict__ g,
                                                            float *__restrict__ partial, const int64_t partial_stride,
@@ -240,13 +51,7 @@ __global__ __launch_bounds__(512) void amp_backward_kernel(const NetDims d, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = blockIdx.y;
     float *out = partial + (int64_t)blockIdx.x * partial_stride + src.off[n];
-    switch (n) {
-#define CASE(NB) case NB: amp_backward_pair<NB>(d, w, M, keys, g, out, smem, raw); break;
-        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
-        CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
-#undef CASE
-        default: break;
-    }
+    naqs::ampbw::pair_dispatch(n, d, w, M, keys, g, out, smem, raw, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void amp_reduce_kernel(int64_t count, int n_partials, int64_t partial_stride,
@@ -415,10 +220,8 @@ int naqs::net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, c
         HIP_TRY(hipMalloc((void **)&net->d_gpart, 2 * (size_t)MAX_TILE_WGS * stride * sizeof(float)));
     }
     float *gpart = net->d_gpart + (slot ? (size_t)MAX_TILE_WGS * stride : 0);
-    const int nin_max = 2 * (d.P - 1);
-    const int S_max = (nin_max + 1 + 5 + 3) & ~3;
     const int NW = d.Ha >> 4;
-    const size_t lds = ((size_t)((d.Ha * S_max + 8 + 3) & ~3) + 2 * (size_t)d.Ha * (GT + 1) + 5 * GT + GT + (size_t)NW * 5 * GT) * sizeof(float);
+    const size_t lds = naqs::ampbw::smem_floats(d) * sizeof(float);
     if (lds > 156 * 1024) return NAQS_ERR_UNSUPPORTED;
     if (!net->grad_attr_set) {
         const int lds_max = 156 * 1024;
@@ -437,6 +240,23 @@ int naqs::net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, c
     hipLaunchKernelGGL(amp_reduce_kernel, dim3((unsigned)((n_block_params + 255) / 256)), dim3(256), 0, s, n_block_params, n_wg,
                        stride, gpart, grad_dev);
     HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
+// what net_blocks_backward would launch, for a caller that runs the workgroups inside a launch of its own
+// (naqs_phase_grad.hip: backward_mega_kernel): the partial-sum scratch (allocated on first use), the reduction it needs
+// afterwards and the pairs' offsets
+int naqs::net_blocks_backward_plan(naqs_net *net, const NetDims &d, const int64_t *src_off, int64_t n_block_params, int64_t M, int slot,
+                                   BlockReduceJob *job, naqs::ampbw::AmpSrc *src) {
+    if (d.Ha > 128 || (d.Ha & 15) || M <= 0 || !job || !src) return NAQS_ERR_INVALID;
+    const int n_wg = (int)std::min<int64_t>(MAX_TILE_WGS, (M + GT - 1) / GT);
+    const int64_t stride = (std::max(net->amp_params, net->ph_params) + 3) & ~3ll;
+    if (!net->d_gpart) {
+        HIP_TRY(hipMalloc((void **)&net->d_gpart, 2 * (size_t)MAX_TILE_WGS * stride * sizeof(float)));
+    }
+    job->count = n_block_params; job->stride = stride; job->n_partials = n_wg;
+    job->partial = net->d_gpart + (slot ? (size_t)MAX_TILE_WGS * stride : 0);
+    for (int n = 0; n < MAXP; ++n) src->off[n] = src_off[n] - src_off[0];
     return NAQS_OK;
 }
 

@@ -238,6 +238,9 @@ struct BlockReduceJob {
 int net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const int64_t *src_off, int64_t n_block_params,
                         int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, int raw, hipStream_t s,
                         BlockReduceJob *defer = nullptr, int slot = 0);
+namespace ampbw { struct AmpSrc; }
+int net_blocks_backward_plan(naqs_net *net, const NetDims &d, const int64_t *src_off, int64_t n_block_params, int64_t M, int slot,
+                             BlockReduceJob *job, ampbw::AmpSrc *src);
 // Adam (Kingma & Ba) on element i of a flat parameter vector, torch.optim.Adam's update rule (no amsgrad):
 // m <- m + (1 - b1)(g - m); v <- b2 v + (1 - b2) g^2; p <- p - step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 struct AdamArgs {

@@ -26,6 +26,7 @@
 #include "naqs_common.hpp"
 #include "naqs_hash.hpp"
 #include "naqs_net.hpp"
+#include "naqs_amp_backward.hpp"
 
 namespace {
 
@@ -164,11 +165,10 @@ struct GradWJobs {
     int64_t elem_end[MAXL];         // running total of N K + N (reduce kernel)
 };
 
-__global__ __launch_bounds__(256) void grad_w_kernel(const GradWJobs J, const int64_t M, float *__restrict__ cpart_base,
-                                                     float *__restrict__ bpart_base) {
-    __shared__ __attribute__((aligned(16))) float Ps[CH * LDT];
-    __shared__ __attribute__((aligned(16))) float Qs[CH * LDT];
-    int job = 0, bid = blockIdx.x;
+// (bid: the block's index among ALL jobs' blocks; Ps, Qs: [CH * LDT] floats of LDS each)
+__device__ __forceinline__ void grad_w_body(const GradWJobs &J, const int64_t M, float *__restrict__ cpart_base,
+                                            float *__restrict__ bpart_base, int bid, float *Ps, float *Qs) {
+    int job = 0;
     while (job + 1 < J.n && bid >= J.block_end[job]) ++job;
     if (job > 0) bid -= J.block_end[job - 1];
     const int Np = J.Np[job], Kp = J.Kp[job], nbn = Np / TB, nbk = Kp / TB;
@@ -247,6 +247,14 @@ __global__ __launch_bounds__(256) void grad_w_kernel(const GradWJobs J, const in
     }
 }
 
+// bid0: index of the launch's first block among all jobs' blocks (the launch may cover a sub-range of the jobs)
+__global__ __launch_bounds__(256) void grad_w_kernel(const GradWJobs J, const int64_t M, float *__restrict__ cpart_base,
+                                                     float *__restrict__ bpart_base, const int bid0) {
+    __shared__ __attribute__((aligned(16))) float Ps[CH * LDT];
+    __shared__ __attribute__((aligned(16))) float Qs[CH * LDT];
+    grad_w_body(J, M, cpart_base, bpart_base, bid0 + (int)blockIdx.x, Ps, Qs);
+}
+
 // sum_{b < n} p[b * stride], added in the order b = 0, 1, ... (the result every reduction of this file has always had), the
 // loads issued eight at a time so that the chain is not one memory round trip per term
 __device__ __forceinline__ float ordered_sum(const float *__restrict__ p, const int64_t stride, const int n) {
@@ -307,13 +315,12 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, co
 }
 
 // Dout[i][k] = [In[i][k] > 0] * sum_n D[i][n] W[n][k]
-__global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ D, const float *__restrict__ W,
-                                                      const float *__restrict__ In, const int64_t M, const int Np, const int Kp,
-                                                      float *__restrict__ Dout) {
-    __shared__ __attribute__((aligned(16))) float Ds[TB * LDD];
-    __shared__ __attribute__((aligned(16))) float Ws[CH * LDT];
-    const int64_t i0 = (int64_t)blockIdx.x * TB;
-    const int k0 = blockIdx.y * TB;
+// (bx, by: sample tile and column tile; Ds: [TB * LDD], Ws: [CH * LDT] floats of LDS)
+__device__ __forceinline__ void grad_in_body(const float *__restrict__ D, const float *__restrict__ W,
+                                             const float *__restrict__ In, const int64_t M, const int Np, const int Kp,
+                                             float *__restrict__ Dout, const int bx, const int by, float *Ds, float *Ws) {
+    const int64_t i0 = (int64_t)bx * TB;
+    const int k0 = by * TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wk = wave & 1, lm = lane & 15, lq = lane >> 4;
     f32x4 acc[2][2];
@@ -375,6 +382,52 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
                 const int k = k0 + wk * 32 + tk * 16 + lm;
                 if (i < M) Dout[i * Kp + k] = In[i * Kp + k] > 0.0f ? acc[ti][tk][r] : 0.0f;
             }
+}
+
+__global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ D, const float *__restrict__ W,
+                                                      const float *__restrict__ In, const int64_t M, const int Np, const int Kp,
+                                                      float *__restrict__ Dout) {
+    __shared__ __attribute__((aligned(16))) float Ds[TB * LDD];
+    __shared__ __attribute__((aligned(16))) float Ws[CH * LDT];
+    grad_in_body(D, W, In, M, Np, Kp, Dout, (int)blockIdx.x, (int)blockIdx.y, Ds, Ws);
+}
+
+// The three independent pieces of the backward pass below the seeds, as ONE launch (the training step's usual network: two
+// hidden phase layers, 64-unit amplitude blocks): blocks [0, n_gin) are grad_in_kernel's (the first hidden layer's delta),
+// the next n_amp amp_backward_kernel's (workgroup x pair) and the rest grad_w_kernel's for the layers whose deltas exist
+// already (all but the first: its delta is what the grad_in blocks are producing; that job gets its own small launch
+// afterwards).  Each piece alone leaves most of the chip idle (240 / 300 / 630 workgroups of a 15-18 us latency chain);
+// together they take about as long as the longest.  Same device functions, same operands: same numbers.
+struct MegaArgs {
+    int n_gin, gin_tiles_i, n_amp, amp_wgs;
+    const float *D, *W, *In;
+    float *Dout;
+    int Np, Kp;
+    int64_t M;
+    float *cpart, *bpart;
+    int gw_bid0;
+    const float *amp_w, *g_amp;
+    const uint64_t *keys;
+    float *amp_partial;
+    int64_t amp_stride;
+};
+__global__ __launch_bounds__(256) void backward_mega_kernel(const MegaArgs A, const NetDims d, const GradWJobs J,
+                                                            const naqs::ampbw::AmpSrc src) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    if (bid < A.n_gin) {
+        grad_in_body(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD);
+        return;
+    }
+    bid -= A.n_gin;
+    if (bid < A.n_amp) {
+        const int wg = bid % A.amp_wgs, n = bid / A.amp_wgs;
+        naqs::ampbw::pair_dispatch(n, d, A.amp_w, A.M, A.keys, A.g_amp, A.amp_partial + (int64_t)wg * A.amp_stride + src.off[n], smem, 0,
+                                   wg, A.amp_wgs);
+        return;
+    }
+    bid -= A.n_amp;
+    grad_w_body(J, A.M, A.cpart, A.bpart, A.gw_bid0 + bid, smem, smem + CH * LDT);
 }
 
 struct TrainLayout {            // carve-up of net->d_train for `cap` rows
@@ -667,8 +720,12 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
         HIP_TRY(hipGetLastError());
     }
-    st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, sa,
-                                   &F.set[0], 0);
+    // NAQS_TRAIN_MEGA=0: every piece its own launch
+    const bool mega = H == 2 && d.Ha == 64 && !side && naqs::env_int("NAQS_TRAIN_MEGA", 1) == 1;
+    naqs::ampbw::AmpSrc amp_src{};
+    if (mega) st = naqs::net_blocks_backward_plan(net, net->dims, net->amp_src_off, net->amp_params, M, 0, &F.set[0], &amp_src);
+    else st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, sa,
+                                        &F.set[0], 0);
     if (st != NAQS_OK) return st;
     F.n_sets = 1;
     F.set_end[0] = net->amp_params;
@@ -681,6 +738,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     }
     const float *dl[MAXL];                            // delta of linear layer l's output
     dl[H] = top;
+    MegaArgs A{};
     for (int l = H; l > 0; --l) {
         const int Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
         const float *in = reinterpret_cast<const float *>(base + L.act[l - 1]);
@@ -691,6 +749,12 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
             hipLaunchKernelGGL(delta_below_top_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, gsrc,
                                net->d_wb + wb_offset(net, l), in, Kp, dnext);
             HIP_TRY(hipGetLastError());
+            dl[l - 1] = dnext;
+            continue;
+        }
+        if (mega) {                                       // (l == 1 here: part of the one launch below)
+            A.n_gin = (int)((M + TB - 1) / TB) * (Kp / TB); A.gin_tiles_i = (int)((M + TB - 1) / TB);
+            A.D = dl[l]; A.W = net->d_wb + wb_offset(net, l); A.In = in; A.Dout = dnext; A.Np = Np; A.Kp = Kp;
             dl[l - 1] = dnext;
             continue;
         }
@@ -723,8 +787,22 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         elems += (int64_t)N * K + N;
         J.elem_end[l] = elems;
     }
-    hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart);
-    HIP_TRY(hipGetLastError());
+    if (mega) {
+        A.M = M; A.cpart = cpart; A.bpart = bpart; A.gw_bid0 = J.block_end[0];
+        A.amp_wgs = F.set[0].n_partials; A.n_amp = A.amp_wgs * d.P;
+        A.amp_w = net->d_w; A.g_amp = g_amp; A.keys = keys_dev;
+        A.amp_partial = const_cast<float *>(F.set[0].partial); A.amp_stride = F.set[0].stride;
+        const size_t lds = std::max(naqs::ampbw::smem_floats(d), (size_t)(TB * LDD + CH * LDT)) * sizeof(float);
+        if (lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(backward_mega_kernel, dim3((unsigned)(A.n_gin + A.n_amp + blocks_total - J.block_end[0])), dim3(256), lds, s,
+                           A, d, J, amp_src);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, s, J, M, cpart, bpart, 0);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart, 0);
+        HIP_TRY(hipGetLastError());
+    }
     if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the amplitude blocks' partial sums are complete
     F.total = F.set_end[0] + elems;
     return launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, s);

@@ -374,3 +374,28 @@ def test_fused_step_calls_equal_their_parts():
     c = float((k2.sum() & 0xFFFFF).item())
     want = torch.cat([sums2, torch.tensor([len(k2), len(k2) ** 2, c, c * c], dtype=torch.float64, device="cuda")])
     assert torch.equal(ext, want)
+
+
+@pytest.mark.parametrize("mol,n_samples", [("N2", 10 ** 6), ("N2", 300), ("LiH", 10 ** 5)])
+def test_backward_as_one_launch_equals_its_pieces(mol, n_samples, monkeypatch):
+    """backward_mega_kernel (grad_in + amplitude blocks + the upper layers' weight gradients in one launch) runs the device
+    functions of the separate launches on the same operands: every gradient element bit for bit."""
+    from test_nade import make_wf
+    z = golden(f"nade_{mol}.npz")
+    hil, wf = make_wf(mol, z, device="cuda")
+    fused = wf.fused()
+    keys, counts, probs = fused.sample(n_samples, 5, 100000)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    g = torch.randn((len(keys), 2), device="cuda", generator=gen) / len(keys)
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NAQS_TRAIN_MEGA", mode)
+        for p in wf.model.parameters():
+            p.grad = None
+        fused._grad_flat = None
+        lp, saved = fused.forward_saved(keys)
+        fused.backward_saved(saved, g)
+        torch.cuda.synchronize()
+        grads[mode] = torch.cat([p.grad.reshape(-1) for p in wf.model.parameters()]).clone()
+        assert fused.last_kernel() is not None
+    assert torch.equal(grads["1"], grads["0"]) and float(grads["1"].abs().max()) > 0
