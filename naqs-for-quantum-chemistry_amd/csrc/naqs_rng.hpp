@@ -198,11 +198,40 @@ NAQS_HD int64_t binomial(int64_t n, double p, RngStream &g) {
 // uniform log call for every lane), the k-term and the mode's — are evaluated by different lanes at once (a quad: one log
 // call deep; a pair: two) and exchanged, and the test is assembled with the arithmetic of btrs_attempt.  Attempts
 // behind an accepted one are never tested.
+// Lane jj of every group of G consecutive lanes (G = 4: quads, G = 2: the two pairs of a quad), broadcast to the group: a
+// DPP quad_perm move — one VALU instruction per 32 bits, where __shfl goes through the LDS crossbar (ds_bpermute, ~100
+// cycles of latency on a chain with nothing else to overlap it; the generator has ~30 of them per draw).
+template <int CTRL>
+__device__ __forceinline__ int dpp_quad(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int G>
+__device__ __forceinline__ int group_bcast(int v, int jj) {
+    if (G == 4) {
+        switch (jj & 3) {                                 // quad_perm [jj, jj, jj, jj]
+            case 0: return dpp_quad<0x00>(v);
+            case 1: return dpp_quad<0x55>(v);
+            case 2: return dpp_quad<0xAA>(v);
+            default: return dpp_quad<0xFF>(v);
+        }
+    }
+    return (jj & 1) ? dpp_quad<0xF5>(v) : dpp_quad<0xA0>(v);   // quad_perm [1, 1, 3, 3] / [0, 0, 2, 2]
+}
+template <int G>
+__device__ __forceinline__ double group_bcast(double v, int jj) {
+    return __hiloint2double(group_bcast<G>(__double2hiint(v), jj), group_bcast<G>(__double2loint(v), jj));
+}
+template <int G>
+__device__ __forceinline__ int64_t group_bcast(int64_t v, int jj) {
+    const int lo = group_bcast<G>((int)(uint32_t)v, jj), hi = group_bcast<G>((int)(uint32_t)((uint64_t)v >> 32), jj);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 template <int G>
 __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, const double p, const uint32_t k0,
                                                   const uint32_t k1, const uint32_t c0, const uint32_t c1) {
     static_assert(G == 2 || G == 4, "a pair or a quad");
-    const int lane = threadIdx.x & 63, j = lane & (G - 1), base = lane & ~(G - 1);
+    const int lane = threadIdx.x & 63, j = lane & (G - 1);
     int64_t fixed = 0;
     if (need && (n <= 0 || !(p > 0.0))) need = false;
     if (need && p >= 1.0) { fixed = n; need = false; }
@@ -232,12 +261,11 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
         }
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {                        // the group's attempts, in attempt order
-            const int src = base + jj;
-            int cls_j = __shfl(cls, src, 64);
+            int cls_j = group_bcast<G>(cls, jj);
             const bool exact = pending && cls_j == 1;           // uniform within a group
             if (__ballot(exact) != 0ull) {
                 if (exact) {
-                    const double us_j = __shfl(us, src, 64), v_j = __shfl(v, src, 64), k_j = __shfl(kk, src, 64);
+                    const double us_j = group_bcast<G>(us, jj), v_j = group_bcast<G>(v, jj), k_j = group_bcast<G>(kk, jj);
                     const double alpha = (2.83 + 5.1 * t.rb) * t.spq;
                     const double r = t.p * rcp_fast(1.0 - t.p);
                     // arguments of the four logarithms; term 1 (log1p) goes through log(1 + x) with Kahan's correction
@@ -250,11 +278,11 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
                     if (G == 4) {
                         const double mine = log(j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)));
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) T[q] = __shfl(mine, base + q, 64);
+                        for (int q = 0; q < 4; ++q) T[q] = group_bcast<4>(mine, q);
                     } else {
                         const double m0 = log(j == 0 ? a0 : a1), m1 = log(j == 0 ? a2 : a3);
-                        T[0] = __shfl(m0, base, 64); T[1] = __shfl(m0, base + 1, 64);
-                        T[2] = __shfl(m1, base, 64); T[3] = __shfl(m1, base + 1, 64);
+                        T[0] = group_bcast<2>(m0, 0); T[1] = group_bcast<2>(m0, 1);
+                        T[2] = group_bcast<2>(m1, 0); T[3] = group_bcast<2>(m1, 1);
                     }
                     const double l1p = a1 == 1.0 ? x1 : T[1] * x1 * rcp_fast(a1 - 1.0);      // log1p(x1)
                     const double h_m = (t.m + 0.5) * T[3] + stirling_tail(t.m) + stirling_tail(t.n - t.m);
@@ -264,7 +292,7 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
                 }
             }
             if (pending && cls_j == 0) {
-                k = __shfl(kk, src, 64);
+                k = group_bcast<G>(kk, jj);
                 pending = false;
             }
         }

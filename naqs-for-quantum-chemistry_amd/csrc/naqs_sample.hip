@@ -76,8 +76,8 @@ __device__ __forceinline__ void publish_info(int64_t *early, const int64_t M, co
 
 // quad (4 consecutive lanes) sum: every lane of the quad gets the total
 __device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
+    v += __int_as_float(naqs::dpp_quad<0xB1>(__float_as_int(v)));      // quad_perm [1, 0, 3, 2]: lane ^ 1
+    v += __int_as_float(naqs::dpp_quad<0x4E>(__float_as_int(v)));      // quad_perm [2, 3, 0, 1]: lane ^ 2
     return v;
 }
 
@@ -163,9 +163,8 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
     const double den = sub == 0 ? p01 : p23, num = sub == 0 ? (double)p[1] : (double)p[3];
     const int64_t hi_sub = binomial_group<2>(den > 0.0, m_sub, fmin(1.0, num / den), k0, k1, ab,
                                              (uint32_t)n | ((uint32_t)(2 + sub) << 8));
-    const int quad0 = (int)(threadIdx.x & 63) & ~3;
-    const int64_t hi = __shfl(hi_sub, quad0, 64);
-    const int64_t n3 = __shfl(hi_sub, quad0 + 2, 64);
+    const int64_t hi = naqs::group_bcast<4>(hi_sub, 0);
+    const int64_t n3 = naqs::group_bcast<4>(hi_sub, 2);
     out[0] = n01 - hi; out[1] = hi; out[2] = n23 - n3; out[3] = n3;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -797,10 +796,11 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     }
     // Levels per launch beyond the head: one (sample_level_kernel; or an expand and a scatter launch) unless the PREVIOUS
     // draw's size of the level a launch would start at says that few enough workgroups will be active for
-    // sample_multi_kernel (three levels while <= 2048 prefixes enter — 512 workgroups of 4 —, two while <= 16384).  The
+    // sample_multi_kernel (three levels while <= 2048 prefixes enter — 512 workgroups of 4 —, two while <= 8192; measured: 4096 / 16384 is 25 us slower per N2 step).  The
     // sizes are a hint read from mapped memory without synchronising (stale, or from another cap, at worst a slower cut);
     // the samples do not depend on the cut.  NAQS_SAMPLE_MULTI=1: always one level per launch.
     const int multi = fused_levels ? std::min(3, std::max(1, naqs::env_int("NAQS_SAMPLE_MULTI", 3))) : 1;
+    const int64_t multi3_max = naqs::env_int("NAQS_SAMPLE_MULTI3_MAX", 2048);
     volatile const int64_t *hint = net->h_info + 4;
     for (int n = n_first; n < d.P;) {
         const int left = d.P - n;
@@ -808,8 +808,8 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         if (multi > 1 && left >= 2) {
             const int64_t h = hint[n];
             const int want = left == 4 ? 2 : std::min(left, 3);                  // 6 -> 3 + 3, 5 -> 3 + 2, 4 -> 2 + 2
-            if (h > 0 && h <= 2048 && want == 3 && multi >= 3) nl = 3;
-            else if (h > 0 && h <= 16384) nl = 2;
+            if (h > 0 && h <= multi3_max && want == 3 && multi >= 3) nl = 3;
+            else if (h > 0 && h <= 4 * multi3_max) nl = 2;
         }
         const int n_end = n + nl - 1;                         // last level of this launch
         const int nin = n_end == 0 ? 1 : 2 * n_end;
