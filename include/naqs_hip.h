@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 4
+#define NAQS_ABI_VERSION 5
 
 typedef struct naqs_ham naqs_ham_t;
 

@@ -398,6 +398,8 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
 // already (all but the first: its delta is what the grad_in blocks are producing; that job gets its own small launch
 // afterwards).  Each piece alone leaves most of the chip idle (240 / 300 / 630 workgroups of a 15-18 us latency chain);
 // together they take about as long as the longest.  Same device functions, same operands: same numbers.
+// (Measured and rejected: the first layer's blocks inside this launch too, waiting on a device-scope count of the finished
+// grad_in blocks — the fences and the polling cost 12-18 us per step more than the 7 us launch they replace.)
 struct MegaArgs {
     int n_gin, gin_tiles_i, n_amp, amp_wgs;
     const float *D, *W, *In;
