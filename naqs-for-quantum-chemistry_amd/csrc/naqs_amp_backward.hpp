@@ -40,7 +40,7 @@ template <int NB>
 __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float *__restrict__ w, const int64_t M,
                                                   const uint64_t *__restrict__ keys, const float *__restrict__ g,
                                                   float *__restrict__ out, float *smem, const int raw, const int wg,
-                                                  const int n_wgs) {
+                                                  const int n_wgs, const int g_stride) {
     constexpr int NIN = NB == 0 ? 1 : 2 * NB;
     constexpr int S = (NIN + 1 + 5 + 3) & ~3;
     constexpr int RT = (NIN + 1 + 15) / 16;               // 16-row tiles of the input axis (inputs + the bias input)
@@ -90,7 +90,7 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
                 x[NB + k] = ((second >> k) & 1u) ? 1.0f : -1.0f;
             }
         }
-        const float gi = valid ? g[i] : 0.0f;
+        const float gi = valid ? g[i * g_stride] : 0.0f;      // (g_stride 2: a column of the loss gradient [M][2])
         // forward of this wave's 16 hidden units; the activations go to their tile, the partial outputs to LDS
         float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
@@ -222,9 +222,9 @@ inline size_t smem_floats(const NetDims &d) {
 // all pairs: the switch over the compile-time pair index
 __device__ __forceinline__ void pair_dispatch(const int n, const NetDims &d, const float *__restrict__ w, const int64_t M,
                                               const uint64_t *__restrict__ keys, const float *__restrict__ g, float *__restrict__ out,
-                                              float *smem, const int raw, const int wg, const int n_wgs) {
+                                              float *smem, const int raw, const int wg, const int n_wgs, const int g_stride = 1) {
     switch (n) {
-#define NAQS_CASE(NB) case NB: amp_backward_pair<NB>(d, w, M, keys, g, out, smem, raw, wg, n_wgs); break;
+#define NAQS_CASE(NB) case NB: amp_backward_pair<NB>(d, w, M, keys, g, out, smem, raw, wg, n_wgs, g_stride); break;
         NAQS_CASE(0) NAQS_CASE(1) NAQS_CASE(2) NAQS_CASE(3) NAQS_CASE(4) NAQS_CASE(5) NAQS_CASE(6) NAQS_CASE(7)
         NAQS_CASE(8) NAQS_CASE(9) NAQS_CASE(10) NAQS_CASE(11) NAQS_CASE(12) NAQS_CASE(13) NAQS_CASE(14) NAQS_CASE(15)
 #undef NAQS_CASE

@@ -54,6 +54,26 @@ __global__ __launch_bounds__(512) void amp_backward_kernel(const NetDims d, cons
     naqs::ampbw::pair_dispatch(n, d, w, M, keys, g, out, smem, raw, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// aggregate_phase: the amplitude blocks (blockIdx.z == 0, on g[:, 0]) and the per-pair phase blocks (1, raw, on g[:, 1]) in ONE
+// launch; the loss gradient's two columns are read in place (stride 2), no split launch in front
+// (the two sets' descriptions are separate kernel arguments: nested in a struct their dynamically indexed tables end up in
+// scratch memory — measured 2x slower than two launches)
+__global__ __launch_bounds__(512) void amp_backward2_kernel(const NetDims d0, const float *__restrict__ w0, float *__restrict__ partial0,
+                                                            const AmpSrc src0, const NetDims d1, const float *__restrict__ w1,
+                                                            float *__restrict__ partial1, const AmpSrc src1, const int64_t M,
+                                                            const uint64_t *__restrict__ keys, const float *__restrict__ g_amp,
+                                                            const float *__restrict__ g_ph, const int64_t partial_stride,
+                                                            const int g_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockIdx.y;
+    if (blockIdx.z == 0)
+        naqs::ampbw::pair_dispatch(n, d0, w0, M, keys, g_amp, partial0 + (int64_t)blockIdx.x * partial_stride + src0.off[n], smem, 0,
+                                   (int)blockIdx.x, (int)gridDim.x, g_stride);
+    else
+        naqs::ampbw::pair_dispatch(n, d1, w1, M, keys, g_ph, partial1 + (int64_t)blockIdx.x * partial_stride + src1.off[n], smem, 1,
+                                   (int)blockIdx.x, (int)gridDim.x, g_stride);
+}
+
 __global__ __launch_bounds__(256) void amp_reduce_kernel(int64_t count, int n_partials, int64_t partial_stride,
                                                          const float *__restrict__ partial, float *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -257,6 +277,30 @@ int naqs::net_blocks_backward_plan(naqs_net *net, const NetDims &d, const int64_
     job->count = n_block_params; job->stride = stride; job->n_partials = n_wg;
     job->partial = net->d_gpart + (slot ? (size_t)MAX_TILE_WGS * stride : 0);
     for (int n = 0; n < MAXP; ++n) src->off[n] = src_off[n] - src_off[0];
+    return NAQS_OK;
+}
+
+// both block sets of an aggregate-phase network in one launch (same hidden width and pair count); the reductions are left
+// to the caller like net_blocks_backward's with `defer`
+int naqs::net_blocks_backward2(naqs_net *net, int64_t M, const uint64_t *keys_dev, const float *g_amp, const float *g_ph, int g_stride,
+                               BlockReduceJob jobs[2], hipStream_t s) {
+    const NetDims &d0 = net->dims, &d1 = net->dph;
+    if (d0.Ha != d1.Ha || d0.P != d1.P || M <= 0) return NAQS_ERR_INVALID;
+    AmpSrc src0, src1;
+    int st = net_blocks_backward_plan(net, d0, net->amp_src_off, net->amp_params, M, 0, &jobs[0], &src0);
+    if (st != NAQS_OK) return st;
+    st = net_blocks_backward_plan(net, d1, net->ph_src_off, net->ph_params, M, 1, &jobs[1], &src1);
+    if (st != NAQS_OK) return st;
+    const size_t lds = std::max(naqs::ampbw::smem_floats(d0), naqs::ampbw::smem_floats(d1)) * sizeof(float);
+    if (lds > 156 * 1024) return NAQS_ERR_UNSUPPORTED;
+    if (!net->grad2_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        net->grad2_attr_set = true;
+    }
+    hipLaunchKernelGGL(amp_backward2_kernel, dim3((unsigned)jobs[0].n_partials, (unsigned)d0.P, 2), dim3((unsigned)((d0.Ha >> 4) * WAVE)), lds, s,
+                       d0, net->d_w, const_cast<float *>(jobs[0].partial), src0, d1, net->d_wph, const_cast<float *>(jobs[1].partial), src1, M,
+                       keys_dev, g_amp, g_ph, jobs[0].stride, g_stride);
+    HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
 

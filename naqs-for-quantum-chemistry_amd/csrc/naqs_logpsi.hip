@@ -64,14 +64,11 @@ constexpr int AMP_SPLIT = NAQS_AMP_SPLIT;   // waves splitting the hidden units 
 // staged once, wave (t, q) runs hidden-unit slice q for the 64 samples of tile t, the AMP_SPLIT partial
 // outputs of a tile meet in LDS in fixed order.  (The kernel is latency-bound: splitting the hidden units
 // over more waves was measured 2x faster than giving each wave all of them.)
-__global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w,
-                                                                           int64_t M, const uint64_t *__restrict__ keys,
-                                                                           float *__restrict__ scratch, const ElocFeed feed,
-                                                                           const int raw) {
+__device__ __forceinline__ void amp_body(const NetDims &d, const float *__restrict__ w, int64_t M,
+                                         const uint64_t *__restrict__ keys, float *__restrict__ scratch, const ElocFeed &feed,
+                                         const int raw, float (*s_part)[AMP_SPLIT][5][WAVE], float *s_w) {
     // raw: the blocks are phase blocks (aggregate_phase; d describes them: 4 outputs, no symmetry): the output of the
     // realised outcome goes to scratch as it is (nade.py:556-569) instead of through the conditional
-    __shared__ float s_part[AMP_TILES][AMP_SPLIT][5][WAVE];
-    extern __shared__ __attribute__((aligned(16))) float s_w[];   // this pair's packed rows + b2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = wave / AMP_SPLIT, q = wave % AMP_SPLIT;
     const int n = blockIdx.y;            // workgroup-uniform
@@ -128,6 +125,28 @@ __global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const
         scratch[(int64_t)n * M + i] = raw ? (occ == 0 ? t[0] : (occ == 1 ? t[1] : (occ == 2 ? t[2] : t[3])))
                                           : amp_finish(d, n, t, abits, bbits, occ);
     }
+}
+
+__global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp_kernel(const NetDims d, const float *__restrict__ w,
+                                                                           int64_t M, const uint64_t *__restrict__ keys,
+                                                                           float *__restrict__ scratch, const ElocFeed feed,
+                                                                           const int raw) {
+    __shared__ float s_part[AMP_TILES][AMP_SPLIT][5][WAVE];
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // this pair's packed rows + b2
+    amp_body(d, w, M, keys, scratch, feed, raw, s_part, s_w);
+}
+
+// aggregate_phase: the amplitude blocks (blockIdx.z == 0) and the per-pair phase blocks (1, raw) of the same batch in ONE
+// launch — two latency-bound launches of P workgroup columns each otherwise
+__global__ __launch_bounds__(AMP_TILES * AMP_SPLIT * WAVE) void amp2_kernel(const NetDims d0, const float *__restrict__ w0,
+                                                                            float *__restrict__ scratch0, const ElocFeed feed,
+                                                                            const NetDims d1, const float *__restrict__ w1,
+                                                                            float *__restrict__ scratch1, int64_t M,
+                                                                            const uint64_t *__restrict__ keys) {
+    __shared__ float s_part[AMP_TILES][AMP_SPLIT][5][WAVE];
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    if (blockIdx.z == 0) amp_body(d0, w0, M, keys, scratch0, feed, 0, s_part, s_w);
+    else { const ElocFeed none{}; amp_body(d1, w1, M, keys, scratch1, none, 1, s_part, s_w); }
 }
 
 // aggregate_phase epilogue: (log|psi|, phase) = (sum_n conditional log-amplitudes, sum_n phases), pair 0 first (the
@@ -1218,6 +1237,13 @@ __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__
                                                        float *__restrict__ w) {
     pack_amp_body(flat, d, so, w, blockIdx.y);
 }
+// aggregate_phase: both sets of per-pair blocks (blockIdx.z)
+__global__ __launch_bounds__(256) void pack_amp2_kernel(const float *__restrict__ flat, const NetDims d0, const AmpSrcOff so0,
+                                                        float *__restrict__ w0, const NetDims d1, const AmpSrcOff so1,
+                                                        float *__restrict__ w1) {
+    if (blockIdx.z == 0) pack_amp_body(flat, d0, so0, w0, blockIdx.y);
+    else pack_amp_body(flat, d1, so1, w1, blockIdx.y);
+}
 
 __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
                                                float *__restrict__ Wd, float *__restrict__ bd) {
@@ -1536,10 +1562,20 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     const NetDims &d = net->dims;
     net->have_weights = net->have_amp_weights = net->have_wb = false;
     if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack
-        st = pack_amp_blocks(net, flat_dev, s);
-        if (st != NAQS_OK) return st;
-        st = pack_blocks(net->dph, net->ph_src_off, net->d_wph, flat_dev, s);
-        if (st != NAQS_OK) return st;
+        if (net->dims.P == net->dph.P && (naqs::env_int("NAQS_AGG_MERGE", 7) & 4)) {
+            AmpSrcOff so0, so1;
+            for (int n = 0; n < MAXP; ++n) { so0.off[n] = net->amp_src_off[n]; so1.off[n] = net->ph_src_off[n]; }
+            const int total_max = std::max(d.Ha, net->dph.Ha) * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;
+            net->wamp_fresh = false;
+            hipLaunchKernelGGL(pack_amp2_kernel, dim3((total_max + 255) / 256, d.P, 2), dim3(256), 0, s, flat_dev, d, so0, net->d_w, net->dph, so1,
+                               net->d_wph);
+            HIP_TRY(hipGetLastError());
+        } else {
+            st = pack_amp_blocks(net, flat_dev, s);
+            if (st != NAQS_OK) return st;
+            st = pack_blocks(net->dph, net->ph_src_off, net->d_wph, flat_dev, s);
+            if (st != NAQS_OK) return st;
+        }
         st = pack_amp_fragments(net, flat_dev, s);
         if (st != NAQS_OK) return st;
         net->have_weights = net->have_amp_weights = net->have_wb = true;
@@ -1594,7 +1630,7 @@ static int launch_amp_kernel(const NetDims &d, const float *w, int64_t M, const 
     return NAQS_OK;
 }
 
-int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed) {
+int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed, bool launch) {
     const NetDims &d = net->dims;
     if (M >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
     if (M > net->cap_M) {
@@ -1606,6 +1642,7 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
         HIP_TRY(hipMalloc((void **)&net->d_scratch, (size_t)cap * d.P * (net->aggregate ? 2 : 1) * sizeof(float)));
         net->cap_M = cap;
     }
+    if (!launch) return NAQS_OK;
     const ElocFeed none{};
     if (net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) != 0) {      // matrix-core form (0: the VALU amp_kernel)
         const int64_t waves = (M + AMPK_TG * 16 - 1) / (AMPK_TG * 16) * d.P;
@@ -1621,15 +1658,30 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
 
 // aggregate_phase: amplitude blocks, phase blocks (raw), then the sums
 static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, hipStream_t s, const ElocFeed &feed) {
-    int st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
-    if (st != NAQS_OK) return st;
-    float *s_ph = net->d_scratch + (size_t)net->dims.P * net->cap_M;
-    const ElocFeed none{};
+    const bool mfma_amp = net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) != 0;
     const bool prof = net->prof.armed();
-    if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
-    st = launch_amp_kernel(net->dph, net->d_wph, M, keys_dev, s_ph, none, 1, s);
-    if (st != NAQS_OK) return st;
-    if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
+    int st;
+    float *s_ph;
+    if (!mfma_amp && !prof && net->dims.P == net->dph.P && (naqs::env_int("NAQS_AGG_MERGE", 7) & 1)) {
+        st = naqs::net_amp_forward(net, M, keys_dev, s, nullptr, /*launch=*/false);          // (the scratch only)
+        if (st != NAQS_OK) return st;
+        s_ph = net->d_scratch + (size_t)net->dims.P * net->cap_M;
+        const NetDims &d0 = net->dims, &d1 = net->dph;
+        const size_t lds = ((size_t)std::max(d0.Ha, d1.Ha) * ((2 * (d0.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
+        if (lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(amp2_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d0.P, 2),
+                           dim3(AMP_TILES * AMP_SPLIT * WAVE), lds, s, d0, net->d_w, net->d_scratch, feed, d1, net->d_wph, s_ph, M, keys_dev);
+        HIP_TRY(hipGetLastError());
+    } else {
+        st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
+        if (st != NAQS_OK) return st;
+        s_ph = net->d_scratch + (size_t)net->dims.P * net->cap_M;
+        const ElocFeed none{};
+        if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
+        st = launch_amp_kernel(net->dph, net->d_wph, M, keys_dev, s_ph, none, 1, s);
+        if (st != NAQS_OK) return st;
+        if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
+    }
     hipLaunchKernelGGL(agg_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch, s_ph,
                        reinterpret_cast<float2 *>(logpsi_dev), feed);
     HIP_TRY(hipGetLastError());

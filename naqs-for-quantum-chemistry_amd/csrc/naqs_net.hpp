@@ -192,7 +192,7 @@ struct naqs_net {
     int64_t train_cap = 0;                  // rows the training scratch holds
     float *d_wb = nullptr;                  // phase weights row-major [N_pad64][K_pad64] per layer (backward GEMMs)
     bool have_wb = false;
-    bool grad_attr_set = false;
+    bool grad_attr_set = false, grad2_attr_set = false;
     naqs::EventRing prof;
     char last_kernel[96] = {0};             // naqs_net_last_kernel
     int64_t *h_info = nullptr;              // mapped host words the sampler publishes (M, overflow, call sequence number) to
@@ -241,6 +241,8 @@ int net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, const i
 namespace ampbw { struct AmpSrc; }
 int net_blocks_backward_plan(naqs_net *net, const NetDims &d, const int64_t *src_off, int64_t n_block_params, int64_t M, int slot,
                              BlockReduceJob *job, ampbw::AmpSrc *src);
+int net_blocks_backward2(naqs_net *net, int64_t M, const uint64_t *keys_dev, const float *g_amp, const float *g_ph, int g_stride,
+                         BlockReduceJob jobs[2], hipStream_t s);
 // Adam (Kingma & Ba) on element i of a flat parameter vector, torch.optim.Adam's update rule (no amsgrad):
 // m <- m + (1 - b1)(g - m); v <- b2 v + (1 - b2) g^2; p <- p - step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 struct AdamArgs {
@@ -273,5 +275,6 @@ int net_info_alloc(naqs_net *net);
 int net_sample_early(naqs_net *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev, int64_t *counts_dev,
                      float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream, int64_t *early, int64_t seq);
 // naqs_logpsi.hip: grow the [P][M] scratch and launch amp_kernel (feed == nullptr: no E_loc hand-over)
-int net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed = nullptr);
+int net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hipStream_t s, const ElocFeed *feed = nullptr,
+                    bool launch = true);      // launch = false: only grow the scratch
 }  // namespace naqs

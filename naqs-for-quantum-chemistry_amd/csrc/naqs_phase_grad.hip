@@ -660,16 +660,22 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         // both sets of per-pair blocks through the same backward kernel: amplitude blocks on g[:, 0], phase blocks (raw
         // outputs, no conditional) on g[:, 1]; the forward scratch ([2 P][cap] floats, free by now) holds the two columns
         if (M > net->cap_M || !net->d_scratch) return NAQS_ERR_INVALID;
-        float *g_amp = net->d_scratch, *g_ph = net->d_scratch + M;
-        hipLaunchKernelGGL(split_g2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, reinterpret_cast<const float2 *>(g_dev),
-                           g_amp, g_ph);
-        HIP_TRY(hipGetLastError());
-        st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, s,
-                                       &F.set[0], 0);
-        if (st != NAQS_OK) return st;
-        st = naqs::net_blocks_backward(net, net->dph, net->d_wph, net->ph_src_off, net->ph_params, M, keys_dev, g_ph,
-                                       grad_dev + net->amp_params, 1, s, &F.set[1], 1);
-        if (st != NAQS_OK) return st;
+        if (net->dims.Ha == net->dph.Ha && net->dims.P == net->dph.P && (naqs::env_int("NAQS_AGG_MERGE", 7) & 2)) {
+            // one launch for both sets, the two columns of g read where they are
+            st = naqs::net_blocks_backward2(net, M, keys_dev, g_dev, g_dev + 1, 2, F.set, s);
+            if (st != NAQS_OK) return st;
+        } else {
+            float *g_amp = net->d_scratch, *g_ph = net->d_scratch + M;
+            hipLaunchKernelGGL(split_g2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, reinterpret_cast<const float2 *>(g_dev),
+                               g_amp, g_ph);
+            HIP_TRY(hipGetLastError());
+            st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, s,
+                                           &F.set[0], 0);
+            if (st != NAQS_OK) return st;
+            st = naqs::net_blocks_backward(net, net->dph, net->d_wph, net->ph_src_off, net->ph_params, M, keys_dev, g_ph,
+                                           grad_dev + net->amp_params, 1, s, &F.set[1], 1);
+            if (st != NAQS_OK) return st;
+        }
         F.n_sets = 2;
         F.set_end[0] = net->amp_params; F.set_end[1] = net->amp_params + net->ph_params;
         F.set_out[0] = 0; F.set_out[1] = net->amp_params;

@@ -331,3 +331,30 @@ def test_sampler_with_wide_blocks_matches_psi_squared():
     m = expect >= 5
     chi2 = ((obs[m] - expect[m]) ** 2 / expect[m]).sum()
     assert stats.chi2.sf(chi2, m.sum()) > 1e-4, (chi2, m.sum())
+
+
+@pytest.mark.parametrize("fix", ["LiH_aggphase", "N2_aggphase"])
+def test_aggregate_phase_merged_launches_equal_separate_ones(fix, monkeypatch):
+    """aggregate_phase networks run their two sets of per-pair blocks (amplitude, phase) as ONE launch each way (forward,
+    backward, re-pack): same device functions on the same operands -> log psi and every gradient element bit for bit."""
+    mol, z, hil, wf = _wf(fix)
+    keys = torch.as_tensor(z["samp_keys"].astype(np.int64), device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g = torch.randn((len(keys), 2), device="cuda", generator=gen) / len(keys)
+    out = {}
+    for mode in ("7", "0"):
+        monkeypatch.setenv("NAQS_AGG_MERGE", mode)
+        fused = wf.fused()
+        assert fused.aggregate
+        fused.refresh()
+        for p in wf.model.parameters():
+            p.grad = None
+        fused._grad_flat = None
+        lp = fused.log_psi(keys).clone()
+        lp_t, saved = fused.forward_saved(keys)
+        fused.backward_saved(saved, g)
+        torch.cuda.synchronize()
+        out[mode] = (lp, lp_t.clone(), torch.cat([p.grad.reshape(-1) for p in wf.model.parameters()]).clone())
+    for a, b in zip(out["7"], out["0"]):
+        assert torch.equal(a, b)
+    assert float(out["7"][2].abs().max()) > 0
