@@ -8,6 +8,9 @@ cp $G/prof_serial/bench_kernel_stats.csv $P/${ROUND}_bench_n2_10k_kernel_stats_s
 cp $G/prof_li2o/bench_kernel_stats.csv $P/${ROUND}_bench_li2o_50k_rowshard_kernel_stats.csv
 cp $G/prof_train/train_kernel_stats.csv $P/${ROUND}_train_step_n2_kernel_stats.csv
 cp $G/train_step_timing.txt $P/${ROUND}_train_step_timing.txt
+cp $G/step_timeline_train.txt $P/${ROUND}_train_step_n2_timeline.txt
+cp $G/step_timeline_train_h2o.txt $P/${ROUND}_train_step_h2o_timeline.txt
+cp $G/train_onecall_ab.txt $P/${ROUND}_train_step_onecall_ab.txt
 cp $G/train_scaling_n2.json $P/${ROUND}_train_step_scaling_model.json
 cp $G/source_hash.txt $P/${ROUND}_library_source_hash.txt
 tail -4 $G/pytest.log > $P/${ROUND}_gpu_test_suite.txt; tail -2 $G/smoke.log >> $P/${ROUND}_gpu_test_suite.txt

@@ -30,7 +30,12 @@ PMC="$ISSUE" pmc pmc_issue_li2o $L
 PMC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" pmc pmc_wait_n2 $B
 PMC="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" pmc pmc_mfma_n2 $B
 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_train -o train -- python3 $R/tools/train_loop_profile.py > $G/prof_train.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $G/prof_train_h2o -o train -- python3 $R/tools/train_loop_profile.py $R/tests/golden/ham_H2O.npz 1000000 300 40 > $G/prof_train_h2o.log 2>&1
 cd $R
+# per-step timelines (launch order, kernel time, idle gap after each kernel) of the one-call training step
+for t in train train_h2o; do python3 tools/step_timeline.py $G/prof_$t/train_kernel_trace.csv > $G/step_timeline_$t.txt 2>&1; done
+# the one-call step against the call-by-call loop, interleaved on this box
+( bash tools/train_ab.sh tests/golden/ham_N2.npz NAQS_TRAIN_ONECALL=1 NAQS_TRAIN_ONECALL=0; bash tools/train_ab.sh tests/golden/ham_H2O.npz NAQS_TRAIN_ONECALL=1 NAQS_TRAIN_ONECALL=0 ) > $G/train_onecall_ab.txt 2>&1
 for m in N2 H2O Li2O; do python tools/train_loop_profile.py tests/golden/ham_$m.npz >> $G/train_step_timing.txt 2>&1; done
 NAQS_PROFILE_DEFAULT_ANSATZ=1 python tools/train_loop_profile.py >> $G/train_step_timing.txt 2>&1
 cd naqs-for-quantum-chemistry_amd
