@@ -389,7 +389,7 @@ class FusedLogPsi:
         return k, counts[:m], probs[:m], weights[:m], (log_psi[:m], (k, None, None), eloc[:m], sums)
 
     @torch.no_grad()
-    def vmc_step(self, ham, n_samples, seed, max_unique, m_lo, m_hi, adam=None):
+    def vmc_step(self, ham, n_samples, seed, max_unique, m_lo, m_hi, adam=None, keys_out=None):
         """One whole VMC training step as ONE library call (``naqs_vmc_step``): sampling, the host's look at (M, overflow),
         forward + E_loc, loss gradient + backward, Adam on the flat parameter vector and the re-pack of the kernels' weight
         layouts — the interpreter is not on the GPU's critical path between the first and the last launch of the step.
@@ -399,7 +399,10 @@ class FusedLogPsi:
         sums, g, ev)) — the tensors are views of length M (None when not taken)."""
         cap = int(max_unique)
         dev = self.device
-        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        # keys_out: where the sampler writes the keys (int64 [>= cap], contiguous; e.g. the caller's tracking buffer)
+        keys = keys_out if keys_out is not None else torch.empty(cap, dtype=torch.int64, device=dev)
+        if keys.dtype != torch.int64 or keys.numel() < cap or not keys.is_contiguous():
+            raise ValueError("vmc_step: keys_out must be a contiguous int64 tensor of at least max_unique elements")
         counts = torch.empty(cap, dtype=torch.int64, device=dev)
         probs = torch.empty(cap, dtype=torch.float32, device=dev)
         weights = torch.empty(cap, dtype=torch.float64, device=dev)

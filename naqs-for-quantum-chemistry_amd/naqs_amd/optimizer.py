@@ -148,7 +148,35 @@ class OptimizerBase:
         self.reset_optimizer()
 
     # how often each basis state has appeared as a unique sample (reference: a Counter updated every step)
+    def _track_sampled(self, keys):
+        """energy.py:300 (a Counter updated every step), deferred: the step's keys stay on the device and are folded into the
+        Counter when it is looked at, or once 2^25 of them (268 MB) are waiting.  Folding is a data-dependent-size operation
+        (torch.unique), i.e. a host synchronisation plus a sort: every 256 steps it was ~0.05 ms per step of a 0.28 ms step."""
+        if keys.numel() and keys.untyped_storage().nbytes() > 32 * keys.numel():
+            keys = keys.clone()                  # (a view would pin its whole max_unique-sized buffer until the next fold)
+        self._sampled_pending.append(keys)
+        self._sampled_pending_n = getattr(self, "_sampled_pending_n", 0) + int(keys.shape[0])
+        if self._sampled_pending_n >= (1 << 25) or len(self._sampled_pending) >= (1 << 16):
+            self._flush_sampled_idxs()
+
+    def _sampled_ring_slot(self, cap):
+        """The one-call step lets the sampler write its keys straight into the tracking buffer: -> a view of `cap` elements
+        at the buffer's write offset (folding the buffer first when the slot would not fit)."""
+        ring = getattr(self, "_sampled_ring", None)
+        if ring is None or ring.numel() < 2 * cap:
+            self._flush_sampled_idxs()
+            ring = self._sampled_ring = torch.empty(max(1 << 25, 2 * cap), dtype=torch.int64, device=self.device)
+            self._sampled_ring_off = 0
+        if self._sampled_ring_off + cap > ring.numel():
+            self._flush_sampled_idxs()
+        return ring[self._sampled_ring_off:self._sampled_ring_off + cap]
+
     def _flush_sampled_idxs(self):
+        self._sampled_pending_n = 0
+        off = getattr(self, "_sampled_ring_off", 0)
+        if off:
+            self._sampled_pending.append(self._sampled_ring[:off])
+            self._sampled_ring_off = 0
         if self._sampled_pending:
             k, c = torch.unique(torch.cat(self._sampled_pending), return_counts=True)
             self._sampled_pending = []
@@ -162,6 +190,7 @@ class OptimizerBase:
     @sampled_idxs.setter
     def sampled_idxs(self, value):
         self._sampled_idxs, self._sampled_pending = Counter(value), []
+        self._sampled_ring_off = self._sampled_pending_n = 0
 
     @property
     def last_loss(self):
@@ -322,9 +351,7 @@ class OptimizerBase:
         keys = keys_to_device(states_idx, self.device)
         M = keys.shape[0]
         if self.track_sampled_idxs:          # energy.py:300; folded into the Counter in batches (no per-step sync)
-            self._sampled_pending.append(keys)
-            if len(self._sampled_pending) >= 256:
-                self._flush_sampled_idxs()
+            self._track_sampled(keys)
         # shard of rows this rank owns (the whole table when single-process)
         b, e_ = shard_bounds(M, rank, world)
         saved = None
@@ -580,8 +607,9 @@ class PartialSamplingOptimizer(OptimizerBase):
             free = (self.n_samples != self.n_unq_samples_min) and (self.n_samples != self.n_samples_max)
             m_lo = self.n_unq_samples_min if (free and last_action >= 0) else 0
             seed = wf._next_sample_seed(self.generator)
+            slot = self._sampled_ring_slot(int(self.n_unq_samples_max)) if self.track_sampled_idxs else None
             taken, n_unq, overflow, out = fused.vmc_step(self.pauli_hamiltonian, self.n_samples, seed, self.n_unq_samples_max,
-                                                          m_lo, self.n_unq_samples_max, adam=self.optimizer)
+                                                          m_lo, self.n_unq_samples_max, adam=self.optimizer, keys_out=slot)
             if taken:
                 break
             action = 0
@@ -606,9 +634,7 @@ class PartialSamplingOptimizer(OptimizerBase):
         wf.fused_repacked()
         self._sample_keys, self._sample_weights, self._prefused = keys, weights, None
         if self.track_sampled_idxs:
-            self._sampled_pending.append(keys)
-            if len(self._sampled_pending) >= 256:
-                self._flush_sampled_idxs()
+            self._sampled_ring_off += int(keys.shape[0])       # the keys are in the tracking buffer already (energy.py:300)
         self._loss_terms, self._last_loss = (g, lp), None
         if self.scheduler is not None:
             self.scheduler.step()
