@@ -83,6 +83,81 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 using naqs::binomial_group;
 
+// raw outputs of block n for one prefix -> the float32 conditional probabilities p[c] = exp(log-amp)^2 (nade.py:673) and
+// the electron-budget mask of the four outcomes (nade.py:695)
+__device__ __forceinline__ void probs_from_outputs(const NetDims &d, const int n, const float (&t)[5], const uint32_t abits,
+                                                   const uint32_t bbits, float (&p)[4], bool (&phys)[4]) {
+    float la[4];
+    bool ok[4];
+    naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
+    naqs::amp_budget_mask(d, n, abits, bbits, phys);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float e = ok[c] ? expf(la[c]) : 0.0f;
+        p[c] = e * e;
+    }
+}
+
+__device__ __forceinline__ void split_quad(const int n, const uint32_t ab, const int64_t cnt, const uint32_t k0, const uint32_t k1,
+                                           const float (&p)[4], const bool (&phys)[4], int64_t (&out)[4], long long *clk);
+
+// Matrix-core mode: a block's MLP depends on the prefix bits only, not on the counts, so the kernels that run several levels
+// per launch let their idle waves evaluate every possible descendant ("candidate") of the launch's entry prefixes while
+// wave 0 is in the binomial rounds of a level that fits it; the later levels then start from the probabilities.  Same
+// item, same arithmetic as expand_quad's: the same bits.
+//
+// The schedule: items of 16 candidates (one matrix-core item of one wave), level n + 1 first; item j runs in pass
+// min(its level - 1, j / (n_waves - 1)) on wave 1 + j % (n_waves - 1) — at most one item per wave and pass while the list is
+// short enough (five items in three levels from four entries; six in the four-level head), same-level items of a wave
+// sharing one fetch of the pair's fragments.  Candidate ci of level n + lj is entry ci >> 2 lj followed by the outcomes
+// (ci >> 2 (lj - 1)) & 3, ..., ci & 3; its probabilities go to cp[(lj - 1) * 64 + ci] (float4) and its physical mask to
+// cphys[...] (bit c) — at most 64 candidates per level by construction (E * 4^lj <= 64).
+template <int CT>
+__device__ __forceinline__ void cand_jobs_t(const NetDims &d, const naqs::ushort_t *__restrict__ wamp, const int n, const int LV,
+                                            const int E, const int entries, const uint32_t *s_entry, float *outs, f32x4 *cp,
+                                            uint8_t *cphys, const int wave, const int n_waves, const int pass) {
+    const int lane = threadIdx.x & 63;
+    naqs::AmpFrag<CT> f;
+    int have = -1, job = 0;
+    for (int lj = 1; lj < LV; ++lj) {
+        const int items = ((E << (2 * lj)) + 15) >> 4;            // (the last item of a short level carries unused candidates)
+        for (int it = 0; it < items; ++it, ++job) {
+            if (min(lj - 1, job / (n_waves - 1)) != pass || job % (n_waves - 1) != wave - 1) continue;
+            if (((it * 16) >> (2 * lj)) >= entries) continue;     // all 16 candidates descend from absent entries
+            const int ci = it * 16 + (lane & 15);
+            const int e = ci >> (2 * lj);
+            uint32_t ab16 = e < entries ? s_entry[e] : 0u;
+            for (int k = 0; k < lj; ++k) {
+                const uint32_t c = (uint32_t)(ci >> (2 * (lj - 1 - k))) & 3u;
+                ab16 |= ((c & 1u) << (n + k)) | ((c >> 1) << (16 + n + k));
+            }
+            const int lev = n + lj;
+            if (have != lev) { naqs::amp_mfma_load<CT>(wamp + (size_t)lev * naqs::amp_mfma_pair_elems(CT * 16), lane, f); have = lev; }
+            naqs::amp_mfma_item<CT>(d, f, lev, ab16, lane, outs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 16) {
+                float t[5], p[4];
+                bool phys[4];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) t[c] = outs[lane * 8 + c];
+                probs_from_outputs(d, lev, t, ab16 & 0xffffu, ab16 >> 16, p, phys);
+                cp[(lj - 1) * 64 + ci] = (f32x4){p[0], p[1], p[2], p[3]};
+                cphys[(lj - 1) * 64 + ci] = (uint8_t)((phys[0] ? 1 : 0) | (phys[1] ? 2 : 0) | (phys[2] ? 4 : 0) | (phys[3] ? 8 : 0));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+__device__ __forceinline__ void cand_jobs(const NetDims &d, const naqs::ushort_t *__restrict__ wamp, const int n, const int LV,
+                                          const int E, const int entries, const uint32_t *s_entry, float *outs, f32x4 *cp,
+                                          uint8_t *cphys, const int wave, const int n_waves, const int pass) {
+    if (d.Ha == 64) cand_jobs_t<4>(d, wamp, n, LV, E, entries, s_entry, outs, cp, cphys, wave, n_waves, pass);
+    else cand_jobs_t<2>(d, wamp, n, LV, E, entries, s_entry, outs, cp, cphys, wave, n_waves, pass);
+}
+
 // One prefix, one quad of lanes (q = lane & 3): the hidden units of block n are split four ways, then the quad draws the
 // first-level binomial of the multinomial split together and its two halves the two independent second-level ones.  Weights of pair n are in s_w (staged and
 // synchronised by the caller).  On return lane q == 0 holds the children counts (un-physical ones zeroed, nade.py:695)
@@ -139,19 +214,19 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
 #pragma unroll
         for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + quad_sum(o[c]);
     }
-    float la[4];
-    bool ok[4], phys[4];
-    naqs::amp_conditional(d, n, t, abits, bbits, la, ok);
-    naqs::amp_budget_mask(d, n, abits, bbits, phys);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float e = ok[c] ? expf(la[c]) : 0.0f;
-        p[c] = e * e;
-    }
+    bool phys[4];
+    probs_from_outputs(d, n, t, abits, bbits, p, phys);
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[1] = clock64();     // conditional + probabilities done
+    split_quad(n, ab, cnt, k0, k1, p, phys, out, clk);
+}
+
+// the second half of expand_quad: the count's multinomial split given the conditional probabilities and the physical mask
+__device__ __forceinline__ void split_quad(const int n, const uint32_t ab, const int64_t cnt, const uint32_t k0, const uint32_t k1,
+                                           const float (&p)[4], const bool (&phys)[4], int64_t (&out)[4], long long *clk) {
+    const int q = threadIdx.x & 3;
     // multinomial(count; p) as a binary tree of binomials (same distribution as the reference's conditional chain,
     // nade.py:31-35, two dependent rounds instead of three; the float64 renormalisation of :682-683 cancels in the
     // ratios): first {2,3} against {0,1}, then 1 within {0,1} and 3 within {2,3}
-    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[1] = clock64();     // conditional + probabilities done
     const double p01 = (double)p[0] + (double)p[1], p23 = (double)p[2] + (double)p[3], tot = p01 + p23;
     // first split by the whole quad (four attempts per round), then lanes {0,1} draw outcome 1 within {0,1} and lanes
     // {2,3} outcome 3 within {2,3} (two attempts per round each); every lane of a group ends up with the group's variate
@@ -364,11 +439,19 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
     __shared__ float s_prob[2][64];
     __shared__ uint32_t s_wave[SB / WAVE];
     __shared__ long long s_base[3];
+    // matrix-core mode: probabilities of every possible descendant of the entry prefixes (cand_jobs), the candidate index
+    // of each live prefix, the entry prefixes' strings
+    __shared__ __attribute__((aligned(16))) f32x4 s_cp[(NL - 1) * 64];
+    __shared__ uint8_t s_cphys[(NL - 1) * 64];
+    __shared__ uint8_t s_cand[2][64];
+    __shared__ uint32_t s_entry[E];
+    const bool ahead = wamp != nullptr;
     const int64_t U = b.U[n];
     if (b.U[MAXP + 1] != 0 || (int64_t)blockIdx.x * E >= U) return;                    // workgroup-uniform
     const int64_t nwg = (U + E - 1) / E;
     const int tid = threadIdx.x, u = tid >> 2, lane = tid & 63, wave = tid >> 6;
-    int U_loc = (int)min((int64_t)E, U - (int64_t)blockIdx.x * E);
+    const int entries = (int)min((int64_t)E, U - (int64_t)blockIdx.x * E);
+    int U_loc = entries;
     uint32_t mid_a = 0u, mid_b = 0u;                       // this workgroup's prefixes at the launch's 2nd (and 3rd) level
     for (int li = 0; li < NL; ++li) {
         const int lev = n + li;
@@ -376,21 +459,37 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         uint32_t ab = 0u;
         int64_t cnt = 0;
         float pr = 0.0f;
+        int cand = u;                                      // candidate index of this quad's prefix at its level
         if (li == 0) {
             const int64_t gu = (int64_t)blockIdx.x * E + u;
             if (active) { ab = b.ab[cur][gu]; cnt = b.cnt[cur][gu]; pr = b.prob[cur][gu]; }
+            if (ahead && active && (tid & 3) == 0) s_entry[u] = ab;
         } else {
             __syncthreads();                               // the previous level's children are in LDS
-            if (active) { ab = s_ab[li & 1][u]; cnt = s_cnt[li & 1][u]; pr = s_prob[li & 1][u]; }
+            if (active) { ab = s_ab[li & 1][u]; cnt = s_cnt[li & 1][u]; pr = s_prob[li & 1][u]; cand = s_cand[li & 1][u]; }
         }
         if (wamp == nullptr) {
             __syncthreads();                               // everyone done with the previous pair's rows
             stage_pair_weights(d, w, lev, s_w, SB);
         }
         __syncthreads();
-        int64_t out[4];
-        float p[4];
-        expand_quad(d, s_w, lev, ab, cnt, k0, k1, out, p, nullptr, wamp);
+        int64_t out[4] = {0, 0, 0, 0};
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ahead && wave > 0 && (E << (2 * li)) <= 16) {
+            // this level's prefixes fill at most wave 0: the other waves evaluate the later levels' candidates meanwhile
+            cand_jobs(d, wamp, n, NL, E, entries, s_entry, s_w + (size_t)wave * 128, s_cp, s_cphys, wave, SB / WAVE, li);
+        } else if (ahead && li > 0) {
+            bool phys[4] = {false, false, false, false};
+            if (active) {
+                const f32x4 pv = s_cp[(li - 1) * 64 + cand];
+                const uint32_t pm = s_cphys[(li - 1) * 64 + cand];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { p[c] = pv[c]; phys[c] = ((pm >> c) & 1u) != 0u; }
+            }
+            split_quad(lev, ab, cnt, k0, k1, p, phys, out, nullptr);
+        } else {
+            expand_quad(d, s_w, lev, ab, cnt, k0, k1, out, p, nullptr, wamp);
+        }
         const bool owner = active && (tid & 3) == 0;
         uint32_t mine = 0;
         if (owner)
@@ -417,6 +516,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
                         s_ab[(li + 1) & 1][pos] = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
                         s_cnt[(li + 1) & 1][pos] = out[c];
                         s_prob[(li + 1) & 1][pos] = pr * p[c];
+                        s_cand[(li + 1) & 1][pos] = (uint8_t)(cand * 4 + c);
                         ++pos;
                     }
                 }
@@ -518,11 +618,21 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
     __shared__ int64_t s_cnt[2][HP];
     __shared__ float s_prob[2][HP];
     __shared__ uint32_t s_wave[HT / WAVE];
+    // matrix-core mode, four-level head: while wave 0 expands the root, the other waves evaluate every possible prefix of
+    // levels 1-3 (4 + 16 + 64 candidates: cand_jobs with the root as the one entry); those levels start from the probabilities
+    constexpr bool AHEAD_OK = HT == 256 && HL == 4;
+    __shared__ __attribute__((aligned(16))) f32x4 s_cp[AHEAD_OK ? 3 * 64 : 1];
+    __shared__ uint8_t s_cphys[AHEAD_OK ? 3 * 64 : 1];
+    __shared__ uint8_t s_cand[2][AHEAD_OK ? HP : 1];
+    __shared__ uint32_t s_entry[1];
+    const bool ahead = AHEAD_OK && wamp != nullptr;
     const int tid = threadIdx.x, u = tid >> 2, q = tid & 3, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         for (int i = 0; i < MAXP + 2; ++i) b.U[i] = 0;
         b.U[0] = 1;
         s_ab[0][0] = 0u; s_cnt[0][0] = n_samples; s_prob[0][0] = 1.0f;
+        s_entry[0] = 0u;
+        if (AHEAD_OK) s_cand[0][0] = 0;
     }
     int U = 1;
     for (int n = 0; n < HL; ++n) {
@@ -533,10 +643,24 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         const uint32_t ab = active ? s_ab[cur][u] : 0u;
         const int64_t cnt = active ? s_cnt[cur][u] : 0;
         const float pr = active ? s_prob[cur][u] : 0.0f;
+        const int cand = (ahead && active) ? s_cand[cur][u] : 0;
         __syncthreads();
-        int64_t out[4];
-        float p[4];
-        expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, nullptr, wamp);
+        int64_t out[4] = {0, 0, 0, 0};
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ahead && wave > 0 && n < 3) {                  // (levels 0-2 have at most 16 prefixes: wave 0)
+            cand_jobs(d, wamp, 0, HL, 1, 1, s_entry, s_w + (size_t)wave * 128, s_cp, s_cphys, wave, HT / WAVE, n);
+        } else if (ahead && n > 0) {
+            bool phys[4] = {false, false, false, false};
+            if (active) {
+                const f32x4 pv = s_cp[(n - 1) * 64 + cand];
+                const uint32_t pm = s_cphys[(n - 1) * 64 + cand];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { p[c] = pv[c]; phys[c] = ((pm >> c) & 1u) != 0u; }
+            }
+            split_quad(n, ab, cnt, k0, k1, p, phys, out, nullptr);
+        } else {
+            expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, nullptr, wamp);
+        }
         uint32_t mine = 0;                                 // survivors of this quad's prefix, held by its first lane
         if (active && q == 0)
 #pragma unroll
@@ -563,6 +687,7 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
                         b.ab[(n + 1) & 1][pos] = child; b.cnt[(n + 1) & 1][pos] = out[c]; b.prob[(n + 1) & 1][pos] = pr * p[c];
                     } else {
                         s_ab[nxt][pos] = child; s_cnt[nxt][pos] = out[c]; s_prob[nxt][pos] = pr * p[c];
+                        if (AHEAD_OK) s_cand[nxt][pos] = (uint8_t)(cand * 4 + c);
                     }
                     ++pos;
                 }
