@@ -165,7 +165,8 @@ class OptimizerBase:
         ring = getattr(self, "_sampled_ring", None)
         if ring is None or ring.numel() < 2 * cap:
             self._flush_sampled_idxs()
-            ring = self._sampled_ring = torch.empty(max(1 << 25, 2 * cap), dtype=torch.int64, device=self.device)
+            ring = self._sampled_ring = torch.empty(max(int(getattr(self, "sampled_ring_elems", 1 << 25)), 2 * cap), dtype=torch.int64,
+                                                    device=self.device)
             self._sampled_ring_off = 0
         if self._sampled_ring_off + cap > ring.numel():
             self._flush_sampled_idxs()

@@ -252,6 +252,7 @@ def test_one_call_training_step_equals_the_step_by_step_loop(mol, kw, tmp_path, 
         z, hil, wf, opt = make_opt_gpu(mol, tmp_path / mode, scheduler=torch.optim.lr_scheduler.StepLR,
                                        scheduler_args=dict(step_size=7, gamma=0.5), **kw)
         assert opt._can_onecall() == (mode == "1")
+        opt.sampled_ring_elems = 1          # (the smallest tracking buffer: two slots, folded into the Counter every other step)
         opt.run(n_epochs=25, save_freq=None, save_final=False, output_freq=10)
         out = capsys.readouterr().out
         runs[mode] = dict(e=np.array(opt.log[LogKey.E_LOC]), v=np.array(opt.log[LogKey.E_LOC_VAR]),
