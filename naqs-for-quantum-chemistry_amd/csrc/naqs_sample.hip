@@ -565,7 +565,10 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         const int64_t base = s_base[0];
         int64_t pos = base + before + (incl - mine);
         if (owner && mine) {
-            const int nxt = (cur + NL) & 1;                // the global ping-pong half NL levels on
+            // the OTHER half of the global ping-pong arrays, whatever NL: this launch's workgroups read their entry prefixes
+            // from half `cur` at their own pace (a workgroup may start after others have finished), so nothing may be written
+            // there — with `(cur + NL) & 1` a two-level launch wrote its output over its own input
+            const int nxt = cur ^ 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (out[c] > 0) {
@@ -925,6 +928,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     // sizes are a hint read from mapped memory without synchronising (stale, or from another cap, at worst a slower cut);
     // the samples do not depend on the cut.  NAQS_SAMPLE_MULTI=1: always one level per launch.
     const int multi = fused_levels ? std::min(3, std::max(1, naqs::env_int("NAQS_SAMPLE_MULTI", 3))) : 1;
+    int half = n_first & 1;                                // which half of the ping-pong arrays holds the level a launch starts at
     const int64_t multi3_max = naqs::env_int("NAQS_SAMPLE_MULTI3_MAX", 2048);
     volatile const int64_t *hint = net->h_info + 4;
     for (int n = n_first; n < d.P;) {
@@ -945,32 +949,34 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
             const unsigned grid_m = (unsigned)((std::min(bound, cap) + E - 1) / E);
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
             if (nl == 3)
-                hipLaunchKernelGGL((sample_multi_kernel<3>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
+                hipLaunchKernelGGL((sample_multi_kernel<3>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                    keys_dev, counts_dev, probs_dev, wamp, early, seq);
             else
-                hipLaunchKernelGGL((sample_multi_kernel<2>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
+                hipLaunchKernelGGL((sample_multi_kernel<2>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                    keys_dev, counts_dev, probs_dev, wamp, early, seq);
             HIP_TRY(hipGetLastError());
             for (int i = 0; i < nl; ++i) bound = bound > cap ? bound : bound * 4;
             n += nl;
+            half ^= 1;
             continue;
         }
         const unsigned grid = (unsigned)((std::min(bound, cap) + SB - 1) / SB);
         const unsigned grid_e = (unsigned)((std::min(bound, cap) + EXP_PARENTS - 1) / EXP_PARENTS);
         if (fused_levels && (int64_t)grid_e <= resident_wg) {
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
-            hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, tag, cap, last,
+            hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                keys_dev, counts_dev, probs_dev, clk_dev, wamp, early, seq);
             HIP_TRY(hipGetLastError());
         } else {
-            hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, n & 1, k0, k1, wamp);
+            hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, wamp);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, n & 1, cap, last, keys_dev, counts_dev,
+            hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, half, cap, last, keys_dev, counts_dev,
                                probs_dev);
             HIP_TRY(hipGetLastError());
         }
         bound = bound > cap ? bound : bound * 4;
         ++n;
+        half ^= 1;
     }
     hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
                        weights_dev, early, seq, net->d_info_alias + 4);

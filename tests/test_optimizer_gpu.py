@@ -267,3 +267,34 @@ def test_one_call_training_step_equals_the_step_by_step_loop(mol, kw, tmp_path, 
     assert a["t"] == 25 and np.isfinite(a["e"]).all()
     if kw:
         assert a["msgs"], "the adaptive sample count was meant to act in this case"
+
+
+def test_training_run_is_reproducible_at_large_tables(tmp_path, monkeypatch):
+    """Two identically seeded Li2O runs (tables of 10^3 .. 3 x 10^4 unique samples in the first steps: sampler launches with
+    more workgroups than are resident at once) give the same energies and sample counts bit for bit.  A two-level sampler
+    launch once wrote its output over its own input half of the ping-pong arrays; only this kind of run saw it."""
+    from naqs_amd import packing
+    from naqs_amd.hilbert import Encoding, Hilbert
+    from naqs_amd.optimizer import LogKey, PartialSamplingOptimizer
+    from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+    ham = packing.load_packed(os.path.join(GOLDEN, "ham_Li2O.npz"))
+    na, nb = int(ham.n_alpha), int(ham.n_beta)
+    logs = []
+    for rep, multi3_max in enumerate(("2048", "2048", "16384")):
+        monkeypatch.setenv("NAQS_SAMPLE_MULTI3_MAX", multi3_max)       # (16384: also the cut with up to 4 096 workgroups per launch)
+        torch.manual_seed(1)
+        hil = Hilbert.get(int(ham.n_qubits), na, nb, encoding=Encoding.SIGNED)
+        wf = NAQSComplex_NADE_orbitals(hil, device="cuda", qubit_ordering=-1, amp_hidden_size=[64], phase_hidden_size=[512, 512],
+                                       use_amp_spin_sym=True, use_phase_spin_sym=False, aggregate_phase=False,
+                                       n_alpha_electrons=na, n_beta_electrons=nb)
+        opt = PartialSamplingOptimizer(n_samples=1000000, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5,
+                                       wavefunction=wf, qubit_hamiltonian=ham, pre_compute_H=False, n_electrons=na + nb,
+                                       n_alpha_electrons=na, n_beta_electrons=nb, optimizer=torch.optim.Adam,
+                                       optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'eps': 1e-15}, {'lr': 1e-2}],
+                                       save_loc=str(tmp_path / str(rep)), seed=1, grad_clip_factor=None, log_exact_energy=False,
+                                       pauli_hamiltonian_dtype=np.float64, normalise_psi=True)
+        opt.run(n_epochs=60, save_freq=None, save_final=False, output_freq=10 ** 9)
+        logs.append((np.array(opt.log[LogKey.E_LOC]), np.array(opt.log[LogKey.N_UNIQUE_SAMP])))
+    assert logs[0][1][:, 1].max() > 20000
+    for e, n in logs[1:]:
+        assert np.array_equal(n, logs[0][1]) and np.array_equal(e, logs[0][0])
