@@ -16,6 +16,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 dev = torch.device("cuda", 0)
 
 
+shape = (dict(amp_hidden_size=[128], phase_hidden_size=[128], aggregate_phase=True) if os.environ.get("NAQS_PROFILE_DEFAULT_ANSATZ") == "1"
+         else dict(amp_hidden_size=[64], phase_hidden_size=[512, 512], aggregate_phase=False))
+
+
 def run(onecall):
     os.environ["NAQS_TRAIN_ONECALL"] = onecall
     with contextlib.redirect_stdout(io.StringIO()):
@@ -23,9 +27,8 @@ def run(onecall):
         mol, qh = load_molecule(mol_f)
     na, nb = mol.get_n_alpha_electrons(), mol.get_n_beta_electrons()
     hil = Hilbert.get(N=mol.n_qubits, N_alpha=na, N_beta=nb, encoding=Encoding.SIGNED)
-    wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, use_amp_spin_sym=True, use_phase_spin_sym=False,
-                                   n_alpha_electrons=na, n_beta_electrons=nb, device=dev, amp_hidden_size=[64],
-                                   phase_hidden_size=[512, 512], aggregate_phase=False)
+    wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, use_amp_spin_sym=(na == nb), use_phase_spin_sym=False,
+                                   n_alpha_electrons=na, n_beta_electrons=nb, device=dev, **shape)
     opt = PartialSamplingOptimizer(n_samples=1000000, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5,
                                    wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False, n_electrons=mol.n_electrons,
                                    n_alpha_electrons=na, n_beta_electrons=nb, optimizer=torch.optim.Adam,
