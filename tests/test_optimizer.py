@@ -135,3 +135,59 @@ def test_two_process_step_equals_single_process(tmp_path):
     for (e1, v1), (e2, v2) in zip(outs[0]["res"], outs[1]["res"]):
         assert abs(e1 - e2) < 1e-6 * max(1, abs(e1)) and abs(v1 - v2) < 1e-5 * max(1, abs(v1))
     assert torch.max(torch.abs(outs[0]["params"] - outs[1]["params"])).item() < 2e-5
+
+
+def test_one_call_loop_adapts_the_sample_count_like_get_samples(tmp_path, monkeypatch, capsys):
+    """`_onecall_step` re-implements get_samples' adaptive rules (energy.py:936-971) around `FusedLogPsi.vmc_step`, which
+    abandons a step when get_samples would have re-sampled.  Scripted sampler outcomes (unique counts / tree overflows as a
+    function of n_samples) drive both: same sequence of sample counts, same messages, same final n_samples."""
+    from naqs_amd.nade import MaxBatchSizeExceededError
+
+    def outcome(n_samples, script):
+        """-> number of unique samples, or None for a tree overflow"""
+        return script(n_samples)
+
+    scripts = [
+        lambda n: min(n // 7, 4000),                                    # grows: too few -> x10 ... until enough
+        lambda n: None if n > 10 ** 6 else n // 3,                      # overflows above 1e6 -> /10
+        lambda n: 3 if n < 10 ** 9 else 50,                             # stays too small up to n_samples_max
+        lambda n: None if n >= 10 ** 5 else 2,                          # overflow above, too few below: the rules must not oscillate
+        lambda n: 2000,                                                 # fine at once
+    ]
+    for start in (2000, 10 ** 7):
+        for script in scripts:
+            logs = []
+            for mode in ("get_samples", "onecall"):
+                z, hil, wf, opt = make_opt("LiH", tmp_path / mode, monkeypatch, n_samples=start, n_samples_max=10 ** 9,
+                                           n_unq_samples_min=100, n_unq_samples_max=3000)
+                calls = []
+                if mode == "get_samples":
+                    def fake_sample(num_samples, **kw):
+                        calls.append(int(num_samples))
+                        m = outcome(int(num_samples), script)
+                        if m is None or m > opt.n_unq_samples_max:
+                            raise MaxBatchSizeExceededError
+                        t = torch.zeros(m, dtype=torch.int64)
+                        return torch.zeros((m, 1)), t, t.float(), t, t.double()
+                    monkeypatch.setattr(opt.wavefunction, "sample", fake_sample)
+                    opt.use_fused = False
+                    opt.get_samples(lazy=True)
+                else:
+                    class Fake:
+                        def vmc_step(self, ham, n_samples, seed, max_unique, m_lo, m_hi, adam=None, keys_out=None):
+                            calls.append(int(n_samples))
+                            m = outcome(int(n_samples), script)
+                            if m is None or m > max_unique:
+                                return False, 0, True, None
+                            if m < m_lo or m > m_hi:
+                                return False, m, False, None
+                            t = torch.zeros(m, dtype=torch.int64)
+                            return True, m, False, (t, t, t.float(), t.double(), t.float(), t.double(), t.double(), t.float(), t.double())
+                    monkeypatch.setattr(opt.wavefunction, "fused", lambda need_phase=True: Fake())
+                    monkeypatch.setattr(opt.wavefunction, "fused_repacked", lambda: None)
+                    opt.track_sampled_idxs = False
+                    opt._onecall_step()
+                out = [l for l in capsys.readouterr().out.splitlines() if "unique samples generated" in l or "MaxBatch" in l]
+                logs.append((calls, out, opt.n_samples))
+            assert logs[0] == logs[1], (start, logs)
+            assert len(logs[0][0]) >= 1
