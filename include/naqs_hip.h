@@ -319,7 +319,10 @@ int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t n_sam
  * with the caller: the step is abandoned after sampling — nothing evaluated, nothing updated — when the tree overflowed or
  * M is outside [m_lo, m_hi]; info_host[0] = M, [1] = overflow, [2] = 1 iff the step was taken.  adam_step < 1: stop after the
  * backward pass (the caller owns the optimiser).  The point of one call: between the sampler's last kernel and the re-pack
- * the GPU never waits for the caller's interpreter (measured: ~0.1 ms per step between the forward and the backward pass). */
+ * the GPU never waits for the caller's interpreter (measured: ~0.1 ms per step between the forward and the backward pass).
+ * The one host/device rendezvous, M, is read from mapped host memory that the sampler writes as soon as the last level's size
+ * is known (polled; NAQS_SPIN_WAIT=0: wait for the stream instead).  With adam_step >= 1 the reductions of the backward pass
+ * apply Adam's update in the same launch (torch.optim.Adam's rule, as naqs_adam_step). */
 int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
                   int64_t m_hi, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
                   float *logpsi_dev, double *eloc_dev, double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
