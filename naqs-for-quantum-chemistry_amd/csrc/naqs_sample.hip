@@ -418,7 +418,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
 // Children stay in (prefix, outcome) order at every step and a draw is keyed by its prefix, so the samples are the ones
 // every other cut of the tree into launches produces (tests/test_sampler_gpu.py).
 // The look-back word of a workgroup carries, beside the survivors of the launch's last level (9 bits), its prefix counts
-// at the intermediate levels (7 bits each): the workgroup that closes the chain then knows those levels' total sizes too
+// at the intermediate levels (7 bits each, up to three of them): the workgroup that closes the chain then knows those levels' total sizes too
 // (U[n + 1], ...; more than `cap` prefixes alive at ANY level is the overflow the reference raises, nade.py:710-712).
 // Every workgroup adds up ALL its predecessors' words (up to 256 loads in flight per round of its first wave): fine for
 // the ~10^2..10^3 active workgroups this kernel is chosen for (the host picks NL from the previous call's level sizes,
@@ -431,14 +431,14 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
                                                           int64_t *__restrict__ counts_out, float *__restrict__ probs_out,
                                                           const naqs::ushort_t *__restrict__ wamp, int64_t *__restrict__ early,
                                                           const int64_t seq) {
-    static_assert(NL == 2 || NL == 3, "two or three levels per launch");
+    static_assert(NL >= 2 && NL <= 4, "two to four levels per launch");
     constexpr int E = 64 >> (2 * (NL - 1));
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_ab[2][64];
     __shared__ int64_t s_cnt[2][64];
     __shared__ float s_prob[2][64];
     __shared__ uint32_t s_wave[SB / WAVE];
-    __shared__ long long s_base[3];
+    __shared__ long long s_base[4];
     // matrix-core mode: probabilities of every possible descendant of the entry prefixes (cand_jobs), the candidate index
     // of each live prefix, the entry prefixes' strings
     __shared__ __attribute__((aligned(16))) f32x4 s_cp[(NL - 1) * 64];
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
     const int tid = threadIdx.x, u = tid >> 2, lane = tid & 63, wave = tid >> 6;
     const int entries = (int)min((int64_t)E, U - (int64_t)blockIdx.x * E);
     int U_loc = entries;
-    uint32_t mid_a = 0u, mid_b = 0u;                       // this workgroup's prefixes at the launch's 2nd (and 3rd) level
+    uint32_t mid_a = 0u, mid_b = 0u, mid_c = 0u;           // this workgroup's prefixes at the launch's 2nd (3rd, 4th) level
     for (int li = 0; li < NL; ++li) {
         const int lev = n + li;
         const bool active = u < U_loc;
@@ -522,16 +522,16 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
                 }
             }
             U_loc = (int)total;
-            if (li == 0) mid_a = total; else mid_b = total;
+            if (li == 0) mid_a = total; else if (li == 1) mid_b = total; else mid_c = total;
             continue;
         }
         // last level of the launch: place among the other workgroups' children (look-back over their words)
         if (wave == 0) {
             if (lane == 0)
                 __hip_atomic_store(&b.wg_state[blockIdx.x],
-                                   ((unsigned long long)tag << 32) | (unsigned long long)(total | (mid_a << 9) | (mid_b << 16)),
+                                   ((unsigned long long)tag << 32) | (unsigned long long)(total | (mid_a << 9) | (mid_b << 16) | (mid_c << 23)),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            long long part = 0, part_a = 0, part_b = 0;
+            long long part = 0, part_a = 0, part_b = 0, part_c = 0;
             for (int64_t j0 = 0; j0 < (int64_t)blockIdx.x; j0 += 4 * WAVE) {
                 unsigned long long v[4];
 #pragma unroll
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
                     part += (long long)(x & 0x1ffu);
                     part_a += (long long)((x >> 9) & 0x7fu);
                     part_b += (long long)((x >> 16) & 0x7fu);
+                    part_c += (long long)((x >> 23) & 0x7fu);
                 }
             }
 #pragma unroll
@@ -558,8 +559,9 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
                 part += __shfl_down(part, off, 64);
                 part_a += __shfl_down(part_a, off, 64);
                 part_b += __shfl_down(part_b, off, 64);
+                part_c += __shfl_down(part_c, off, 64);
             }
-            if (lane == 0) { s_base[0] = part; s_base[1] = part_a; s_base[2] = part_b; }
+            if (lane == 0) { s_base[0] = part; s_base[1] = part_a; s_base[2] = part_b; s_base[3] = part_c; }
         }
         __syncthreads();
         const int64_t base = s_base[0];
@@ -596,10 +598,12 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         }
         if ((int64_t)blockIdx.x == nwg - 1 && tid == 0) {
             const int64_t all = base + total, all_a = s_base[1] + mid_a, all_b = NL > 2 ? s_base[2] + mid_b : 0;
+            const int64_t all_c = NL > 3 ? s_base[3] + mid_c : 0;
             b.U[n + 1] = all_a < cap ? all_a : cap;
             if (NL > 2) b.U[n + 2] = all_b < cap ? all_b : cap;
+            if (NL > 3) b.U[n + 3] = all_c < cap ? all_c : cap;
             b.U[n + NL] = all < cap ? all : cap;
-            const bool over = all > cap || all_a > cap || all_b > cap;
+            const bool over = all > cap || all_a > cap || all_b > cap || all_c > cap;
             if (over) b.U[MAXP + 1] = 1;
             if (last && early != nullptr) publish_info(early, over ? 0 : all, over ? 1 : 0, seq);
         }
@@ -853,7 +857,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const size_t o_cc = off; off = align_up(off + (size_t)lay * 4 * sizeof(int64_t));
     const size_t o_cp = off; off = align_up(off + (size_t)lay * 4 * sizeof(float));
     const size_t o_wg = off; off = align_up(off + (size_t)nwg_cap * sizeof(uint32_t));
-    const int64_t nws_cap = (lay + 3) / 4;                  // look-back words: sample_multi_kernel<3> has a workgroup per 4 prefixes
+    const int64_t nws_cap = lay;                            // look-back words: sample_multi_kernel<4> has a workgroup per prefix
     const size_t o_ws = off; off = align_up(off + (size_t)nws_cap * sizeof(unsigned long long));
     const size_t o_U = off; off = align_up(off + (size_t)U_SLOTS * sizeof(int64_t));
     if (cap > net->samp_cap) {
@@ -927,7 +931,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     // sample_multi_kernel (three levels while <= 2048 prefixes enter — 512 workgroups of 4 —, two while <= 8192; measured: 4096 / 16384 is 25 us slower per N2 step).  The
     // sizes are a hint read from mapped memory without synchronising (stale, or from another cap, at worst a slower cut);
     // the samples do not depend on the cut.  NAQS_SAMPLE_MULTI=1: always one level per launch.
-    const int multi = fused_levels ? std::min(3, std::max(1, naqs::env_int("NAQS_SAMPLE_MULTI", 3))) : 1;
+    const int multi = fused_levels ? std::min(4, std::max(1, naqs::env_int("NAQS_SAMPLE_MULTI", 4))) : 1;
     int half = n_first & 1;                                // which half of the ping-pong arrays holds the level a launch starts at
     const int64_t multi3_max = naqs::env_int("NAQS_SAMPLE_MULTI3_MAX", 2048);
     volatile const int64_t *hint = net->h_info + 4;
@@ -936,9 +940,14 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         int nl = 1;
         if (multi > 1 && left >= 2) {
             const int64_t h = hint[n];
-            const int want = left == 4 ? 2 : std::min(left, 3);                  // 6 -> 3 + 3, 5 -> 3 + 2, 4 -> 2 + 2
-            if (h > 0 && h <= multi3_max && want == 3 && multi >= 3) nl = 3;
-            else if (h > 0 && h <= 4 * multi3_max) nl = 2;
+            // (four levels: one entry prefix per workgroup, i.e. at most `multi3_max / 4` of them enter)
+            // and only while the worst-case grid is small: the launch must cover min(4^n, cap) prefixes whatever the hint says)
+            if (h > 0 && 4 * h <= multi3_max && left >= 4 && left != 5 && multi >= 4 && std::min(bound, cap) <= 4096) nl = 4;   // 6 -> 4 + 2, 4 -> 4
+            else {
+                const int want = left == 4 ? 2 : std::min(left, 3);              // 6 -> 3 + 3, 5 -> 3 + 2, 4 -> 2 + 2
+                if (h > 0 && h <= multi3_max && want == 3 && multi >= 3) nl = 3;
+                else if (h > 0 && h <= 4 * multi3_max) nl = 2;
+            }
         }
         const int n_end = n + nl - 1;                         // last level of this launch
         const int nin = n_end == 0 ? 1 : 2 * n_end;
@@ -948,7 +957,10 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
             const int E = 64 >> (2 * (nl - 1));
             const unsigned grid_m = (unsigned)((std::min(bound, cap) + E - 1) / E);
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
-            if (nl == 3)
+            if (nl == 4)
+                hipLaunchKernelGGL((sample_multi_kernel<4>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
+                                   keys_dev, counts_dev, probs_dev, wamp, early, seq);
+            else if (nl == 3)
                 hipLaunchKernelGGL((sample_multi_kernel<3>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                    keys_dev, counts_dev, probs_dev, wamp, early, seq);
             else

@@ -155,7 +155,7 @@ def test_launch_fusions_change_nothing(mol, monkeypatch):
     from naqs_amd.nade import MaxBatchSizeExceededError
     outs = []
     for head, fuse, multi in (("2", "1", "1"), ("1", "1", "1"), ("0", "1", "1"), ("2", "0", "1"), ("0", "0", "1"), ("1", "1", "3"),
-                              ("1", "1", "2"), ("0", "1", "3"), ("2", "1", "2")):
+                              ("1", "1", "2"), ("0", "1", "3"), ("2", "1", "2"), ("1", "1", "4"), ("0", "1", "4")):
         monkeypatch.setenv("NAQS_SAMPLE_HEAD", head)
         monkeypatch.setenv("NAQS_SAMPLE_FUSED", fuse)
         monkeypatch.setenv("NAQS_SAMPLE_MULTI", multi)
@@ -170,7 +170,7 @@ def test_launch_fusions_change_nothing(mol, monkeypatch):
     M = len(outs[0][0])
     for cap in (M - 1, M, M + M // 8, 2 * M):
         res = []
-        for multi in ("1", "2", "3"):
+        for multi in ("1", "2", "4"):
             monkeypatch.setenv("NAQS_SAMPLE_HEAD", "1")
             monkeypatch.setenv("NAQS_SAMPLE_FUSED", "1")
             monkeypatch.setenv("NAQS_SAMPLE_MULTI", multi)
