@@ -872,7 +872,7 @@ __device__ __forceinline__ void amp_mfma_prologue(const NetDims &d, const ushort
 // scratch[n][i] = conditional log-amplitude of sample i's outcome at pair n (summed by the phase kernel, block 0..P-1)
 constexpr int AMPK_TG = 2, AMPK_WAVES = 4;
 template <int CT>
-__global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void amp_mfma_kernel(const NetDims d, const ushort_t *__restrict__ wamp, int64_t M,
+__global__ __launch_bounds__(AMPK_WAVES * 64) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 2 : 4))) void amp_mfma_kernel(const NetDims d, const ushort_t *__restrict__ wamp, int64_t M,
                                                                    const uint64_t *__restrict__ keys,
                                                                    float *__restrict__ scratch, const ElocFeed feed) {
     __shared__ __attribute__((aligned(16))) float s_outs[AMPK_WAVES][128];
@@ -1387,6 +1387,12 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
             if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cu_count = prop.multiProcessorCount;
             if (hipMalloc((void **)&net->d_w, (size_t)poff * sizeof(float)) != hipSuccess) st0 = NAQS_ERR_NOMEM;
             if (st0 == NAQS_OK && hipMalloc((void **)&net->d_wph, (size_t)poff2 * sizeof(float)) != hipSuccess) st0 = NAQS_ERR_NOMEM;
+            // the amplitude blocks as matrix-core fragments too: the sampler's block MLP (the forward pass of this family keeps
+            // the one merged VALU launch for both sets of blocks)
+            if (st0 == NAQS_OK && (d.Ha == 32 || d.Ha == 64 || d.Ha == 128) && 2 * (P - 1) <= 30) {
+                const size_t elems = (size_t)P * amp_mfma_pair_elems(d.Ha);
+                if (hipMalloc((void **)&net->d_wamp, elems * sizeof(unsigned short)) != hipSuccess) st0 = NAQS_ERR_NOMEM;
+            }
         }
         if (st0 != NAQS_OK) { naqs_net_destroy(net); return st0; }
         *out = net;
@@ -1437,7 +1443,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cu_count = prop.multiProcessorCount;
         if (hipMalloc((void **)&net->d_w, (size_t)net->w_floats * sizeof(float)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMalloc((void **)&net->d_wh, (size_t)net->wh_elems * sizeof(unsigned short)) != hipSuccess) st = NAQS_ERR_NOMEM;
-        if (st == NAQS_OK && (d.Ha == 32 || d.Ha == 64)) {   // amplitude blocks as MFMA fragments (phase kernel prologue);
+        if (st == NAQS_OK && (d.Ha == 32 || d.Ha == 64 || d.Ha == 128)) {   // amplitude blocks as MFMA fragments (phase kernel prologue);
             const size_t elems = (size_t)P * amp_mfma_pair_elems(d.Ha);   // input slot 31 must be free for the bias: 2 (P - 1) <= 30
             if (hipMalloc((void **)&net->d_wamp, elems * sizeof(unsigned short)) != hipSuccess) st = NAQS_ERR_NOMEM;
         }
@@ -1648,7 +1654,8 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
         const int64_t waves = (M + AMPK_TG * 16 - 1) / (AMPK_TG * 16) * d.P;
         const unsigned grid = (unsigned)((waves + AMPK_WAVES - 1) / AMPK_WAVES);
         const size_t lds = 0;
-        if (d.Ha == 64) hipLaunchKernelGGL(amp_mfma_kernel<4>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        if (d.Ha == 128) hipLaunchKernelGGL(amp_mfma_kernel<8>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        else if (d.Ha == 64) hipLaunchKernelGGL(amp_mfma_kernel<4>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
         else hipLaunchKernelGGL(amp_mfma_kernel<2>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
         HIP_TRY(hipGetLastError());
         return NAQS_OK;
@@ -1658,7 +1665,8 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
 
 // aggregate_phase: amplitude blocks, phase blocks (raw), then the sums
 static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, hipStream_t s, const ElocFeed &feed) {
-    const bool mfma_amp = net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) != 0;
+    // (NAQS_AMP_MODE=2: the amplitude blocks as matrix-core items + a second launch for the phase blocks; default: one merged VALU launch)
+    const bool mfma_amp = net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 2;
     const bool prof = net->prof.armed();
     int st;
     float *s_ph;
@@ -1673,7 +1681,11 @@ static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float 
                            dim3(AMP_TILES * AMP_SPLIT * WAVE), lds, s, d0, net->d_w, net->d_scratch, feed, d1, net->d_wph, s_ph, M, keys_dev);
         HIP_TRY(hipGetLastError());
     } else {
-        st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
+        if (mfma_amp) st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
+        else {                                             // the VALU form, like the merged launch (same numbers)
+            st = naqs::net_amp_forward(net, M, keys_dev, s, nullptr, /*launch=*/false);
+            if (st == NAQS_OK) st = launch_amp_kernel(net->dims, net->d_w, M, keys_dev, net->d_scratch, feed, 0, s);
+        }
         if (st != NAQS_OK) return st;
         s_ph = net->d_scratch + (size_t)net->dims.P * net->cap_M;
         const ElocFeed none{};
@@ -1708,7 +1720,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     // amplitude conditionals inside the phase kernel (matrix cores) unless NAQS_AMP_MODE=0 or the width does not tile
     const size_t amp_scratch = (size_t)d.P * rb_max * 16 * 8 * sizeof(float);          // [P][BM][8] raw outputs of the items
     const bool amp_in_phase = use_h && net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
-                              amp_scratch <= 150 * 1024;
+                              amp_scratch <= 150 * 1024 && d.Ha <= 64;      // (128-unit blocks: two fragment sets do not fit the prologue's registers)
     if (!amp_in_phase) {
         st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
         if (st != NAQS_OK) return st;

@@ -154,7 +154,8 @@ __device__ __forceinline__ void cand_jobs_t(const NetDims &d, const naqs::ushort
 __device__ __forceinline__ void cand_jobs(const NetDims &d, const naqs::ushort_t *__restrict__ wamp, const int n, const int LV,
                                           const int E, const int entries, const uint32_t *s_entry, float *outs, f32x4 *cp,
                                           uint8_t *cphys, const int wave, const int n_waves, const int pass) {
-    if (d.Ha == 64) cand_jobs_t<4>(d, wamp, n, LV, E, entries, s_entry, outs, cp, cphys, wave, n_waves, pass);
+    if (d.Ha == 128) cand_jobs_t<8>(d, wamp, n, LV, E, entries, s_entry, outs, cp, cphys, wave, n_waves, pass);
+    else if (d.Ha == 64) cand_jobs_t<4>(d, wamp, n, LV, E, entries, s_entry, outs, cp, cphys, wave, n_waves, pass);
     else cand_jobs_t<2>(d, wamp, n, LV, E, entries, s_entry, outs, cp, cphys, wave, n_waves, pass);
 }
 
@@ -183,7 +184,11 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         float *outs = const_cast<float *>(s_w) + (size_t)wave * 128;
         const uint32_t ab16 = (uint32_t)__shfl((int)ab, 4 * (lane & 15), 64);
-        if (d.Ha == 64) {
+        if (d.Ha == 128) {
+            naqs::AmpFrag<8> f;
+            naqs::amp_mfma_load<8>(wamp + (size_t)n * naqs::amp_mfma_pair_elems(128), lane, f);
+            naqs::amp_mfma_item<8>(d, f, n, ab16, lane, outs);
+        } else if (d.Ha == 64) {
             naqs::AmpFrag<4> f;
             naqs::amp_mfma_load<4>(wamp + (size_t)n * naqs::amp_mfma_pair_elems(64), lane, f);
             naqs::amp_mfma_item<4>(d, f, n, ab16, lane, outs);
