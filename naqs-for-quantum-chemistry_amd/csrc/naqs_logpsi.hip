@@ -1237,12 +1237,14 @@ __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__
                                                        float *__restrict__ w) {
     pack_amp_body(flat, d, so, w, blockIdx.y);
 }
-// aggregate_phase: both sets of per-pair blocks (blockIdx.z)
+// aggregate_phase: both sets of per-pair blocks (blockIdx.z = 0, 1) and, when they exist, the amplitude blocks' matrix-core
+// fragments (2) in one launch
 __global__ __launch_bounds__(256) void pack_amp2_kernel(const float *__restrict__ flat, const NetDims d0, const AmpSrcOff so0,
                                                         float *__restrict__ w0, const NetDims d1, const AmpSrcOff so1,
-                                                        float *__restrict__ w1) {
+                                                        float *__restrict__ w1, ushort_t *__restrict__ wamp) {
     if (blockIdx.z == 0) pack_amp_body(flat, d0, so0, w0, blockIdx.y);
-    else pack_amp_body(flat, d1, so1, w1, blockIdx.y);
+    else if (blockIdx.z == 1) pack_amp_body(flat, d1, so1, w1, blockIdx.y);
+    else pack_amp_mfma_body(flat, d0, so0, wamp, blockIdx.y);
 }
 
 __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
@@ -1571,11 +1573,15 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
         if (net->dims.P == net->dph.P && (naqs::env_int("NAQS_AGG_MERGE", 7) & 4)) {
             AmpSrcOff so0, so1;
             for (int n = 0; n < MAXP; ++n) { so0.off[n] = net->amp_src_off[n]; so1.off[n] = net->ph_src_off[n]; }
-            const int total_max = std::max(d.Ha, net->dph.Ha) * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;
+            const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
+            const int total_max = std::max(std::max(d.Ha, net->dph.Ha) * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8, net->d_wamp ? frag : 0);
             net->wamp_fresh = false;
-            hipLaunchKernelGGL(pack_amp2_kernel, dim3((total_max + 255) / 256, d.P, 2), dim3(256), 0, s, flat_dev, d, so0, net->d_w, net->dph, so1,
-                               net->d_wph);
+            hipLaunchKernelGGL(pack_amp2_kernel, dim3((total_max + 255) / 256, d.P, net->d_wamp ? 3 : 2), dim3(256), 0, s, flat_dev, d, so0, net->d_w,
+                               net->dph, so1, net->d_wph, net->d_wamp);
             HIP_TRY(hipGetLastError());
+            net->wamp_fresh = net->d_wamp != nullptr;
+            net->have_weights = net->have_amp_weights = net->have_wb = true;
+            return NAQS_OK;
         } else {
             st = pack_amp_blocks(net, flat_dev, s);
             if (st != NAQS_OK) return st;
