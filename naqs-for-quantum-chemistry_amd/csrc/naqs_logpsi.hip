@@ -1042,6 +1042,383 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_h(const NetDims d, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// phase_kernel_ws — the same tile of log psi with the workgroup's waves SPECIALISED during the big hidden layer (round 4).
+// phase_kernel_h runs prologue -> layer 0 -> layer 1 -> layer 2 with all eight waves in step: the matrix cores idle through
+// the amplitude prologue (14 k of the tile's 51 k cycles at N2 / 48 rows) and the VALU idles through layer 1.  The two only
+// share the occupation strings, so here layer 1 belongs to waves 0-3 — one per SIMD, eight column tiles each: 32 RB
+// accumulator registers x 3, every weight fragment re-requested right after its last use, i.e. 7/8 of a chunk (~1 k cycles)
+// ahead of its next one, no second buffer — while waves 4-7, their SIMD partners, run the (tile, pair) amplitude items, the
+// E_loc key hand-over and the conditionals of their own items.  The f16x2 format is what makes it fit: 96 accumulators + 64
+// fragment registers + two sets of activation fragments stay under the 256 registers two waves per SIMD can have, and two
+// planes of 48 rows leave LDS for the items' raw outputs beside the activation tile.  Same arithmetic in the same order as
+// phase_kernel_h (chunks ascending, smallest term first; the items are the shared amp_mfma_item): bit-identical results.
+// Shape: hidden layers of 512 units, first layer one K chunk (2 (P - 1) <= 32), f16x2 format, amplitude width <= 64.
+// ------------------------------------------------------------------------------------------------
+constexpr int WS_MW = 4;                         // matrix waves (0 .. WS_MW - 1); the others are the amplitude waves
+constexpr int WS_NCT = 8;                        // column tiles of a matrix wave in the big layer: 4 x 8 x 16 = 512 columns
+
+template <int RB, int DBG = 0>
+__device__ __forceinline__ void ws_accumulate(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
+                                              const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
+                                              f32x4 (&acc)[RB][WS_NCT]) {
+    bf16x8 b[2][WS_NCT], a0[2][RB], a1[2][RB];
+    auto load_b2 = [&](int k0, int c0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c = c0; c < c0 + 2; ++c)
+                b[p][c] = *reinterpret_cast<const bf16x8 *>(w_ptr + p * wplane + ((size_t)c * Kh_pad + (DBG == 2 ? 0 : k0)) * 16);
+    };
+    auto load_a = [&](int k0, bf16x8 (&a)[2][RB]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                a[p][rb] = *reinterpret_cast<const bf16x8 *>(a_ptr + p * plane_stride + rb * 16 * ldh + k0);
+    };
+    auto mma2 = [&](const bf16x8 (&a)[2][RB], int c0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = c0; c < c0 + 2; ++c) {
+                f32x4 v = acc[rb][c];
+                if constexpr (DBG == 1) {                       // (timing aid: the stream without the matrix work)
+                    v[0] += __builtin_bit_cast(f32x4, b[0][c])[0] + __builtin_bit_cast(f32x4, b[1][c])[1] + __builtin_bit_cast(f32x4, a[0][rb])[0] + __builtin_bit_cast(f32x4, a[1][rb])[0];
+                    acc[rb][c] = v;
+                    continue;
+                }
+                v = mfma_h<2>(a[1][rb], b[0][c], v);            // smallest terms first (the order of mlp_accumulate_h)
+                v = mfma_h<2>(a[0][rb], b[1][c], v);
+                v = mfma_h<2>(a[0][rb], b[0][c], v);
+                acc[rb][c] = v;
+            }
+    };
+#pragma unroll
+    for (int c0 = 0; c0 < WS_NCT; c0 += 2) load_b2(0, c0);
+    load_a(0, a0);
+    int k0 = 0;
+    for (; k0 + 64 <= Kh_pad; k0 += 64) {
+        load_a(k0 + 32, a1);
+#pragma unroll
+        for (int c0 = 0; c0 < WS_NCT; c0 += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(a0, c0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b2(k0 + 32, c0);
+        }
+        const int kn = min(k0 + 64, Kh_pad - 32);          // unconditional (clamped): a branch makes the s_waitcnt merge conservative
+        load_a(kn, a0);
+#pragma unroll
+        for (int c0 = 0; c0 < WS_NCT; c0 += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(a1, c0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b2(kn, c0);
+        }
+    }
+    if (k0 < Kh_pad) {                                      // odd number of chunks: the last one is already loaded
+#pragma unroll
+        for (int c0 = 0; c0 < WS_NCT; c0 += 2) mma2(a0, c0);
+    }
+}
+
+// write-back of four interleaved column tiles (64 adjacent columns: a lane owns four adjacent ones, tile_col) of a matrix wave
+template <int RB, bool SAVE, int NCT, int C0>
+__device__ __forceinline__ void ws_writeback4(ushort_t *__restrict__ planes, int ldh, f32x4 (&acc)[RB][NCT],
+                                              const float (&bvs)[NCT], int col0, int lane, float *__restrict__ save, int save_ld,
+                                              int64_t row0, int64_t M, const LayerScale sc) {
+    constexpr int BM = RB * 16;
+    const int kg = lane >> 4;
+    const int plane_stride = BM * ldh;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float h[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h[c] = fmaxf(fmaf(acc[rb][C0 + c][r], sc.c, bvs[C0 + c]), 0.0f);
+            const int row = rb * 16 + kg * 4 + r;
+            if (SAVE && save != nullptr && row0 + row < M)
+                *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) =
+                    (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn};
+            ushort_t *dst = planes + row * ldh + col0;                              // 8-byte aligned
+            uint32_t a1, a2, b1, b2;
+            split2_pair(h[0], h[1], a1, a2);
+            split2_pair(h[2], h[3], b1, b2);
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2 *>(dst + plane_stride) = make_uint2(a2, b2);
+        }
+}
+
+// the amplitude waves' share of a tile: items q0 .. q1 (pair-major, q = n RB + t), the E_loc key hand-over, then the
+// conditionals of exactly those items — nothing here needs another wave, so there is no workgroup barrier inside
+template <int CT, int RB>
+__device__ __forceinline__ void ws_amp_work(const NetDims &d, const ushort_t *__restrict__ wamp, int64_t M, int64_t row0,
+                                            const uint64_t *__restrict__ keys, const ElocFeed &feed, const uint32_t *s_ab,
+                                            float (*s_lan)[RB * 16], float *__restrict__ s_o, AmpFrag<CT> &f0, int aw, int lane,
+                                            long long *clk, int wave) {
+    constexpr int BM = RB * 16;
+    constexpr int AW = PH_WAVES - WS_MW;
+    const size_t pair_elems = amp_mfma_pair_elems(CT * 16);
+    const int P = d.P, items = RB * P;
+    const int q0 = items * aw / AW, q1 = items * (aw + 1) / AW;
+    AmpFrag<CT> f1;
+    int na = q0 < q1 ? q0 / RB : -1, nb = -1;                   // f0 holds pair na (requested by the caller before the first barrier)
+    const int n_last = q0 < q1 ? (q1 - 1) / RB : -1;
+    for (int q = q0; q < q1; ++q) {
+        const int n = q / RB, t = q - n * RB;
+        const uint32_t ab = s_ab[t * 16 + (lane & 15)];
+        float *outs = s_o + ((size_t)n * BM + t * 16) * 8;
+        if (n == na) {
+            if (nb < n && n_last > n) { nb = n + 1; amp_mfma_load<CT>(wamp + (size_t)nb * pair_elems, lane, f1); }
+            __builtin_amdgcn_sched_barrier(0);
+            amp_mfma_item<CT>(d, f0, n, ab, lane, outs);
+        } else {
+            if (na < n && n_last > n) { na = n + 1; amp_mfma_load<CT>(wamp + (size_t)na * pair_elems, lane, f0); }
+            __builtin_amdgcn_sched_barrier(0);
+            amp_mfma_item<CT>(d, f1, n, ab, lane, outs);
+        }
+    }
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 8] = clock64();
+    // fused log-psi + E_loc call: narrow the key and insert it into the E_loc hash table (an atomicCAS round trip to L2
+    // that nothing in this kernel waits for)
+    {
+        const int r = aw * WAVE + lane;
+        if (r < BM && feed.tab != nullptr && row0 + r < M) {
+            const uint64_t key = keys[row0 + r];
+            if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, row0 + r, key);
+            else naqs::feed_key<uint64_t>(feed, row0 + r, key);
+        }
+    }
+    // the raw outputs of this wave's items were written by this wave: LDS operations of a wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = q0 * 16 + lane; e < q1 * 16; e += WAVE) {
+        const int q = e >> 4, s = e & 15;
+        const int n = q / RB, r = (q - n * RB) * 16 + s;
+        float o[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o[c] = s_o[((size_t)n * BM + r) * 8 + c];
+        const uint32_t ab = s_ab[r], mask = (1u << n) - 1u;
+        const int occ = (int)((ab >> n) & 1u) + 2 * (int)((ab >> (16 + n)) & 1u);
+        s_lan[n][r] = naqs::amp_finish(d, n, o, ab & mask, (ab >> 16) & mask, occ);
+    }
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 15] = clock64();
+}
+
+template <int RB, bool SAVE>
+__global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, const float *__restrict__ w,
+                                                              const ushort_t *__restrict__ wh, int64_t M,
+                                                              const uint64_t *__restrict__ keys,
+                                                              const float *__restrict__ scratch, float2 *__restrict__ out,
+                                                              const ElocFeed feed, const naqs::PhaseSave save,
+                                                              const ushort_t *__restrict__ wamp,
+                                                              const naqs::PhaseScales *__restrict__ scales, const int flags) {
+    // wamp == nullptr: the amplitude conditionals were computed by a kernel of their own (scratch[n][i]); waves 4-7 then
+    // only wait at the barrier
+    extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
+    __shared__ uint32_t s_ab[RB * 16];                 // model-order occupation strings of the tile's samples
+    __shared__ float s_lan[MAXP][RB * 16];             // conditional log-amplitudes, pair-major
+    __shared__ __attribute__((aligned(16))) float s_part[WS_MW][RB * 16][4];   // the output layer's partial rows, per matrix wave
+    constexpr int BM = RB * 16;
+    constexpr int FMT = 2, NP = 2;
+    constexpr int AW = PH_WAVES - WS_MW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int P = d.P, ldh = d.ldh;
+    float *s_o = reinterpret_cast<float *>(planes + (size_t)NP * BM * ldh);     // [P][BM][8] raw outputs of the items
+    const bool ha64 = d.Ha == 64;
+
+    NAQS_MARK(0);
+    // touch layer 0's weight planes (one dword per 128-byte line): at launch start every XCD's L2 misses them
+    uint32_t warm0 = 0, warm1 = 0;
+    {
+        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(wh + d.wh_off[0]);
+        const int n_dw = NP * d.N_pad[0] * d.Kh_pad[0] / 2;
+        if (tid * 32 < n_dw) warm0 = w0[tid * 32];
+        if ((tid + PH_THREADS) * 32 < n_dw) warm1 = w0[(tid + PH_THREADS) * 32];
+    }
+    // the key load goes out before the fragment loads (vector loads return in order); every wave requests the fragments of
+    // an amplitude wave's first pair (unconditional: inside a branch the compiler cannot count the loads behind the key's)
+    uint64_t key = 0ull;
+    if (tid < BM && row0 + tid < M) key = keys[row0 + tid];
+    __builtin_amdgcn_sched_barrier(0);
+    const int aw = wave >= WS_MW ? wave - WS_MW : 0;
+    const int items = RB * P;
+    const int first_pair = (items * aw / AW) / RB;
+    AmpFrag<4> f4;
+    AmpFrag<2> f2;
+    if (wamp != nullptr) {                // (workgroup-uniform)
+        if (ha64) amp_mfma_load<4>(wamp + (size_t)first_pair * amp_mfma_pair_elems(64), lane, f4);
+        else amp_mfma_load<2>(wamp + (size_t)first_pair * amp_mfma_pair_elems(32), lane, f2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < BM) {                      // model-order occupation strings of the tile's samples
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            if (k < P) {
+                a |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+                b |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+            }
+        }
+        s_ab[tid] = a | (b << 16);
+    }
+    __syncthreads();
+    NAQS_MARK(1);
+
+    // layer 0 (one K chunk): the +-1 inputs are built in registers as the A operand (lane (m, kg): sample m of the row block,
+    // inputs 8 kg .. 8 kg + 7 as four f16 pairs; 2 (P - 1) is even: a pair is valid or not as a whole) — no input tile in LDS,
+    // no barrier before the layer.  Same MFMAs in the same order as mlp_layer0_pre.
+    const int m = lane & 15, kg = lane >> 4;
+    LayerScale sc;
+    sc.c = scales->c[0]; sc.sn = scales->sn[0]; sc.isn = scales->isn[0];
+    {
+        bf16x8 pre[NP][CBT];
+        mlp_layer0_fetch<RB, NP>(d, wh + d.wh_off[0], wave, lane, pre);
+        const int N0 = d.N_pad[0], cb0 = wave * CBT;
+        float bvs0[CBT];
+#pragma unroll
+        for (int c = 0; c < CBT; ++c) bvs0[c] = (w + d.b_off[0])[tile_col(cb0 + c, m, N0)] * sc.sn;
+        const uint32_t pmask = (1u << (P - 1)) - 1u;
+        const int nv = min(max(2 * (P - 1) - 8 * kg, 0), 8) >> 1;
+        f32x4 acc0[RB][CBT];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const uint32_t ab = s_ab[rb * 16 + m];
+            const uint32_t tb = ((ab & pmask) | (((ab >> 16) & pmask) << (P - 1))) >> (8 * kg);
+            const bool live = row0 + rb * 16 + m < M;                      // rows past M: zero inputs
+            uint32_t aw4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t wv = 0xBC00BC00u ^ ((tb << (15 - 2 * j)) & 0x8000u) ^ ((tb << (30 - 2 * j)) & 0x80000000u);
+                aw4[j] = (live && j < nv) ? wv : 0u;
+            }
+            bf16x8 a;
+            __builtin_memcpy(&a, aw4, sizeof(a));
+#pragma unroll
+            for (int c = 0; c < CBT; ++c) {
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = NP - 1; p >= 0; --p) v = mfma_h<FMT>(a, pre[p][c], v);       // smallest terms first
+                acc0[rb][c] = v;
+            }
+        }
+        if (SAVE && save.x != nullptr) {                                   // training forward: the inputs also go to HBM
+            const int nin = 2 * (P - 1);
+            for (int e = tid; e < BM * nin; e += PH_THREADS) {
+                const int r = e / nin, k = e - r * nin;
+                if (row0 + r < M) {
+                    const uint32_t ab = s_ab[r];
+                    const bool set = k < P - 1 ? ((ab >> k) & 1u) : ((ab >> (16 + k - (P - 1))) & 1u);
+                    save.x[(row0 + r) * save.x_ld + k] = set ? 1.0f : -1.0f;
+                }
+            }
+        }
+        ws_writeback4<RB, SAVE, CBT, 0>(planes, ldh, acc0, bvs0, (cb0 >> 2) * 64 + 4 * m, lane, save.act[0], save.act_ld[0], row0, M, sc);
+    }
+    asm volatile("" ::"v"(warm0), "v"(warm1));
+    __syncthreads();
+    NAQS_MARK(5);
+
+    // the big layer: matrix waves | amplitude waves
+    sc.c = scales->c[1]; sc.sn = scales->sn[1]; sc.isn = scales->isn[1];
+    const int N1 = d.N_pad[1], Kh1 = d.Kh_pad[1];
+    if (wave < WS_MW) {
+        f32x4 acc[RB][WS_NCT];
+        float bvs[WS_NCT];
+        if (flags & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = 0; c < WS_NCT; ++c) acc[rb][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int cb0 = wave * WS_NCT;
+        const float *bias = w + d.b_off[1];
+#pragma unroll
+        for (int c = 0; c < WS_NCT; ++c) bvs[c] = bias[tile_col(cb0 + c, m, N1)] * sc.sn;
+        // (developer aid: bits 4 / 8 skip the amplitude / the matrix work, 16 / 32 the MFMAs / the stream — timing only, wrong results)
+        const ushort_t *a_ptr = planes + m * ldh + 8 * kg, *w_ptr = wh + d.wh_off[1] + (size_t)cb0 * Kh1 * 16 + lane * 8;
+        if (flags & 8) {}
+#ifdef NAQS_WS_DEBUG
+        else if (flags & 16) ws_accumulate<RB, 1>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
+        else if (flags & 32) ws_accumulate<RB, 2>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
+#endif
+        else ws_accumulate<RB>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
+        if (flags & 1) __builtin_amdgcn_s_setprio(0);
+        NAQS_MARK(9);
+        // the output layer (512 -> 4) straight from the accumulators, in f32: h = max(acc c + sn b, 0) is sn x the hidden
+        // activation; this lane holds it for 12 RB / 3 rows x 8 columns (two groups of four adjacent ones) and adds its
+        // columns' products with the four output rows of W (plain row-major f32, packed by pack_net_kernel); the 16 lanes of
+        // a row then add up (four DPP exchanges), and the four matrix waves' partial rows meet in LDS — fixed order
+        // throughout.  No write-back of the 512-wide activations, no second pass over them, no barrier in between.
+        const float *W2 = w + d.w_off[2];
+        const int K2 = d.K_pad[2];
+        const int g0 = cb0 >> 2;
+        f32x4 wv[2][4];                                                    // [group][output]: four adjacent columns each
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wv[g][o] = *reinterpret_cast<const f32x4 *>(W2 + (size_t)o * K2 + (g0 + g) * 64 + 4 * m);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rb * 16 + kg * 4 + r;
+                float po[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float h[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) h[c] = fmaxf(fmaf(acc[rb][4 * g + c][r], sc.c, bvs[4 * g + c]), 0.0f);
+                    if (SAVE && save.act[1] != nullptr && row0 + row < M)
+                        *reinterpret_cast<f32x4 *>(save.act[1] + (row0 + row) * save.act_ld[1] + (g0 + g) * 64 + 4 * m) =
+                            (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn};
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) po[o] = fmaf(h[c], wv[g][o][c], po[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float v = po[o];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+                    po[o] = v;
+                }
+                if (m == 0) *reinterpret_cast<f32x4 *>(&s_part[wave][row][0]) = (f32x4){po[0], po[1], po[2], po[3]};
+            }
+    } else {
+        if (flags & 2) __builtin_amdgcn_s_setprio(1);
+        if ((flags & 4) || wamp == nullptr) {}
+        else if (ha64) ws_amp_work<4, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f4, aw, lane, save.clk, wave);
+        else ws_amp_work<2, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f2, aw, lane, save.clk, wave);
+        if (flags & 2) __builtin_amdgcn_s_setprio(0);
+    }
+    NAQS_MARK(10);
+    __syncthreads();                                      // the output partials and s_lan are complete
+    NAQS_MARK(6);
+
+    if (tid < BM) {
+        const int64_t i = row0 + tid;
+        if (i < M) {
+            float la = 0.0f;
+            if (wamp != nullptr) for (int n = 0; n < P; ++n) la += s_lan[n][tid];      // fixed order: block 0..P-1
+            else for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + i];
+            const uint32_t ab = s_ab[tid];
+            const int occ = (int)((ab >> (P - 1)) & 1u) + 2 * (int)((ab >> (16 + P - 1)) & 1u);
+            const float ph = fmaf((s_part[0][tid][occ] + s_part[1][tid][occ]) + (s_part[2][tid][occ] + s_part[3][tid][occ]), sc.isn,
+                                  (w + d.b_off[2])[occ]);
+            out[i] = make_float2(la, ph);
+            if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
+        }
+    }
+    NAQS_MARK(7);
+}
+
 // the weight maxima the f16x2 scales are derived from: per phase layer max |W|, max_j sum_k |W[j][k]|, max |b| — one wave per
 // row (a 512 x 512 layer: 512 waves, one load round trip each), per-workgroup partials stored plainly
 struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
@@ -1270,9 +1647,17 @@ __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, 
                                                 const int fmt, const naqs::PhaseRaw *__restrict__ raw) {
     const float *src = flat + jobs.src_off[l];
     if (with_f32) pack_phase_f32(src, jobs.K[l], jobs.N[l], d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l]);
-    else {                                              // the split kernels only need the (padded) bias from this buffer
+    else {                                              // the split kernels only need the (padded) bias from this buffer ...
         for (int n = blockIdx.x * 256 + threadIdx.x; n < d.N_pad[l]; n += gridDim.x * 256)
             w[d.b_off[l] + n] = n < jobs.N[l] ? src[jobs.N[l] * jobs.K[l] + n] : 0.0f;
+        // ... and phase_kernel_ws the output layer as plain row-major f32 [N_pad][K_pad] (it multiplies by it on the VALU)
+        if (l == d.n_lin - 1) {
+            const int Kp = d.K_pad[l], total = d.N_pad[l] * Kp;
+            for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+                const int n = e / Kp, k = e - n * Kp;
+                w[d.w_off[l] + e] = (n < jobs.N[l] && k < jobs.K[l]) ? src[n * jobs.K[l] + k] : 0.0f;
+            }
+        }
     }
     if (fmt == 2) pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l));
     else pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
@@ -1465,6 +1850,11 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
             NAQS_PH_ATTR(1, 1) NAQS_PH_ATTR(2, 1) NAQS_PH_ATTR(3, 1)
             NAQS_PH_ATTR(1, 2) NAQS_PH_ATTR(2, 2) NAQS_PH_ATTR(3, 2) NAQS_PH_ATTR(4, 2)
 #undef NAQS_PH_ATTR
+#define NAQS_WS_ATTR(RB)                                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all);
+            NAQS_WS_ATTR(1) NAQS_WS_ATTR(2) NAQS_WS_ATTR(3)
+#undef NAQS_WS_ATTR
             (void)hipGetLastError();            // a refused attribute must not stay behind as the runtime's "last error"
         }
         if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
@@ -1743,17 +2133,43 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the split kernels only
     if (!use_h && !net->packed_f32) return NAQS_ERR_INVALID;
+    // wave-specialised form (phase_kernel_ws): the published shape in the f16x2 format, tiles of up to 48 rows
+    const bool ws_shape = fmt == 2 && d.n_lin == 3 && d.N_pad[0] == PH_WAVES * CBT * 16 && d.N_pad[1] == WS_MW * WS_NCT * 16 &&
+                          d.Kh_pad[0] == 32 && d.N_pad[2] == 16 && (d.Ha == 64 || d.Ha == 32) && CBT == 4 && PH_WAVES == 8;
+    const int ws_mode = naqs::env_int("NAQS_PHASE_WS", 1);
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
     if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
+    bool ws = ws_shape && ws_mode != 0;
+    if (ws) {
+        const int rb_ws = std::min(rb, 3);
+        if (rb_ws * lds_h16 + (size_t)d.P * rb_ws * 16 * 8 * sizeof(float) > 155 * 1024) ws = false;
+        else rb = rb_ws;
+    }
     const int bm = rb * 16;
     const unsigned grid = (unsigned)((M + bm - 1) / bm);
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
-    if (use_h) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_h<RB=%d, SAVE=%d, FMT=%d (%s)>%s", rb, save.x != nullptr ? 1 : 0,
+    if (ws) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_ws<RB=%d, SAVE=%d> (f16x2%s)", rb,
+                          save.x != nullptr ? 1 : 0, amp_in_phase ? ", amplitude waves beside the matrix waves" : "");
+    else if (use_h) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_h<RB=%d, SAVE=%d, FMT=%d (%s)>%s", rb, save.x != nullptr ? 1 : 0,
                              fmt, fmt == 2 ? "f16x2" : "bf16x3", amp_in_phase ? " incl. amplitude prologue" : "");
     else std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel<RB=%d> (f32 MFMA)", rb);
-    if (use_h) {
+    if (ws) {
+        const size_t lds = rb * lds_h16 + (size_t)d.P * bm * 8 * sizeof(float);
+        const int flags = naqs::env_int("NAQS_WS_FLAGS", 0);
+#define NAQS_WS_LAUNCH(RB)                                                                                                              \
+        do {                                                                                                                            \
+            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_ws<RB, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags); \
+            else hipLaunchKernelGGL((phase_kernel_ws<RB, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags); \
+        } while (0)
+        switch (rb) {
+            case 1: NAQS_WS_LAUNCH(1); break;
+            case 2: NAQS_WS_LAUNCH(2); break;
+            default: NAQS_WS_LAUNCH(3); break;
+        }
+#undef NAQS_WS_LAUNCH
+    } else if (use_h) {
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
 #define NAQS_PH_LAUNCH(RB, FMT)                                                                                                         \
         do {                                                                                                                            \
