@@ -53,9 +53,17 @@ PMC_TRAFFIC = "profiles/r03_pmc_traffic.json"
 PMC_ISSUE = "profiles/r03_pmc_issue.json"
 
 
-def phase_format():
-    """Split format of the log-psi kernel (NAQS_PHASE_MODE, default 2): 2 = f16x2 (three f16 MFMA products per f32
-    product), 1 = bf16x3 (six bf16 products), 0 = exact-f32 MFMA."""
+def phase_format(kernel_name=None):
+    """Split format of the log-psi kernel: 2 = f16x2 (three f16 MFMA products per f32 product), 1 = bf16x3 (six bf16
+    products), 0 = exact-f32 MFMA.  Read from the name of the kernel that RAN (`naqs_net_last_kernel`: the library falls back
+    to the f32 kernel when a split format's planes do not fit the LDS); NAQS_PHASE_MODE (default 2) only before any launch."""
+    if kernel_name:
+        if "f16x2" in kernel_name:
+            return 2
+        if "bf16x3" in kernel_name:
+            return 1
+        if "f32 MFMA" in kernel_name:
+            return 0
     return int(os.environ.get("NAQS_PHASE_MODE", "2"))
 
 
@@ -111,7 +119,7 @@ def logpsi_flops(n_qubits, M, amp_in_kernel=True):
     return f
 
 
-def logpsi_executed_flops(n_qubits, M, fmt=None):
+def logpsi_executed_flops(n_qubits, M, fmt=None, out_layer_on_valu=False):
     """16-bit flops the matrix cores execute for the same launch.  f16x2 (fmt 2): every f32 product is three f16 products
     (two where one operand is exact in f16: the +-1 / 0 inputs of the phase MLP's first layer and of the amplitude blocks'
     first layer); bf16x3 (fmt 1): six (three) bf16 products in the phase MLP — the amplitude blocks are f16x2 in both."""
@@ -119,7 +127,8 @@ def logpsi_executed_flops(n_qubits, M, fmt=None):
     full, exact = (3, 2) if fmt == 2 else (6, 3)
     P = n_qubits // 2
     dims = [max(1, 2 * (P - 1)), 512, 512, 4]
-    f = 2.0 * M * (exact * dims[0] * dims[1] + full * dims[1] * dims[2] + full * dims[2] * dims[3])
+    # phase_kernel_ws forms the 512 -> 4 output layer from the accumulators with f32 FMAs: not matrix-core work
+    f = 2.0 * M * (exact * dims[0] * dims[1] + full * dims[1] * dims[2] + (0 if out_layer_on_valu else full * dims[2] * dims[3]))
     f += 2.0 * M * sum(2 * max(1, 2 * n) * 64 + 3 * 64 * 5 for n in range(P))
     return f
 
@@ -496,13 +505,13 @@ def logpsi_roofline(kernel_name, t_s, n_qubits, rows, amp_in_kernel, t_isolated_
     """`frac` is what the silicon does: executed 16-bit flops (three f16 MFMA products per f32 product in the f16x2 split,
     six bf16 ones in bf16x3) against the dense bf16/f16 MFMA peak.  The algorithmic view — the network's f32 flops against
     the f32-MFMA peak, the rate an exact-f32 kernel could reach at most — is kept under `f32_equivalent`; it may exceed 1."""
-    fmt = phase_format()
+    fmt = phase_format(kernel_name)
     flops = logpsi_flops(n_qubits, rows, amp_in_kernel)
     tf = flops / t_s / 1e12 if t_s > 0 else 0.0
     if fmt == 0:
         return {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                 "traffic": None, "kernel": kernel_name, "kernel_us": t_s * 1e6, "algorithmic_flops_per_launch": flops}
-    exec_flops = logpsi_executed_flops(n_qubits, rows, fmt) if amp_in_kernel else flops
+    exec_flops = logpsi_executed_flops(n_qubits, rows, fmt, "phase_kernel_ws" in (kernel_name or "")) if amp_in_kernel else flops
     etf = exec_flops / t_s / 1e12 if t_s > 0 else 0.0
     roof = {"bound": "mfma", "achieved": etf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": etf / MFMA_BF16_PEAK_TF,
             "traffic": None, "dtype_executed": ("f16" if fmt == 2 else "bf16") + " (f32 accumulate)", "kernel": kernel_name,
@@ -515,8 +524,8 @@ def logpsi_roofline(kernel_name, t_s, n_qubits, rows, amp_in_kernel, t_isolated_
     return roof
 
 
-def dtype_label():
-    fmt = phase_format()
+def dtype_label(kernel_name=None):
+    fmt = phase_format(kernel_name)
     net = {2: "f16x2-split MFMA, f32-equivalent", 1: "bf16x3-split MFMA, f32-equivalent", 0: "f32 MFMA"}[fmt if fmt in (0, 1, 2) else 2]
     return f"f32 network ({net}) / f64 E_loc"
 
@@ -690,10 +699,11 @@ def worker(args):
     if rank == 0:
         t_kernel = kern_ms / max(launches, 1) * 1e-3
         t_mlp = mlp_ms / max(mlp_launches, 1) * 1e-3
-        amp_in_kernel = os.environ.get("NAQS_AMP_MODE", "1") == "1" and phase_format() >= 1
+        lp_name = nets[0].last_kernel()
+        amp_in_kernel = "amplitude" in lp_name                            # the kernel's own name says whether the items ran inside it
         eloc_roof = eloc_roofline(ham.last_kernel(), t_kernel, M, ham.K, ham.Kxy, f"{args.molecule}_{M}",
                                   serial["eloc_kernel_us"] * 1e-6 if serial and serial["eloc_kernel_us"] > 0 else None)
-        mlp_roof = logpsi_roofline(nets[0].last_kernel(), t_mlp, ham.n_qubits, M, amp_in_kernel,
+        mlp_roof = logpsi_roofline(lp_name, t_mlp, ham.n_qubits, M, amp_in_kernel,
                                    serial["logpsi_kernel_us"] * 1e-6 if serial and serial["logpsi_kernel_us"] > 0 else None)
         # HBM bytes per launch: hardware counters, from the committed rocprofv3 --pmc passes of this same command
         # (tools/collect_pmc.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 corrections applied there) — replayed only
@@ -714,7 +724,7 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype_label(), "data": "synthetic",
+            "dtype": dtype_label(lp_name), "data": "synthetic",
             "config": {"workload": f"{args.molecule} STO-3G ({ham.n_qubits} qubits, K={ham.K} Pauli terms, "
                                    f"Kxy={ham.Kxy}), {M} unique samples per GPU, 1xMI355X per rank",
                        "stages": "fused NADE log-psi eval (amp 1x64, phase 2x512; builds the key hash + psi table) + matrix-free E_loc "
@@ -754,7 +764,8 @@ def sharded_main(args, dev, world, rank, use_dist):
         eloc_roof = eloc_roofline(res.pop("eloc_kernel_name", "eloc_kernel2"), t_eloc, rows, K, Kxy,
                                   f"{args.molecule}_{args.samples}" if world == 1 else None, None)
         res.pop("eloc_issue", None)
-        mlp_roof = logpsi_roofline(res.pop("logpsi_kernel_name", "phase_kernel_h"), t_lp, ham_p.n_qubits, S, True, None)
+        lp_name = res.pop("logpsi_kernel_name", "phase_kernel_h")
+        mlp_roof = logpsi_roofline(lp_name, t_lp, ham_p.n_qubits, S, "amplitude" in lp_name, None)
         dominant, other = (mlp_roof, eloc_roof) if t_lp >= t_eloc else (eloc_roof, mlp_roof)
         roofline = dict(dominant)
         roofline["other_kernels"] = [other]
@@ -762,7 +773,7 @@ def sharded_main(args, dev, world, rank, use_dist):
                          f"row-sharded table",
                "value": res["value"], "unit": "unique samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": dtype_label(), "data": "synthetic",
+               "dtype": dtype_label(lp_name), "data": "synthetic",
                "config": {"workload": res["workload"], "collectives_per_step": res["collectives_per_step"],
                           "ranks": (f"{dist.get_world_size()} {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} rank(s)"
                                     if use_dist else "single process, no process group"),

@@ -1614,6 +1614,13 @@ __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__
                                                        float *__restrict__ w) {
     pack_amp_body(flat, d, so, w, blockIdx.y);
 }
+// the amplitude blocks alone (naqs_net_set_amp_weights): the VALU rows (blockIdx.z = 0) and the matrix-core fragments (1) in
+// one launch, so that the sampler takes the same form of the block MLPs whichever call packed the weights last
+__global__ __launch_bounds__(256) void pack_amp_both_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
+                                                            float *__restrict__ w, ushort_t *__restrict__ wamp) {
+    if (blockIdx.z == 0) pack_amp_body(flat, d, so, w, blockIdx.y);
+    else pack_amp_mfma_body(flat, d, so, wamp, blockIdx.y);
+}
 // aggregate_phase: both sets of per-pair blocks (blockIdx.z = 0, 1) and, when they exist, the amplitude blocks' matrix-core
 // fragments (2) in one launch
 __global__ __launch_bounds__(256) void pack_amp2_kernel(const float *__restrict__ flat, const NetDims d0, const AmpSrcOff so0,
@@ -1924,8 +1931,21 @@ static int pack_amp_blocks(naqs_net_t *net, const float *flat_dev, hipStream_t s
     net->wamp_fresh = false;
     return pack_blocks(net->dims, net->amp_src_off, net->d_w, flat_dev, s);
 }
-// the amplitude blocks as MFMA fragments (naqs_net_set_weights only: the sampler's naqs_net_set_amp_weights keeps to the
-// VALU rows, and net_amp_forward falls back to amp_kernel while the fragments are stale)
+// rows + fragments of the amplitude blocks in one launch (naqs_net_set_amp_weights)
+static int pack_amp_both(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
+    if (!net->d_wamp) return pack_amp_blocks(net, flat_dev, s);
+    const NetDims &d = net->dims;
+    AmpSrcOff so;
+    for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
+    const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
+    const int total_max = std::max(d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8, frag);
+    net->wamp_fresh = false;
+    hipLaunchKernelGGL(pack_amp_both_kernel, dim3((total_max + 255) / 256, d.P, 2), dim3(256), 0, s, flat_dev, d, so, net->d_w, net->d_wamp);
+    HIP_TRY(hipGetLastError());
+    net->wamp_fresh = true;
+    return NAQS_OK;
+}
+// the amplitude blocks as MFMA fragments alone (the aggregate-phase family's unmerged path)
 static int pack_amp_fragments(naqs_net_t *net, const float *flat_dev, hipStream_t s) {
     if (!net->d_wamp) return NAQS_OK;
     const NetDims &d = net->dims;
@@ -1945,7 +1965,9 @@ NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, in
     if (st != NAQS_OK) return st;
     net->have_weights = net->have_wb = false;   // the packed phase layers no longer belong to these parameters
     net->have_amp_weights = false;
-    st = pack_amp_blocks(net, flat_dev, reinterpret_cast<hipStream_t>(stream));
+    // rows AND fragments: the sampler picks the matrix-core form of the block MLPs whenever the fragments are current, and the
+    // two forms round differently — the same (parameters, seed) must not draw differently depending on which call packed last
+    st = pack_amp_both(net, flat_dev, reinterpret_cast<hipStream_t>(stream));
     if (st != NAQS_OK) return st;
     net->have_amp_weights = true;
     return NAQS_OK;

@@ -21,7 +21,9 @@
 // matrices live in zero-padded buffers whose leading dimensions are multiples of 64, so there is no edge code.
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <thread>
 
 #include "naqs_common.hpp"
 #include "naqs_hash.hpp"
@@ -581,24 +583,39 @@ NAQS_API int naqs_net_train_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64
 // short spin; waking up costs tens of microseconds during which the GPU has nothing to do): it sees them about a
 // microsecond after the store and queues the forward pass while the sampler's last launches are still running.
 // NAQS_SPIN_WAIT=0: wait for the stream instead.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
 static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
-                           int64_t *counts_dev, float *probs_dev, double *weights_dev, hipStream_t s, int64_t out[2]) {
+                           int64_t *counts_dev, float *probs_dev, double *weights_dev, hipStream_t s, int64_t out[2],
+                           int64_t *info_dev = nullptr) {
+    // info_dev: where the sampler leaves its plain (M, overflow) words on the device (default: the handle's own two words)
     static const bool spin = [] { const char *e = getenv("NAQS_SPIN_WAIT"); return !e || atoi(e) != 0; }();
     int st0 = naqs::net_info_alloc(net);
     if (st0 != NAQS_OK) return st0;
     const int64_t seq = ++net->info_seq;
-    int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, net->d_info2, s,
+    int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev,
+                                    info_dev ? info_dev : net->d_info2, s,
                                     net->d_info_alias, seq);
     if (st != NAQS_OK) return st;
     volatile int64_t *h = net->h_info;
     if (spin) {
+        // bounded: after ~2 s of polling (a sampler call is < 1 ms) the wait falls back to the stream's own completion signal
+        const auto t0 = std::chrono::steady_clock::now();
         for (uint64_t it = 1; h[2] != seq; ++it) {
             if ((it & 0x3FFF) == 0) {                      // every ~0.2 ms: is the stream still alive?
                 const hipError_t q = hipStreamQuery(s);
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) return NAQS_ERR_HIP;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIP_TRY(hipStreamSynchronize(s)); break; }
             }
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {
@@ -622,10 +639,14 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // (M, overflow) land in host memory the sampler writes to directly (mapped, coherent): no copy launch between the sampler
     // and the synchronisation, nothing but the synchronisation between the sampler and the forward pass
-    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info_host);
+    // (info_dev receives the same (M, overflow) on the device, in stream order: the sampler writes it)
+    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info_host, info_dev);
     if (st != NAQS_OK) return st;
-    (void)info_dev;
-    if (info_host[1] != 0 || info_host[0] <= 0) return NAQS_OK;
+    if (info_host[1] != 0 || info_host[0] <= 0) {
+        // nothing was evaluated (overflow, or an empty draw): the sums read as an empty table, not as whatever was there
+        HIP_TRY(hipMemsetAsync(out4_dev, 0, 4 * sizeof(double), s));
+        return NAQS_OK;
+    }
     return naqs_net_train_forward_eloc(net, ham, info_host[0], keys_dev, weights_dev, logpsi_dev, eloc_dev, out4_dev, stream);
 }
 

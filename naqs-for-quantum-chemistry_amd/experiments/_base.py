@@ -147,6 +147,16 @@ def _broadcast_parameters(wavefunction):
         wavefunction.parameters_changed()
 
 
+def open_shell_amp_spin_sym(n_alpha, n_beta, use_amp_spin_sym):
+    """The reference's rule (experiments/_base.py:110-114, restrict_to_ms=True): m_s = |n_alpha - n_beta| // 2; only m_s != 0
+    switches the amplitude spin symmetry off (and says so).  Integer division: a doublet has m_s == 0 and keeps the flag."""
+    m_s = abs(int(n_alpha) - int(n_beta)) // 2
+    if m_s != 0:
+        print("S!=0 and we are restricting ourselves to ms=S --> turning off use_amp_spin_sym as this is not helpful.")
+        return False
+    return use_amp_spin_sym
+
+
 def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretrained_model_loc, continue_experiment,
          reset_optimizer, qubit_ordering, masking, lr, lr_lut, n_samps, n_samps_max, n_unq_samps_min, n_unq_samps_max,
          reweight_samples_by_psi, n_train, n_pretrain, output_freq, save_freq, n_lut, n_hid, n_layer, n_hid_phase,
@@ -166,12 +176,12 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
         print(f"\nRunning experiment {i + 1}/{num_experiments}")
         exp_name_i = exp_name + (f"_{i}" if num_experiments > 1 else "")
         n_alpha, n_beta = molecule.get_n_alpha_electrons(), molecule.get_n_beta_electrons()
-        if n_alpha != n_beta:
-            # open shell: the reference restricts to m_s = S (restrict_to_ms=True is not a command-line option,
-            # experiments/_base.py:72, :101-123) — the same (n_alpha, n_beta)-restricted space with n_alpha != n_beta — and
-            # switches the amplitude spin symmetry off, which assumes interchangeable spin sectors
-            print("S!=0 and we are restricting ourselves to ms=S --> turning off use_amp_spin_sym as this is not helpful.")
-            use_amp_spin_sym = False
+        # open shell: the reference restricts to m_s = S (restrict_to_ms=True is not a command-line option,
+        # experiments/_base.py:72, :101-123) — the same (n_alpha, n_beta)-restricted space with n_alpha != n_beta — and
+        # switches the amplitude spin symmetry off when m_s = |n_alpha - n_beta| // 2 is non-zero (:110-114).  A doublet
+        # (|n_alpha - n_beta| == 1: m_s == 0 in the reference's integer arithmetic) keeps the caller's use_amp_spin_sym,
+        # exactly like the reference — same ansatz, interchangeable checkpoints.
+        use_amp_spin_sym = open_shell_amp_spin_sym(n_alpha, n_beta, use_amp_spin_sym)
         print("\n--- Initialising Hilbert ---\n")
         hilbert = Hilbert.get(N=N, N_alpha=n_alpha, N_beta=n_beta, encoding=Encoding.SIGNED, make_basis=True,
                               verbose=verbose)

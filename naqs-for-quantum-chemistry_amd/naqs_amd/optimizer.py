@@ -144,6 +144,13 @@ class OptimizerBase:
         self.use_fused = True                # HIP sampler / training kernels / FlatAdam when the network supports them
         self._loss_terms = self._last_loss = None
         self._shard_mismatch = None
+        # multi-GPU policy: below `shard_min_rows` rows per rank every kernel of the step is launch-bound and the
+        # sharded step's extra launches and collectives cost more than they save, so every rank then runs the IDENTICAL
+        # single-GPU step (same seed, same parameters, deterministic kernels: bit-identical updates, no collectives) and the
+        # ranks only prove every `replica_proof_every` steps that they still hold the same table.
+        self.shard_min_rows = int(os.environ.get("NAQS_SHARD_MIN_ROWS", "4096"))
+        self.replica_proof_every = int(os.environ.get("NAQS_REPLICA_PROOF_EVERY", "64"))
+        self._dist_mode, self._last_M, self.dist_mode_log = None, None, []
         self.reset_log()
         self.reset_optimizer()
 
@@ -165,8 +172,12 @@ class OptimizerBase:
         ring = getattr(self, "_sampled_ring", None)
         if ring is None or ring.numel() < 2 * cap:
             self._flush_sampled_idxs()
-            ring = self._sampled_ring = torch.empty(max(int(getattr(self, "sampled_ring_elems", 1 << 25)), 2 * cap), dtype=torch.int64,
-                                                    device=self.device)
+            # sized from the problem: 64 steps' worth of the largest table the sampler may return (51 MB at the published
+            # n_unq_samples_max = 1e5), never more than 2^25 keys (268 MB), never less than two slots.  ``_sample_keys`` is
+            # a view into this buffer: valid until the next step's sampler runs (a fold resets the write offset).
+            elems = getattr(self, "sampled_ring_elems", None)
+            elems = min(1 << 25, 64 * cap) if elems is None else int(elems)
+            ring = self._sampled_ring = torch.empty(max(elems, 2 * cap), dtype=torch.int64, device=self.device)
             self._sampled_ring_off = 0
         if self._sampled_ring_off + cap > ring.numel():
             self._flush_sampled_idxs()
@@ -221,6 +232,50 @@ class OptimizerBase:
         if bad is not None and bool(bad.item()):
             raise RuntimeError("distributed VMC step: the ranks sampled different tables (sample count or key checksum "
                                "differs across ranks) — seed every rank identically and broadcast the parameters")
+
+    # ---- multi-GPU policy ----
+    def _active_dist(self):
+        """torch.distributed when THIS step shards its table over the ranks, else None (single process, or a step every rank
+        replicates: ``_choose_dist_mode``)."""
+        return _dist() if getattr(self, "_dist_mode", None) == "sharded" else None
+
+    def _choose_dist_mode(self):
+        """'single' | 'replicated' | 'sharded' for the next step, from the unique-sample count of the LAST step (the same on
+        every rank: they all drew the same table) — the count moves slowly, and the decision has to be made before sampling
+        because the replicated step is one library call that includes the sampler.  The first step replicates."""
+        dist = _dist()
+        if dist is None:
+            mode = "single"
+        else:
+            world = dist.get_world_size()
+            rows = (self._last_M // world) if self._last_M is not None else 0
+            mode = "sharded" if rows >= self.shard_min_rows else "replicated"
+        if mode != self._dist_mode:
+            if dist is not None:
+                self.dist_mode_log.append((self.n_steps, mode))
+                if dist.get_rank() == 0:
+                    what = ("row-sharded step (all-gather of log psi shards, all-reduce of accumulators and gradient)"
+                            if mode == "sharded" else "every rank runs the identical single-GPU step (no collectives)")
+                    print(f"\tdistributed step at epoch {self.n_epochs}: {self._last_M} unique samples over "
+                          f"{dist.get_world_size()} ranks, shard_min_rows={self.shard_min_rows} --> {what}")
+            self._dist_mode = mode
+            self._onecall_cached = None
+        return mode
+
+    def _replica_proof(self, keys):
+        """Replicated steps: every `replica_proof_every` steps one 32-byte all-reduce of (M, M^2, c, c^2), c = 20 low bits of
+        the key sum — W * sum x^2 == (sum x)^2 iff all ranks hold the same x (exact integers in float64).  A mismatch is
+        reported at the next log flush, like the sharded step's proof."""
+        dist = _dist()
+        if dist is None or self.replica_proof_every <= 0 or self.n_steps % self.replica_proof_every != 0:
+            return
+        world = dist.get_world_size()
+        c = (keys.sum() & 0xFFFFF).double()
+        m = torch.tensor(float(keys.shape[0]), dtype=torch.float64, device=self.device)
+        ext = torch.stack([m, m * m, c, c * c])
+        dist.all_reduce(ext)
+        bad = ~((world * ext[1] == ext[0] * ext[0]) & (world * ext[3] == ext[2] * ext[2]))
+        self._shard_mismatch = bad if self._shard_mismatch is None else self._shard_mismatch | bad
 
     def reset_log(self):
         self._pending_log = []
@@ -347,7 +402,10 @@ class OptimizerBase:
                   regularisation_loss=None, n_samps=None, e_loc_clip_factor=None, lazy=False):
         """One VMC step for the sampled states (energy.py:273-377): E_loc (no grad) -> loss
         2 Re sum w log psi (E_loc - <E>) -> backward -> optimiser step -> (<E>, Var)."""
-        dist = _dist()
+        if not getattr(self, "_in_run", False):           # called outside run(): the policy decides from the table at hand
+            self._last_M = int(keys_to_device(states_idx, self.device).shape[0])
+            self._choose_dist_mode()
+        dist = self._active_dist()
         world, rank = (dist.get_world_size(), dist.get_rank()) if dist else (1, 0)
         keys = keys_to_device(states_idx, self.device)
         M = keys.shape[0]
@@ -575,7 +633,7 @@ class PartialSamplingOptimizer(OptimizerBase):
     def _can_prefuse(self):
         """The conditions under which _SGD_step takes its single-GPU fused branch (forward + E_loc in one call) — known
         before sampling, so that the sampler's call can include them."""
-        if not self.use_fused or _dist() is not None or self.normalize_grads or self.bug_compat_full_sample_order:
+        if not self.use_fused or self._active_dist() is not None or self.normalize_grads or self.bug_compat_full_sample_order:
             return False
         if os.environ.get("NAQS_TRAIN_FUSED_ELOC", "1") != "1" or os.environ.get("NAQS_TRAIN_PREFUSE", "1") != "1":
             return False
@@ -723,9 +781,22 @@ class PartialSamplingOptimizer(OptimizerBase):
         print("Training NAQS energy.  Samples will be weighted by their frequency.")
         if self.n_steps == 0:
             self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=False)
-        onecall = self._can_onecall()
+        self._in_run = True
+        try:
+            self._run_epochs(n_epochs, save_freq, output_freq, run_time_at_last_log, steps_at_last_log)
+        finally:
+            self._in_run = False
+        self._flush_log()
+        if save_final:
+            self.save(quiet=False)
+
+    def _run_epochs(self, n_epochs, save_freq, output_freq, run_time_at_last_log, steps_at_last_log):
         for _ in range(n_epochs):
             t0 = time.time()
+            self._choose_dist_mode()                 # multi-GPU: replicate or shard this step (resets the cache on a switch)
+            onecall = getattr(self, "_onecall_cached", None)
+            if onecall is None:
+                onecall = self._onecall_cached = self._can_onecall()
             if onecall:
                 counts, weights, ev = self._onecall_step()
             else:
@@ -736,6 +807,9 @@ class PartialSamplingOptimizer(OptimizerBase):
                 # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU
                 ev = self._SGD_step(states, keys, None, sample_weights=weights, lazy=True)
             self.n_steps += 1
+            self._last_M = len(weights)
+            if self._dist_mode == "replicated":
+                self._replica_proof(self._sample_keys)
             self.run_time += time.time() - t0
             self._pending_log.append((self.n_steps, ev, len(weights), self.run_time))
             self.n_epochs += 1
@@ -758,6 +832,3 @@ class PartialSamplingOptimizer(OptimizerBase):
                       f"var(<E_loc>)={var:.5f}, epoch time={tpe:.2f}s, total time={self.run_time:.1f}s")
             if save_freq is not None and self.n_epochs % save_freq == 0:
                 self.save(os.path.join(self.save_loc, f"opt_{self.n_steps}steps"), quiet=True)
-        self._flush_log()
-        if save_final:
-            self.save(quiet=False)

@@ -48,7 +48,7 @@ assert wf.fused() is not None, "the HIP path must be the one under test"
 opt.run(n_steps, output_freq=10 ** 6)
 energies = [x[1] for x in opt.log[LogKey.E_LOC]]
 params = torch.cat([p.detach().reshape(-1) for p in wf.model.parameters()]).cpu()
-torch.save({"energies": energies, "params": params}, out)
+torch.save({"energies": energies, "params": params, "dist_modes": list(opt.dist_mode_log)}, out)
 if backend != "none":
     dist.barrier()
     dist.destroy_process_group()

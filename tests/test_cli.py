@@ -118,3 +118,17 @@ def test_farm_mode_gives_each_rank_its_own_molecule(tmp_path, monkeypatch, capsy
     monkeypatch.setenv("RANK", "2")                            # more ranks than molecules: nothing to do
     monkeypatch.setenv("WORLD_SIZE", "3")
     assert _base.run(argv=common) == []
+
+
+def test_open_shell_rule_follows_the_reference_integer_arithmetic(capsys):
+    """experiments/_base.py:110-114 of the reference: m_s = |n_alpha - n_beta| // 2 and only m_s != 0 switches the amplitude
+    spin symmetry off.  A doublet (one unpaired electron) has m_s == 0 there and keeps the caller's flag — the ansatz, and
+    with it the checkpoint format, must not differ from the reference's for those inputs."""
+    sys.path.insert(0, PKG)
+    from experiments._base import open_shell_amp_spin_sym
+    for (na, nb), want_true in (((3, 3), True), ((4, 3), True), ((3, 4), True), ((5, 3), False), ((3, 5), False), ((6, 3), False)):
+        m_s = np.abs(na - nb) // 2                                   # the reference's expression
+        assert open_shell_amp_spin_sym(na, nb, True) is (not (m_s != 0)) is want_true, (na, nb)
+        assert open_shell_amp_spin_sym(na, nb, False) is False
+    out = capsys.readouterr().out
+    assert out.count("turning off use_amp_spin_sym") == 6            # printed for the three m_s != 0 sectors only (x2 calls)

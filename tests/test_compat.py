@@ -153,6 +153,7 @@ def _mismatch_worker(rank, world, port, tmp, out):
     oracle_backend.install(__import__("naqs_amd.optimizer").optimizer)
     from test_optimizer import make_opt
     z, hil, wf, opt = make_opt("LiH", os.path.join(tmp, f"r{rank}"), None, seed=11 + rank, n_samples=300)   # different generators
+    opt.shard_min_rows = 0                           # the sharded step (its proof rides in the accumulator all-reduce)
     states, counts, probs = opt.get_samples()
     keys = hil.state2idx(states).squeeze(-1)
     try:
@@ -160,7 +161,15 @@ def _mismatch_worker(rank, world, port, tmp, out):
         raised = False
     except RuntimeError as e:
         raised = "different tables" in str(e)
-    torch.save({"raised": raised, "M": len(keys)}, f"{out}.{rank}")
+    # the replicated step proves the same thing with its own small all-reduce every `replica_proof_every` steps
+    opt._shard_mismatch = None
+    opt.shard_min_rows, opt.replica_proof_every = 10 ** 9, 1
+    try:
+        opt.run(2, output_freq=10 ** 6)
+        raised_replicated = False
+    except RuntimeError as e:
+        raised_replicated = "different tables" in str(e)
+    torch.save({"raised": raised, "raised_replicated": raised_replicated, "M": len(keys)}, f"{out}.{rank}")
     dist.destroy_process_group()
 
 
@@ -187,3 +196,4 @@ def test_ranks_with_different_tables_are_detected(tmp_path):
     mp.spawn(_mismatch_worker, args=(2, _free_port(), str(tmp_path), out), nprocs=2, join=True)
     r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in range(2))
     assert r0["raised"] and r1["raised"], (r0, r1)
+    assert r0["raised_replicated"] and r1["raised_replicated"], (r0, r1)

@@ -94,7 +94,7 @@ def test_shard_bounds_tile():
             assert all(e - s == S for s, e in b if e < n) and all(e - s <= S for s, e in b)
 
 
-def _worker(rank, world, port, tmp, out):
+def _worker(rank, world, port, tmp, out, shard_min_rows=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "naqs-for-quantum-chemistry_amd")):
         if p not in sys.path:
@@ -105,6 +105,8 @@ def _worker(rank, world, port, tmp, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     oracle_backend.install(__import__("naqs_amd.optimizer").optimizer)
     z, hil, wf, opt = make_opt("LiH", os.path.join(tmp, f"r{rank}"), None, seed=11, n_samples=5000)
+    if shard_min_rows is not None:
+        opt.shard_min_rows = shard_min_rows          # 0: every distributed step shards (the branches under test)
     res = []
     for _ in range(3):
         states, counts, probs = opt.get_samples()
@@ -112,7 +114,7 @@ def _worker(rank, world, port, tmp, out):
         res.append(opt._SGD_step(states, keys, None, sample_weights=counts.double() / counts.sum().double()))
     params = torch.cat([p.detach().reshape(-1) for p in wf.model.parameters()])
     if rank == 0:
-        torch.save({"res": res, "params": params}, out)
+        torch.save({"res": res, "params": params, "modes": [m for _, m in opt.dist_mode_log]}, out)
     gathered = [torch.zeros_like(params) for _ in range(world)]
     dist.all_gather(gathered, params)
     assert all(torch.equal(g, gathered[0]) for g in gathered), "ranks diverged"
@@ -135,6 +137,24 @@ def test_two_process_step_equals_single_process(tmp_path):
     for (e1, v1), (e2, v2) in zip(outs[0]["res"], outs[1]["res"]):
         assert abs(e1 - e2) < 1e-6 * max(1, abs(e1)) and abs(v1 - v2) < 1e-5 * max(1, abs(v1))
     assert torch.max(torch.abs(outs[0]["params"] - outs[1]["params"])).item() < 2e-5
+    assert outs[1]["modes"] == ["sharded"]
+
+
+def test_two_process_step_below_the_break_even_is_replicated(tmp_path):
+    """The multi-GPU policy: LiH's table (a few dozen rows) is far below `shard_min_rows` rows per rank, so each of the two
+    ranks runs the whole single-process step — identical energies and parameters, bit for bit, and no gradient all-reduce."""
+    import torch.multiprocessing as mp
+    import socket
+    outs = []
+    for world in (1, 2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"p{world}.pt")
+        mp.spawn(_worker, args=(world, port, str(tmp_path / f"p{world}"), out, None), nprocs=world, join=True)
+        outs.append(torch.load(out, weights_only=False))
+    assert outs[0]["res"] == outs[1]["res"] and torch.equal(outs[0]["params"], outs[1]["params"])
+    assert outs[0]["modes"] == outs[1]["modes"] == ["replicated"]      # (world 1 runs inside a process group of one here)
 
 
 def test_one_call_loop_adapts_the_sample_count_like_get_samples(tmp_path, monkeypatch, capsys):

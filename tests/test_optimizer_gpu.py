@@ -169,13 +169,17 @@ def test_flat_adam_follows_param_group_edits_after_load_state_dict():
     assert abs(step() - 5e-5) < 1e-7
 
 
-def _run_workers(tmp_path, backend, world, port):
-    """Start ``world`` fresh child processes of tests/dist_step_worker.py on cuda:0 and collect what they wrote."""
+def _run_workers(tmp_path, backend, world, port, shard_min_rows=0, tag=""):
+    """Start ``world`` fresh child processes of tests/dist_step_worker.py on cuda:0 and collect what they wrote.
+    shard_min_rows = 0: every distributed step shards (the branches under test); None: the library's own policy."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    outs = [str(tmp_path / f"{backend}_{world}_{r}.pt") for r in range(world)]
+    env.pop("NAQS_SHARD_MIN_ROWS", None)
+    if shard_min_rows is not None:
+        env["NAQS_SHARD_MIN_ROWS"] = str(shard_min_rows)
+    outs = [str(tmp_path / f"{backend}{tag}_{world}_{r}.pt") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_step_worker.py"), backend, str(r), str(world),
                                str(port), outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
@@ -209,6 +213,18 @@ def test_distributed_step_on_one_gpu(tmp_path):
     d = np.abs(np.array(gloo2[0]["energies"]) - e0)
     assert d[:20].max() < 1e-6 and d.max() < 5e-3, d
     assert torch.max(torch.abs(gloo2[0]["params"] - single["params"])).item() < 2e-2
+
+
+def test_small_tables_are_replicated_not_sharded(tmp_path):
+    """The multi-GPU policy (`shard_min_rows`): H2O's tables have a few hundred rows — far below the break-even
+    of the sharded step — so with the default policy every rank runs the identical single-GPU step: gloo world 2 on one GPU
+    reproduces the single-process trajectory BIT FOR BIT (same launches, same seeds, no collective on the data path), the
+    ranks prove to each other that they hold the same table, and the log says which mode ran."""
+    single = _run_workers(tmp_path, "none", 1, 29586)[0]
+    gloo2 = _run_workers(tmp_path, "gloo", 2, 29587, shard_min_rows=None, tag="_policy")
+    assert gloo2[0]["energies"] == single["energies"] and gloo2[1]["energies"] == single["energies"]
+    assert torch.equal(gloo2[0]["params"], single["params"]) and torch.equal(gloo2[1]["params"], single["params"])
+    assert [m for _, m in gloo2[0]["dist_modes"]] == ["replicated"] and single["dist_modes"] == []
 
 
 def test_fused_kernels_follow_parameter_changes(tmp_path):
