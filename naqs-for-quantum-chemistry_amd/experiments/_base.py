@@ -12,6 +12,7 @@ like experiments/bash/naqs/N2_energy_surface.sh pins one run per CUDA_VISIBLE_DE
 """
 import argparse
 import os
+import threading
 import time
 
 import numpy as np
@@ -93,6 +94,13 @@ def get_parser(**overrides):
         p.add_argument(*flags, dest=dest, default=bool(default(k)), action="store_true", help=help_)
     p.add_argument("--farm", action="store_true",
                    help="one molecule of a comma-separated -m list per rank (no communication)")
+    p.add_argument("--per-gpu", dest="per_gpu", type=int, default=1,
+                   help="farm mode: independent runs sharing one GPU (rank r runs on device r // per_gpu)")
+    p.add_argument("--seeds", dest="seeds", type=str, default=None,
+                   help="farm mode: comma-separated seeds; the jobs are every (molecule, seed) pair (the reference's "
+                        "five-seeds-per-molecule protocol, batch_train.sh:11-15)")
+    p.add_argument("--gpus", dest="farm_gpus", type=int, default=0,
+                   help="farm mode without a launcher: GPUs to use (default: all visible); per_gpu x gpus jobs run at a time")
     return p
 
 
@@ -105,11 +113,15 @@ def _mol_name(path):
     return os.path.splitext(os.path.split(os.path.normpath(path))[-1])[0]
 
 
-def _setup_distributed(farm):
+def _setup_distributed(farm, per_gpu=1):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # farm mode: `per_gpu` independent runs share a device (late-training steps launch ~80 workgroups on a 256-CU chip);
+        # the self-launching farm names the device outright
+        dev = int(os.environ["NAQS_FARM_DEVICE"]) if "NAQS_FARM_DEVICE" in os.environ else (local // max(1, per_gpu) if farm else local)
+        torch.cuda.set_device(dev)
     if world > 1 and not farm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,11 +180,37 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
                                       ("-weight_by_psi", reweight_samples_by_psi)) if on]
     if rejected:
         raise NotImplementedError("options outside the MI355X hot path: " + ", ".join(rejected))
+    # Everything that draws from the process-wide random generators (seeding, parameter initialisation, the optimiser's own
+    # generator) happens under one lock: the farm's `--per-gpu k` runs k jobs as threads of one process, and a run must be the
+    # same run whether or not it has neighbours.  The training loop itself only uses the optimiser's generator.
+    _SETUP_LOCK.acquire()
+    locked = [True]
+    try:
+        return _run_locked(locked, molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretrained_model_loc,
+                           continue_experiment, reset_optimizer, qubit_ordering, masking, lr, lr_lut, n_samps, n_samps_max,
+                           n_unq_samps_min, n_unq_samps_max, n_train, n_pretrain, output_freq, save_freq, n_lut, n_hid, n_layer,
+                           n_hid_phase, n_layer_phase, comb_amp_phase, use_amp_spin_sym, use_phase_spin_sym, aggregate_phase,
+                           use_restrictedH, presolveH, verbose, seed, device)
+    finally:
+        if locked[0]:
+            _SETUP_LOCK.release()
+
+
+_SETUP_LOCK = threading.RLock()
+
+
+def _run_locked(locked, molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretrained_model_loc, continue_experiment,
+                reset_optimizer, qubit_ordering, masking, lr, lr_lut, n_samps, n_samps_max, n_unq_samps_min, n_unq_samps_max,
+                n_train, n_pretrain, output_freq, save_freq, n_lut, n_hid, n_layer, n_hid_phase, n_layer_phase, comb_amp_phase,
+                use_amp_spin_sym, use_phase_spin_sym, aggregate_phase, use_restrictedH, presolveH, verbose, seed, device):
     seed = set_global_seed(_agree_on_seed(seed))
     molecule, qubit_hamiltonian = load_molecule(molecule_fname, hamiltonian_fname=hamiltonian_fname, verbose=True)
     N = molecule.n_qubits
     results = []
     for i in range(num_experiments):
+        if not locked[0]:
+            _SETUP_LOCK.acquire()
+            locked[0] = True
         print(f"\nRunning experiment {i + 1}/{num_experiments}")
         exp_name_i = exp_name + (f"_{i}" if num_experiments > 1 else "")
         n_alpha, n_beta = molecule.get_n_alpha_electrons(), molecule.get_n_beta_electrons()
@@ -231,6 +269,8 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
         if reset_optimizer:
             opt.reset_optimizer()
         print("\n----------Training NAQS----------\n")
+        _SETUP_LOCK.release()
+        locked[0] = False
         t0 = time.time()
         if not use_default_lr_schedule:
             opt.run(n_epochs=n_train, save_freq=save_freq, save_final=True, output_freq=output_freq)
@@ -269,24 +309,98 @@ def _summarise(opt, molecule, exp_name, eig_val, n_unq, train_time):
     return dict(final=final, fci=fci, eig=eig_val, n_unq=n_unq, time=train_time)
 
 
+def farm_jobs(molecules, seeds, seed):
+    """The farm's job list: every (molecule, seed) pair, molecule-major; without --seeds one job per molecule with -s."""
+    mols = molecules.split(",")
+    seed_list = [int(x) for x in seeds.split(",")] if seeds else [seed]
+    return [(m, sd) for m in mols for sd in seed_list]
+
+
+def _farm_launch(args, argv):
+    """`--farm` without a launcher (no WORLD_SIZE in the environment): this process — which never touches a GPU — starts ONE
+    child per GPU (`python -m experiments.run ...` with the device and its share of the job list in the environment); a child
+    runs its jobs through `per_gpu` THREADS, each with its own HIP stream (`_farm_threads`).  Threads of one process, not
+    processes: two processes sharing an MI355X run 1.8x the runs per hour, four or more stall for seconds at a time on this
+    pool (profiles/r04_replicas_per_gpu.txt), while streams of one process overlap like the benchmark's two batches do."""
+    import subprocess
+    import sys
+    jobs = farm_jobs(args.molecule, args.seeds, args.seed)
+    n_gpus = args.farm_gpus if args.farm_gpus > 0 else max(1, torch.cuda.device_count())
+    n_gpus = min(n_gpus, len(jobs))
+    argv = list(sys.argv[1:] if argv is None else argv)
+    t0 = time.time()
+    procs = []
+    for g in range(n_gpus):
+        mine = ",".join(str(j) for j in range(g, len(jobs), n_gpus))
+        env = dict(os.environ, WORLD_SIZE=str(n_gpus), RANK=str(g), LOCAL_RANK=str(g), NAQS_FARM_DEVICE=str(g), NAQS_FARM_JOBS=mine)
+        procs.append(subprocess.Popen([sys.executable, "-m", "experiments.run"] + argv, env=env))
+    rcs = [pr.wait() for pr in procs]
+    print(f"farm: {len(jobs)} runs on {n_gpus} GPU(s) x {max(1, args.per_gpu)} per GPU in {time.time() - t0:.1f} s")
+    if any(rcs):
+        raise RuntimeError(f"farm: worker return codes {rcs}")
+    return list(range(len(jobs)))
+
+
+def _farm_threads(args, job_ids):
+    """This process's share of the farm's jobs on `per_gpu` threads: a thread takes the next job, enters its own HIP stream
+    and runs it start to finish (`_run` serialises the seeded set-up phases; the training loops overlap — the library call
+    that is a VMC step releases the interpreter lock)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if args.number != 1 and args.per_gpu > 1:
+        raise NotImplementedError("--per-gpu > 1 with -n > 1: later experiments of a job continue the process-wide random stream")
+    jobs = farm_jobs(args.molecule, args.seeds, args.seed)
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def one(j):
+        mol, seed = jobs[j]
+        if dev is None:
+            return _run_job(args, mol, seed)
+        torch.cuda.set_device(dev)                             # (the current device is per thread)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            res = _run_job(args, mol, seed)
+            torch.cuda.current_stream().synchronize()
+            return res
+
+    import sys
+    old = sys.getswitchinterval()
+    if args.per_gpu > 1:
+        # a thread coming back from the library (which releases the interpreter lock) would otherwise wait up to the default
+        # 5 ms for a neighbour's bytecode to yield — a step is 0.2 ms
+        sys.setswitchinterval(float(os.environ.get("NAQS_FARM_SWITCH_INTERVAL", "2e-5")))
+    try:
+        with ThreadPoolExecutor(max(1, args.per_gpu)) as ex:
+            out = list(ex.map(one, job_ids))
+    finally:
+        sys.setswitchinterval(old)
+    return [r for res in out for r in res]
+
+
 def run_from_parser(parser, argv=None):
     args = parser.parse_args(argv)
     if args.no_mask_psi and args.full_mask_psi:
         raise Exception("Invalid option combination: at most one of -no_mask_psi and -full_mask_psi can be specified.")
-    rank, world = _setup_distributed(args.farm)
-    molecule_fname = args.molecule
+    if args.farm and "WORLD_SIZE" not in os.environ and (args.per_gpu > 1 or args.seeds or args.farm_gpus > 0):
+        return _farm_launch(args, argv)
+    rank, world = _setup_distributed(args.farm, args.per_gpu)
+    if args.farm and "NAQS_FARM_JOBS" in os.environ:           # a child of the self-launching farm: my share, on threads
+        return _farm_threads(args, [int(j) for j in os.environ["NAQS_FARM_JOBS"].split(",") if j != ""])
+    molecule_fname, seed = args.molecule, args.seed
     if args.farm:
-        mols = molecule_fname.split(",")
-        if rank >= len(mols):
+        jobs = farm_jobs(molecule_fname, args.seeds, args.seed)
+        if rank >= len(jobs):
             print(f"rank {rank}: no molecule assigned")
             return []
-        molecule_fname = mols[rank]
+        molecule_fname, seed = jobs[rank]
+    return _run_job(args, molecule_fname, seed)
+
+
+def _run_job(args, molecule_fname, seed):
     exp_name = args.out
     if exp_name is None:
         exp_name = os.path.join(_EXP_BASE_NAME, _mol_name(molecule_fname))
         exp_name += f"_{_samp_str(args.n_samps)}_samps"
     elif args.farm:
-        exp_name = os.path.join(exp_name, _mol_name(molecule_fname))
+        exp_name = os.path.join(exp_name, _mol_name(molecule_fname) + (f"_s{seed}" if args.seeds else ""))
     for on, suffix in ((args.no_amp_sym, "_noAmpSym"), (args.phase_sym, "_phaseSym"), (args.no_restrictedH, "_no_restrictedH"),
                        (args.no_mask_psi, "_no_mask_psi"), (args.full_mask_psi, "_full_mask_psi")):
         if on:
@@ -308,7 +422,7 @@ def run_from_parser(parser, argv=None):
                 comb_amp_phase=args.comb_amp_phase, use_amp_spin_sym=not args.no_amp_sym,
                 use_phase_spin_sym=args.phase_sym, aggregate_phase=not args.single_phase,
                 use_restrictedH=not args.no_restrictedH, loadH=args.loadH, presolveH=args.presolveH,
-                overwrite_pauli_hamiltonian=args.overwriteH, verbose=args.verbose, seed=args.seed)
+                overwrite_pauli_hamiltonian=args.overwriteH, verbose=args.verbose, seed=seed)
 
 
 def run(*args, **kwargs):
