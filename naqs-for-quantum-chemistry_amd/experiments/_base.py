@@ -174,10 +174,11 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
          reweight_samples_by_psi, n_train, n_pretrain, output_freq, save_freq, n_lut, n_hid, n_layer, n_hid_phase,
          n_layer_phase, n_excitations_max, comb_amp_phase, use_amp_spin_sym, use_phase_spin_sym, aggregate_phase,
          use_restrictedH, loadH, presolveH, overwrite_pauli_hamiltonian, verbose, seed, device=None):
-    rejected = [name for name, on in (("-n_lut", n_lut), ("-comb_amp_phase", comb_amp_phase), ("-phase_sym", use_phase_spin_sym),
-                                      ("-loadH", loadH), ("-overwriteH", overwrite_pauli_hamiltonian),
-                                      ("-n_excitations_max", n_excitations_max is not None), ("-n_pretrain", n_pretrain),
-                                      ("-weight_by_psi", reweight_samples_by_psi)) if on]
+    # (-phase_sym / -comb_amp_phase run as PyTorch modules on the device — no published script uses them; -n_pretrain is
+    # OptimizerBase.pre_flatten; -weight_by_psi is accepted and, as in the reference, has no effect on this optimiser:
+    # PartialSamplingOptimizer forces reweight_samples_by_psi = False, energy.py:744)
+    rejected = [name for name, on in (("-n_lut", n_lut), ("-loadH", loadH), ("-overwriteH", overwrite_pauli_hamiltonian),
+                                      ("-n_excitations_max", n_excitations_max is not None)) if on]
     if rejected:
         raise NotImplementedError("options outside the MI355X hot path: " + ", ".join(rejected))
     # Everything that draws from the process-wide random generators (seeding, parameter initialisation, the optimiser's own
@@ -264,7 +265,10 @@ def _run_locked(locked, molecule_fname, hamiltonian_fname, exp_name, num_experim
         if continue_experiment:
             opt.load()
         else:
-            opt.pre_flatten(n_pretrain)
+            if n_pretrain:
+                print('\n----------Pre-training NAQS.----------\n')
+            opt.pre_flatten(n_pretrain, n_samps, optimizer_args={'lr': 1e-3}, output_freq=output_freq, use_sampling=False,
+                            max_batch_size=550000, flatten_phase=False)           # experiments/_base.py:284-289
             opt.save()
         if reset_optimizer:
             opt.reset_optimizer()

@@ -61,6 +61,9 @@ class FusedLogPsi:
         if m.device.type != "cuda":
             raise _lib.NaqsError("FusedLogPsi needs the network on a HIP device (no CPU fallback)")
         self.aggregate = bool(m.aggregate_phase)
+        if getattr(m, "use_phase_spin_sym", False) or getattr(m, "combined_amp_phase_blocks", False):
+            raise NotImplementedError("fused log-psi: phase spin symmetry / combined amplitude-phase blocks (no published "
+                                      "script uses them) run as PyTorch modules")
         if len(m.phase_layers) != (m.P if self.aggregate else 1):
             raise NotImplementedError("fused log-psi: unexpected number of phase blocks")
         if len(m.amp_layers[0].linears()) != 2:

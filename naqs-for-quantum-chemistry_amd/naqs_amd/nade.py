@@ -105,10 +105,6 @@ class OrbitalNADE(nn.Module):
             unsupported.append("num_lut > 0")
         if input_encoding is not InputEncoding.BINARY:
             unsupported.append("InputEncoding.INTEGER")
-        if combined_amp_phase_blocks:
-            unsupported.append("combined_amp_phase_blocks")
-        if use_phase_spin_sym:
-            unsupported.append("use_phase_spin_sym")
         if amp_batch_norm or phase_batch_norm:
             unsupported.append("batch norm")
         if amp_activation is not SoftmaxLogProbAmps or phase_activation is not None:
@@ -122,7 +118,17 @@ class OrbitalNADE(nn.Module):
         self.P = self.N // 2
         self.masking = masking
         self.use_amp_spin_sym = bool(use_amp_spin_sym)
+        self.use_phase_spin_sym = bool(use_phase_spin_sym)
         self.aggregate_phase = bool(aggregate_phase)
+        # -comb_amp_phase (nade.py:257-262): one block per pair emits the amplitude AND the phase outputs, and the phase
+        # symmetry setting follows the amplitude's
+        self.combined_amp_phase_blocks = bool(combined_amp_phase_blocks)
+        if self.combined_amp_phase_blocks:
+            print("\tUsing combined amplitude and phase blocks:\n\t\t--> defaulting to amp network params for these blocks.")
+            if self.use_amp_spin_sym != self.use_phase_spin_sym:
+                print("\t\t--> Warning: must use same spin-sym settings for both amplitude and phase when combining them into a single block.")
+                print(f"\t\t\t--> setting self.use_amp_spin_sym=self.use_phase_spin_sym={self.use_amp_spin_sym}")
+                self.use_phase_spin_sym = self.use_amp_spin_sym
         self.amplitude_encoding = AmplitudeEncoding.LOG_AMP
         self.use_restricted_hilbert = n_alpha_electrons is not None and n_beta_electrons is not None
         if self.use_restricted_hilbert:
@@ -133,13 +139,16 @@ class OrbitalNADE(nn.Module):
         else:
             self._min_n_set = 0
         self._n_out_amp = 5 if self.use_amp_spin_sym else 4
-        self._n_out_phase = 4
+        # with the phase symmetry three outputs: |00>, |01> == |10>, |11> (nade.py:281, 593-595)
+        self._n_out_phase = 3 if self.use_phase_spin_sym else 4
 
         amp, phase = [], []
         for n in range(self.P):
             n_in = max(1, 2 * n)
-            amp.append(OrbitalBlock(n_in, amp_hidden_size, self._n_out_amp, amp_hidden_activation, amp_bias))
-            if self.aggregate_phase or n == self.P - 1:
+            with_phase = self.aggregate_phase or n == self.P - 1
+            n_amp_out = self._n_out_amp + (self._n_out_phase if (with_phase and self.combined_amp_phase_blocks) else 0)
+            amp.append(OrbitalBlock(n_in, amp_hidden_size, n_amp_out, amp_hidden_activation, amp_bias))
+            if with_phase and not self.combined_amp_phase_blocks:
                 phase.append(OrbitalBlock(n_in, phase_hidden_size, self._n_out_phase, phase_hidden_activation,
                                           phase_bias))
         self.amp_layers = nn.ModuleList(amp)
@@ -244,22 +253,39 @@ class OrbitalNADE(nn.Module):
             first, second, x_order = a_in, b_in, None
         h = torch.cat([first, second], -1)                                            # [B, P, 2W]
 
-        W1, b1 = self._stacked_first_layer(self.amp_layers, W)
-        h = torch.einsum("bnk,nhk->bnh", h, W1) + b1
-        n_lin = len(self.amp_layers[0].linears())
-        for l in range(1, n_lin):
-            h = torch.relu(h)
-            Wl = torch.stack([blk.linears()[l].weight for blk in self.amp_layers])
-            bl = torch.stack([blk.linears()[l].bias for blk in self.amp_layers])
-            h = torch.einsum("bnk,nhk->bnh", h, Wl) + bl
+        ordered_in = h
+        if self.use_phase_spin_sym and not self.use_amp_spin_sym:                     # the phase blocks' ordered inputs (nade.py:507-533)
+            swap_p = (idx_a > idx_b).unsqueeze(-1)
+            ordered_in = torch.cat([torch.where(swap_p, b_in, a_in), torch.where(swap_p, a_in, b_in)], -1)
+        ragged = self.combined_amp_phase_blocks and not self.aggregate_phase          # the last block is wider than the others
+        if ragged:
+            outs = []
+            for n, blk in enumerate(self.amp_layers):                                 # plain per-block evaluation
+                xin = h[:, n, :1] * 0 if n == 0 else torch.cat([h[:, n, :n], h[:, n, W:W + n]], -1)
+                outs.append(blk(xin))
+            h = torch.stack([o[:, :self._n_out_amp] for o in outs], 1)
+            comb_phase = torch.cat([x.new_zeros((B, P - 1, self._n_out_phase)), outs[-1][:, self._n_out_amp:].unsqueeze(1)], 1)
+        else:
+            W1, b1 = self._stacked_first_layer(self.amp_layers, W)
+            h = torch.einsum("bnk,nhk->bnh", h, W1) + b1
+            n_lin = len(self.amp_layers[0].linears())
+            for l in range(1, n_lin):
+                h = torch.relu(h)
+                Wl = torch.stack([blk.linears()[l].weight for blk in self.amp_layers])
+                bl = torch.stack([blk.linears()[l].bias for blk in self.amp_layers])
+                h = torch.einsum("bnk,nhk->bnh", h, Wl) + bl
+            comb_phase = h[..., self._n_out_amp:] if self.combined_amp_phase_blocks else None
+            h = h[..., :self._n_out_amp]
         amp = self._symmetrise(h, x_order)                                            # [B, P, 4]
 
         masks = torch.stack([self._mask_from_counts(n, up_a[:, n], up_b[:, n]) if self._softmax_mask_active(n, masking)
                              else torch.ones((B, 4), dtype=torch.bool, device=x.device) for n in range(P)], 1)
         log_amp = self.amplitude_activation(amp, masks)
 
-        if self.aggregate_phase:
-            ph_in = torch.cat([a_in, b_in], -1)
+        if self.combined_amp_phase_blocks:
+            phase = comb_phase
+        elif self.aggregate_phase:
+            ph_in = ordered_in if self.use_phase_spin_sym else torch.cat([a_in, b_in], -1)
             W1, b1 = self._stacked_first_layer(self.phase_layers, W)
             g = torch.einsum("bnk,nhk->bnh", ph_in, W1) + b1
             for l in range(1, len(self.phase_layers[0].linears())):
@@ -269,9 +295,23 @@ class OrbitalNADE(nn.Module):
                 g = torch.einsum("bnk,nhk->bnh", g, Wl) + bl
             phase = g
         else:
-            ph_in = torch.cat([a[:, :P - 1], b[:, :P - 1]], -1) if P > 1 else x.new_zeros((B, 1))
+            if P > 1:
+                if self.use_phase_spin_sym:                                           # the last block's spin-ordered input
+                    ph_in = torch.cat([ordered_in[:, P - 1, :P - 1], ordered_in[:, P - 1, W:W + P - 1]], -1)
+                else:
+                    ph_in = torch.cat([a[:, :P - 1], b[:, :P - 1]], -1)
+            else:
+                ph_in = x.new_zeros((B, 1))
             last = self.phase_layers[0](ph_in)                                        # nade.py:563-569
-            phase = torch.cat([x.new_zeros((B, P - 1, 4)), last.unsqueeze(1)], 1)
+            phase = torch.cat([x.new_zeros((B, P - 1, self._n_out_phase)), last.unsqueeze(1)], 1)
+        if self.use_phase_spin_sym:
+            phase = phase[..., [0, 1, 1, 2]]                                          # nade.py:593-595
+            # spin-exchanged partner configurations differ by a sign per |01> pair (nade.py:597-610), applied to the LAST
+            # block's outputs (:758-759): + pi (N_01 mod 2) where idx(alpha string) < idx(beta string)
+            tot_a, tot_b = (bits_a * pw).sum(1), (bits_b * pw).sum(1)
+            n01 = ((a <= 0) & (b > 0)).sum(1)
+            shift = torch.where(tot_a < tot_b, math.pi * (n01 % 2).to(phase.dtype), torch.zeros_like(phase[:, 0, 0]))
+            phase = torch.cat([phase[:, :P - 1], phase[:, P - 1:] + shift.view(-1, 1, 1)], 1)
         return torch.stack([log_amp, phase], -1)
 
     # ------------------------------------------------------------------ one conditional (sampler)
@@ -293,7 +333,7 @@ class OrbitalNADE(nn.Module):
                 x_order = torch.where(ia > ib, 0, torch.where(ia == ib, 1, 2))
             else:
                 x_in, x_order = torch.cat([a, b], -1), None
-        amp = self._symmetrise(self.amp_layers[n](x_in), x_order)
+        amp = self._symmetrise(self.amp_layers[n](x_in)[..., :self._n_out_amp], x_order)
         phys = self._mask_from_counts(n, up_a, up_b)
         log_amp = self.amplitude_activation(amp, phys if self._softmax_mask_active(n, masking) else None)
         return log_amp, phys

@@ -626,9 +626,49 @@ class PartialSamplingOptimizer(OptimizerBase):
     def get_n_samples(self):
         return self.n_samples
 
-    def pre_flatten(self, n_epochs, *args, **kwargs):
-        if n_epochs:
-            raise NotImplementedError("pre_flatten with n_epochs > 0 (unused: n_pretrain=0, experiments/run.py:14)")
+    def pre_flatten(self, n_epochs, n_samps=1e6, flatten_phase=False, norm_reg_weight=0, use_sampling=True, max_batch_size=-1,
+                    optimizer=torch.optim.Adam, optimizer_args={'lr': 5e-3}, output_freq=50):
+        """Pre-train the amplitudes towards the uniform superposition over the restricted space (energy.py:840-904; what
+        ``-n_pretrain n`` runs, experiments/_base.py:284-289: ``use_sampling=False, max_batch_size=550000``): n supervised
+        epochs, mean-squared error of log|psi| against log(1 / sqrt(size)), Adam on all parameters.  PyTorch modules with
+        autograd on the network's device — a set-up phase over the enumerated space, not the hot path.  (The reference's
+        ``use_sampling=True`` branch returns nothing from its epoch function and cannot run; it is refused here.)"""
+        import math
+        import torch.nn.functional as F
+        print("Pre-flattening NAQS amplitudes", end="...")
+        if not n_epochs:                                      # (the reference enumerates the space even for zero epochs)
+            print("done.")
+            return
+        if use_sampling:
+            raise NotImplementedError("pre_flatten(use_sampling=True): the reference's own branch fails (energy.py:880-887 returns None)")
+        wf = self.wavefunction
+        states = self.hilbert.get_subspace(ret_states=True, ret_idxs=False).to(self.device)
+        opt = optimizer(wf.parameters(), **optimizer_args)
+        log_amp_target = math.log(1 / math.sqrt(len(states)))
+        if max_batch_size < 0:
+            max_batch_size = len(states)
+        n_batches = (len(states) - 1) // max_batch_size + 1
+        print(f"using {n_batches} batch(es) of size of at most {max_batch_size}.")
+        t0 = time.time()
+        for i in range(1, n_epochs + 1):
+            for idx_batch in torch.randperm(len(states)).chunk(n_batches):
+                opt.zero_grad()
+                log_psi = wf.log_psi(states[idx_batch.to(states.device)])
+                target = ([log_amp_target, 0] if flatten_phase else [log_amp_target]) * len(idx_batch)
+                if not flatten_phase:
+                    log_psi = log_psi[..., 0]
+                loss = F.mse_loss(log_psi.reshape(-1), torch.tensor(target, dtype=log_psi.dtype, device=log_psi.device))
+                loss.backward()
+                opt.step()
+            if (i % output_freq == 0) or (i == 1):
+                tpe = (time.time() - t0) / (1 if i == 1 else output_freq)
+                print(f"\t Epoch {i} : loss = {loss.item():.5e}, |psi|^2 = {log_psi[..., 0].exp().norm().detach().item() if flatten_phase else log_psi.exp().norm().detach().item():.3f}, epoch time={tpe:.2f}s")
+                t0 = time.time()
+        opt.zero_grad()
+        for p_ in wf.param_list():
+            p_.grad = None
+        wf.parameters_changed()                               # the fused kernels' packed weights follow
+        print("done.")
 
     def _can_prefuse(self):
         """The conditions under which _SGD_step takes its single-GPU fused branch (forward + E_loc in one call) — known

@@ -401,6 +401,12 @@ VARIANTS = {
     "nomask": (dict(), "small", NadeMasking.NONE),
     "fullmask": (dict(), None, NadeMasking.FULL),
     "fullmask_noampsym": (dict(use_amp_spin_sym=False), None, NadeMasking.FULL),
+    # round 4: the live options no published script uses (experiments/_base.py:533-541): -phase_sym (nade.py:281, 597-610)
+    # and -comb_amp_phase (nade.py:257-262, 294-303, 555: one block per pair emits amplitude AND phase outputs; it forces
+    # the phase symmetry to follow the amplitude symmetry) on run.py's default aggregate-phase ansatz
+    "phasesym": (dict(use_phase_spin_sym=True), None, NadeMasking.PARTIAL),
+    "phasesym_agg": (dict(use_phase_spin_sym=True, aggregate_phase=True), (32, 32, 1), NadeMasking.PARTIAL),
+    "combampphase": (dict(combined_amp_phase_blocks=True, aggregate_phase=True), (32, 32, 1), NadeMasking.PARTIAL),
 }
 PUBLISHED_CFG = {"LiH": (64, 32, 2), "H2O": (64, 32, 2), "CH2": (64, 32, 2)}        # small phase nets for the small fixtures; else 64/512x2
 SMALL_CFG = {"N2": (64, 128, 2)}                                 # keeps the fixture small where the 512-wide phase net is not the point
@@ -434,7 +440,9 @@ def gen_variant(mol, tag, seed=111, with_eloc=None):
         np.savez_compressed(os.path.join(OUT, f"eloc_{mol}.npz"), **out)
     nd = {"cfg_n_hid": cfg[0], "cfg_n_hid_phase": cfg[1], "cfg_n_layer_phase": cfg[2], "seed": seed,
           "cfg_masking": masking.value, "cfg_aggregate_phase": bool(over.get("aggregate_phase", False)),
-          "cfg_use_amp_spin_sym": bool(over.get("use_amp_spin_sym", True))}
+          "cfg_use_amp_spin_sym": bool(over.get("use_amp_spin_sym", True)),
+          "cfg_use_phase_spin_sym": bool(over.get("use_phase_spin_sym", False)),
+          "cfg_combined_amp_phase_blocks": bool(over.get("combined_amp_phase_blocks", False))}
     nd.update(nade_vectors(wf, opt, hil, all_keys))
     np.savez_compressed(os.path.join(OUT, f"nade_{mol}_{tag}.npz"), **nd)
     print(f"[nade] {mol}/{tag}: n_unq={len(nd['samp_keys'])} E={nd['sgd_E']:.6f} Var={nd['sgd_Var']:.6f} "
@@ -509,6 +517,38 @@ def variants():
         gen_variant(mol, "fullmask", with_eloc={"c2": (10000, 2.0)})
     gen_compat_lih()
     gen_open_shell()
+
+
+def widen():
+    """round 4: -phase_sym / -comb_amp_phase fixtures and the pre-training step (-n_pretrain), LiH"""
+    for tag in ("phasesym", "phasesym_agg", "combampphase"):
+        gen_variant("LiH", tag)
+    gen_pretrain("LiH")
+
+
+def gen_pretrain(mol, seed=111, n_epochs=3):
+    """pretrain_<mol>.npz: `opt.pre_flatten` exactly as experiments/_base.py:284-289 calls it (-n_pretrain n: supervised epochs
+    towards the uniform amplitude over the restricted space, energy.py:840-904) — parameters before and after."""
+    set_global_seed(seed)
+    qh = rh.load_qubit_hamiltonian(mol)
+    na, nb = electrons(mol)
+    hil = make_hilbert(mol, qh)
+    cfg = PUBLISHED_CFG.get(mol, (64, 512, 2))
+    wf = NAQSComplex_NADE_orbitals(hil, **wavefunction_args(na, nb, *cfg))
+    opt = make_optimizer(wf, qh, na, nb, n_samples=1000)
+    nd = {"cfg_n_hid": cfg[0], "cfg_n_hid_phase": cfg[1], "cfg_n_layer_phase": cfg[2], "seed": seed, "n_epochs": n_epochs}
+    for k, v_ in wf.model.state_dict().items():
+        nd["sd:" + k] = v_.detach().numpy().copy()
+    opt.pre_flatten(n_epochs, 1000, optimizer_args={'lr': 1e-3}, output_freq=25, use_sampling=False, max_batch_size=550000,
+                    flatten_phase=False)
+    for k, v_ in wf.model.state_dict().items():
+        nd["sd_after:" + k] = v_.detach().numpy().copy()
+    states = hil.basis_states
+    with torch.no_grad():
+        nd["log_amp_after"] = wf.log_psi(states)[..., 0].numpy()
+    nd["target"] = np.float64(np.log(1 / np.sqrt(len(states))))
+    np.savez_compressed(os.path.join(OUT, f"pretrain_{mol}.npz"), **nd)
+    print(f"[pretrain] {mol}: mean log|psi| after {n_epochs} epochs = {nd['log_amp_after'].mean():.6f} (target {nd['target']:.6f})")
 
 
 def gen_open_shell():
@@ -600,6 +640,8 @@ if __name__ == "__main__":
         main()
     if which in ("all", "variants"):
         variants()
+    if which == "widen":
+        widen()
     if which == "compat":
         gen_compat_lih()
     if which == "open-shell":

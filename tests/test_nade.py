@@ -22,10 +22,13 @@ def make_wf(mol, z, device="cpu", masking=None):
         masking = NadeMasking(int(z["cfg_masking"])) if "cfg_masking" in z.files else NadeMasking.PARTIAL
     agg = bool(z["cfg_aggregate_phase"]) if "cfg_aggregate_phase" in z.files else False
     sym = bool(z["cfg_use_amp_spin_sym"]) if "cfg_use_amp_spin_sym" in z.files else True
+    psym = bool(z["cfg_use_phase_spin_sym"]) if "cfg_use_phase_spin_sym" in z.files else False
+    comb = bool(z["cfg_combined_amp_phase_blocks"]) if "cfg_combined_amp_phase_blocks" in z.files else False
     wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=masking,
                                    amp_hidden_size=[int(z["cfg_n_hid"])],
                                    phase_hidden_size=[int(z["cfg_n_hid_phase"])] * int(z["cfg_n_layer_phase"]),
-                                   use_amp_spin_sym=sym, use_phase_spin_sym=False, aggregate_phase=agg,
+                                   use_amp_spin_sym=sym, use_phase_spin_sym=psym, aggregate_phase=agg,
+                                   combined_amp_phase_blocks=comb,
                                    n_alpha_electrons=na, n_beta_electrons=nb, device=device)
     sd = {k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd:")}
     assert set(sd) == set(wf.model.state_dict()), "state_dict keys must match the reference's"

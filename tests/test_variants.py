@@ -18,7 +18,10 @@ VARIANT_FIXTURES = ["LiH_aggphase", "LiH_noampsym", "LiH_fullmask", "N2_aggphase
                     "N2_0.75_fullmask", "N2_2.25_fullmask",
                     # open shell restricted to m_s = S (experiments/_base.py:101-123): CH2 triplet, 5 alpha / 3 beta electrons
                     "CH2_noampsym", "CH2_fullmask_noampsym"]
-TAGS = ["fullmask_noampsym", "aggphase", "noampsym", "nomask", "fullmask"]
+TAGS = ["fullmask_noampsym", "aggphase", "noampsym", "nomask", "fullmask", "phasesym_agg", "phasesym", "combampphase"]
+# round 4: the live options no published script uses — -phase_sym (nade.py:281, 593-610) and -comb_amp_phase
+# (nade.py:257-262, 294-303) — as PyTorch modules, against the reference's own vectors (make_golden.py `widen`)
+WIDEN_FIXTURES = ["LiH_phasesym", "LiH_phasesym_agg", "LiH_combampphase"]
 ADAM = [{'lr': 1e-3, 'betas': (0.9, 0.99), 'weight_decay': 0, 'eps': 1e-15, 'amsgrad': False}, {'lr': 1e-2}]
 
 
@@ -29,13 +32,16 @@ def split(fix):
     raise ValueError(fix)
 
 
-@pytest.mark.parametrize("fix", VARIANT_FIXTURES)
+@pytest.mark.parametrize("fix", VARIANT_FIXTURES + WIDEN_FIXTURES)
 def test_variant_log_psi_matches_reference(fix):
     mol, tag = split(fix)
     z = golden(f"nade_{fix}.npz")
     hil, wf = make_wf(mol, z)
-    assert wf.model.aggregate_phase == (tag == "aggphase") and wf.model.use_amp_spin_sym == ("noampsym" not in tag)
-    assert len(wf.model.phase_layers) == (wf.model.P if tag == "aggphase" else 1)
+    agg = tag in ("aggphase", "phasesym_agg", "combampphase")
+    assert wf.model.aggregate_phase == agg and wf.model.use_amp_spin_sym == ("noampsym" not in tag)
+    assert len(wf.model.phase_layers) == (0 if tag == "combampphase" else (wf.model.P if agg else 1))
+    if fix in WIDEN_FIXTURES:
+        assert wf.model.use_phase_spin_sym and wf.model._n_out_phase == 3      # (-comb_amp_phase forces it to follow the amplitude's)
     s = torch.tensor(z["eval_states"])
     with torch.no_grad():
         cond = wf._evaluate_log_psi(s, gather_state=False).numpy()
@@ -57,7 +63,7 @@ def test_variant_log_psi_matches_reference(fix):
 
 
 @pytest.mark.parametrize("fix", ["LiH_aggphase", "LiH_noampsym", "LiH_fullmask", "N2_aggphase", "N2_noampsym",
-                                 "CH2_noampsym", "CH2_fullmask_noampsym"])
+                                 "CH2_noampsym", "CH2_fullmask_noampsym"] + WIDEN_FIXTURES)
 def test_variant_sgd_step_matches_reference_step(fix, tmp_path, monkeypatch):
     """energy, variance, loss, every gradient and every parameter after the reference's own _SGD_step."""
     import oracle_backend
@@ -118,3 +124,33 @@ def test_variant_sampler_statistics_no_amp_sym():
         p_all = wf.log_psi(hil.get_subspace(ret_states=True))[:, 0].exp().pow(2).double().sum().item()
     kept = counts.sum().item()
     assert abs(kept / n - p_all) < 5 * np.sqrt(max(p_all * (1 - p_all), 1e-9) / n) + 1e-3
+
+
+def test_pre_flatten_follows_the_reference(tmp_path, monkeypatch, capsys):
+    """-n_pretrain n = OptimizerBase.pre_flatten as experiments/_base.py:284-289 calls it (energy.py:840-904): n supervised
+    epochs towards the uniform amplitude over the restricted space.  Parameters after three epochs against the reference's
+    (one batch: the order torch.randperm visits the states in does not enter the mean-squared error beyond rounding)."""
+    import oracle_backend
+    from naqs_amd.optimizer import PartialSamplingOptimizer
+    oracle_backend.install(monkeypatch)
+    z = golden("pretrain_LiH.npz")
+    hil, wf = make_wf("LiH", z)
+    N, na, nb = ELECTRONS["LiH"]
+    ham = packing.load_packed(os.path.join(GOLDEN, "ham_LiH.npz"))
+    opt = PartialSamplingOptimizer(
+        n_samples=1000, n_samples_max=1e12, n_unq_samples_min=10, n_unq_samples_max=1e5, log_exact_energy=False,
+        wavefunction=wf, qubit_hamiltonian=ham, pre_compute_H=False, n_electrons=na + nb, n_alpha_electrons=na,
+        n_beta_electrons=nb, normalise_psi=True, grad_clip_factor=None, optimizer=torch.optim.Adam,
+        optimizer_args=[dict(a) for a in ADAM], save_loc=str(tmp_path), pauli_hamiltonian_dtype=np.float64, seed=3)
+    opt.pre_flatten(int(z["n_epochs"]), 1000, optimizer_args={'lr': 1e-3}, output_freq=25, use_sampling=False,
+                    max_batch_size=550000, flatten_phase=False)
+    out = capsys.readouterr().out
+    assert "Pre-flattening NAQS amplitudes...using 1 batch(es) of size of at most 550000." in out and "Epoch 1 : loss = " in out
+    for name, p in wf.model.named_parameters():
+        assert np.max(np.abs(p.detach().numpy() - z["sd_after:" + name])) < 2e-6, name
+    with torch.no_grad():
+        la = wf.log_psi(hil.get_subspace(ret_states=True))[..., 0].numpy()
+    assert np.max(np.abs(la - z["log_amp_after"])) < 2e-5
+    opt.pre_flatten(0)                                                    # -n_pretrain 0 (every published script): nothing to do
+    with pytest.raises(NotImplementedError):
+        opt.pre_flatten(1, use_sampling=True)                             # the reference's own sampling branch cannot run

@@ -100,6 +100,30 @@ def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
             assert d[flipped].max() < 2.1e-3 and g[flipped].max() <= 1e-3 * g.max(), (name, d[flipped].max())
 
 
+@pytest.mark.parametrize("fix", ["LiH_phasesym", "LiH_phasesym_agg", "LiH_combampphase"])
+def test_live_options_outside_the_fused_family_run_on_device(fix, tmp_path, capsys):
+    """-phase_sym / -comb_amp_phase (no published script uses them): PyTorch modules on the device, announced once, with
+    the HIP E_loc kernel underneath — log psi and one whole _SGD_step against the reference's recorded vectors."""
+    mol, z, hil, wf = _wf(fix)
+    assert wf.fused() is None
+    assert "fused HIP network kernels not available for this ansatz" in capsys.readouterr().out
+    s = torch.tensor(z["eval_states"], device="cuda")
+    with torch.no_grad():
+        lp = wf.log_psi(s).cpu().numpy()
+    assert np.max(np.abs(lp - z["eval_log_psi"])) < 5e-5
+    opt = _opt(mol, wf, tmp_path)
+    states = torch.tensor(z["samp_states"], device="cuda")
+    counts = torch.tensor(z["samp_counts"], device="cuda")
+    keys = hil.state2idx(states).squeeze(-1)
+    E, var = opt._SGD_step(states, keys, None, sample_weights=counts.double() / counts.sum().double())
+    assert abs(E - float(z["sgd_E"])) < 2e-5 * max(1, abs(E))
+    assert abs(var - float(z["sgd_Var"])) < 1e-3 * max(1, abs(var))
+    for name, p in wf.model.named_parameters():
+        assert np.max(np.abs(p.detach().cpu().numpy() - z["sd_after:" + name])) < 2e-5, name
+    opt.run(3, output_freq=10 ** 6)                       # and the training loop (PyTorch sampler, HIP E_loc) runs
+    assert opt.n_steps == 3
+
+
 @pytest.mark.parametrize("fix", ["LiH_aggphase", "N2_aggphase"])
 def test_aggregate_phase_log_psi_on_device(fix):
     """The PyTorch modules on the device (conditionals of every block) and the HIP kernels' gradients against autograd."""
