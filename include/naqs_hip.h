@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 5
+#define NAQS_ABI_VERSION 6
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -355,6 +355,34 @@ int naqs_vmc_loss_grad_ev(int64_t M, const double *eloc_dev, const double *w_dev
  * integers in float64): the per-step proof that the ranks row-sharded ONE table (the reference is single-process; the
  * counterpart is the `weights` / `sampled_idxs` bookkeeping of src/optimizer/energy.py:300, :993). */
 int naqs_shard_proof(int64_t M, const uint64_t *keys_dev, const double *sums_dev, double *ext_dev, void *stream);
+
+/* ---- the row-sharded training step (world > 1) as FOUR library calls with the three collectives in between (round 4) ----
+ * One process per GPU; every rank draws the same table and owns the rows [b, e) = [min(M, rank S), min(M, (rank + 1) S)),
+ * S = ceil(M / world) (src/optimizer/energy.py:273-377 split over ranks as SURVEY 8e describes).  The caller's sequence:
+ *   naqs_vmc_shard_sample_forward          sampler -> host learns (M, overflow) -> [accept M?] -> training forward of MY rows,
+ *                                          (log|psi|, phase) of them written to the front of `logpsi_shard_dev` (>= S rows)
+ *   all-gather of the shards               -> table [world][S_pad][2] float32 (S_pad >= S: equal padded contributions)
+ *   naqs_eloc_gathered                     prep (hash table, psi) straight from the gathered layout, E_loc of my rows against
+ *                                          the whole table, weighted sums -> ext8[0..4), same-table proof -> ext8[4..8)
+ *   all-reduce of ext8
+ *   naqs_net_train_backward_vmc            loss gradient + backward of my rows (sums = the reduced ext8)
+ *   all-reduce of the flat gradient
+ *   naqs_vmc_shard_update                  Adam on the flat parameter vector + re-pack of the kernels' weight layouts
+ * Same kernels and the same arithmetic as the call-by-call path of round 3 (energies and parameters agree bit for bit);
+ * what goes is the interpreter time between the pieces — the GPU idled for it.  info_host[0] = M, [1] = overflow,
+ * [2] = 1 iff the step was taken (M inside [m_lo, m_hi], no overflow; otherwise nothing was evaluated). */
+int naqs_vmc_shard_sample_forward(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo, int64_t m_hi,
+                                  int rank, int world, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev,
+                                  double *weights_dev, float *logpsi_shard_dev, int64_t info_host[3], void *stream);
+/* table_dev: [world][S_pad][2] float32 (log|psi|, phase), shard r = rows r S .. of the M-row table; w_dev, eloc_dev: MY rows
+ * (n_rows entries, row_begin = my first row); ext8_dev: {sum w Re E, sum w Im E, sum w Re^2 E, sum w, M, M^2, c, c^2}
+ * (naqs_eloc_reduced + naqs_shard_proof). */
+int naqs_eloc_gathered(naqs_ham_t *h, int64_t M, const uint64_t *keys_dev, const float *table_dev, int64_t S, int64_t S_pad,
+                       int64_t row_begin, int64_t n_rows, const double *w_dev, double *eloc_dev, double *ext8_dev, void *stream);
+/* naqs_adam_step on the network's flat parameter vector followed by naqs_net_set_weights of the updated parameters. */
+int naqs_vmc_shard_update(naqs_net_t *net, const float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, int64_t adam_step,
+                          void *stream);
 
 /* Host evaluation of the sampler's generators, for known-answer and statistical tests (no device needed):
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */

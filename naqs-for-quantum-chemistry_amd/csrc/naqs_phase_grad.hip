@@ -877,6 +877,46 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
     return NAQS_OK;
 }
 
+// the sharded step's first and last library calls (include/naqs_hip.h: the four-call sequence with its three collectives)
+NAQS_API int naqs_vmc_shard_sample_forward(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
+                                           int64_t m_hi, int rank, int world, uint64_t *keys_dev, int64_t *counts_dev,
+                                           float *probs_dev, double *weights_dev, float *logpsi_shard_dev, int64_t info_host[3],
+                                           void *stream) {
+    if (!net || !info_host || !logpsi_shard_dev || world < 1 || rank < 0 || rank >= world) return NAQS_ERR_INVALID;
+    info_host[2] = 0;
+    int64_t info2[2] = {0, 0};
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    if (!net->have_weights) return NAQS_ERR_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info2);
+    if (st != NAQS_OK) return st;
+    info_host[0] = info2[0]; info_host[1] = info2[1];
+    const int64_t M = info2[0];
+    if (info2[1] != 0 || M <= 0 || M < m_lo || M > m_hi) return NAQS_OK;        // abandoned: the caller adapts n_samples
+    const int64_t S = (M + world - 1) / world, b = std::min<int64_t>(M, (int64_t)rank * S), e = std::min<int64_t>(M, b + S);
+    if (e > b) {
+        st = naqs_net_train_forward(net, e - b, keys_dev + b, logpsi_shard_dev, stream);
+        if (st != NAQS_OK) return st;
+    }
+    info_host[2] = 1;
+    return NAQS_OK;
+}
+
+NAQS_API int naqs_vmc_shard_update(naqs_net_t *net, const float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
+                                   double lr, double beta1, double beta2, double eps, double weight_decay, int64_t adam_step,
+                                   void *stream) {
+    if (!net || !grad_dev || !param_dev || !exp_avg_dev || !exp_avg_sq_dev || adam_step < 1) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    st = naqs_adam_step(net->n_params, param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay, adam_step,
+                        stream);
+    if (st != NAQS_OK) return st;
+    return naqs_net_set_weights(net, param_dev, net->n_params, stream);
+}
+
 NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev,
                                      float *grad_dev, void *stream) {
     return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr);

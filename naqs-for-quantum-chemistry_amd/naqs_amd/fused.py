@@ -447,6 +447,87 @@ class FusedLogPsi:
             self._flat = adam._flat
         return True, m, False, (keys[:m], counts[:m], probs[:m], weights[:m], log_psi[:m], eloc[:m], sums, g[:m], ev)
 
+    # ---- the row-sharded step (world > 1): four library calls, the three collectives between them (include/naqs_hip.h) ----
+    def _step_buffers(self, cap, world, keys_out=None):
+        """Per-handle buffers of the sharded step, allocated once per (cap, world): the step's outputs are views of them and
+        stay valid until the next step (the one-call step of a single process allocates per step; here the gather and
+        reduce buffers have to be persistent anyway)."""
+        key = (int(cap), int(world))
+        sb = getattr(self, "_shard_bufs", None)
+        if sb is None or sb["key"] != key:
+            dev = self.device
+            S_pad = -(-int(cap) // int(world))
+            sb = self._shard_bufs = dict(
+                key=key, S_pad=S_pad,
+                keys=torch.empty(cap, dtype=torch.int64, device=dev), counts=torch.empty(cap, dtype=torch.int64, device=dev),
+                probs=torch.empty(cap, dtype=torch.float32, device=dev), weights=torch.empty(cap, dtype=torch.float64, device=dev),
+                mine=torch.zeros((S_pad, 2), dtype=torch.float32, device=dev),
+                table=torch.empty((S_pad * int(world), 2), dtype=torch.float32, device=dev),
+                eloc=torch.empty((S_pad, 2), dtype=torch.float64, device=dev), g=torch.empty((S_pad, 2), dtype=torch.float32, device=dev),
+                ext=torch.empty(8, dtype=torch.float64, device=dev), ev=torch.empty(2, dtype=torch.float64, device=dev))
+        if self._grad_flat is None:
+            self._grad_flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            self._grad_views, off = [], 0
+            for p in self.wf.param_list():
+                n = p.numel()
+                self._grad_views.append(self._grad_flat[off:off + n].view(p.shape))
+                off += n
+        return sb
+
+    @torch.no_grad()
+    def shard_sample_forward(self, n_samples, seed, max_unique, m_lo, m_hi, rank, world, keys_out=None):
+        """Call 1 (``naqs_vmc_shard_sample_forward``): the sampler, the host's look at (M, overflow), and the training forward
+        of this rank's rows, whose (log|psi|, phase) land at the front of the gather contribution.
+        -> (taken, M, overflow, buffers)."""
+        cap = int(max_unique)
+        sb = self._step_buffers(cap, world)
+        keys = keys_out if keys_out is not None else sb["keys"]
+        info = (ctypes.c_int64 * 3)(0, 0, 0)
+        st = self._lib.naqs_vmc_shard_sample_forward(self._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, int(m_lo), int(m_hi),
+                                                     int(rank), int(world), keys.data_ptr(), sb["counts"].data_ptr(),
+                                                     sb["probs"].data_ptr(), sb["weights"].data_ptr(), sb["mine"].data_ptr(), info,
+                                                     _stream_ptr(self.device))
+        _lib.check(st, "naqs_vmc_shard_sample_forward")
+        sb["keys_used"] = keys
+        return bool(info[2]), int(info[0]), bool(info[1]), sb
+
+    @torch.no_grad()
+    def shard_eloc(self, ham, sb, M, rank, world):
+        """Call 2 (``naqs_eloc_gathered``) on the all-gathered table: E_loc of my rows, weighted sums and the same-table proof
+        -> ext8 (to be all-reduced).  -> (b, e): my row range."""
+        S = -(-M // world)
+        b = min(M, rank * S)
+        e = min(M, b + S)
+        st = self._lib.naqs_eloc_gathered(ham._h, M, sb["keys_used"].data_ptr(), sb["table"].data_ptr(), S, sb["S_pad"], b, e - b,
+                                          sb["weights"][b:].data_ptr() if e > b else None, sb["eloc"].data_ptr(), sb["ext"].data_ptr(),
+                                          _stream_ptr(self.device))
+        _lib.check(st, "naqs_eloc_gathered")
+        return b, e
+
+    @torch.no_grad()
+    def shard_backward(self, sb, b, e):
+        """Call 3 (``naqs_net_train_backward_vmc``) for my rows with the all-reduced sums -> flat gradient of my shard."""
+        st = self._lib.naqs_net_train_backward_vmc(self._h, e - b, sb["keys_used"][b:].data_ptr() if e > b else None,
+                                                   sb["eloc"].data_ptr(), sb["weights"][b:].data_ptr() if e > b else None,
+                                                   sb["ext"].data_ptr(), sb["g"].data_ptr(), sb["ev"].data_ptr(),
+                                                   self._grad_flat.data_ptr(), _stream_ptr(self.device))
+        _lib.check(st, "naqs_net_train_backward_vmc")
+
+    @torch.no_grad()
+    def shard_update(self, adam):
+        """Call 4 (``naqs_vmc_shard_update``): Adam on the flat parameter vector with the all-reduced gradient + re-pack."""
+        grp = next(g_ for g_ in adam.param_groups if g_['params'])
+        t = adam._t + 1
+        st = self._lib.naqs_vmc_shard_update(self._h, self._grad_flat.data_ptr(), adam._flat.data_ptr(), adam._m.data_ptr(),
+                                             adam._v.data_ptr(), float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]),
+                                             float(grp['eps']), float(grp['weight_decay']), t, _stream_ptr(self.device))
+        _lib.check(st, "naqs_vmc_shard_update")
+        if not adam.state:
+            adam._bind_state()
+        adam._t = t
+        adam._opt_called = True
+        self._flat = adam._flat
+
     def prof_enable(self, n, stride=1):
         _lib.check(self._lib.naqs_net_prof_enable(self._h, int(n)), "naqs_net_prof_enable")
         _lib.check(self._lib.naqs_net_prof_stride(self._h, int(stride)), "naqs_net_prof_stride")

@@ -144,11 +144,15 @@ class OptimizerBase:
         self.use_fused = True                # HIP sampler / training kernels / FlatAdam when the network supports them
         self._loss_terms = self._last_loss = None
         self._shard_mismatch = None
-        # multi-GPU policy: below `shard_min_rows` rows per rank every kernel of the step is launch-bound and the
-        # sharded step's extra launches and collectives cost more than they save, so every rank then runs the IDENTICAL
-        # single-GPU step (same seed, same parameters, deterministic kernels: bit-identical updates, no collectives) and the
-        # ranks only prove every `replica_proof_every` steps that they still hold the same table.
-        self.shard_min_rows = int(os.environ.get("NAQS_SHARD_MIN_ROWS", "4096"))
+        # multi-GPU policy: a small table's step is a chain of launch-bound kernels — sharding it adds launches and
+        # three collectives and saves nothing — so below `shard_min_table` unique samples (or `shard_min_rows` rows per rank)
+        # every rank runs the IDENTICAL single-GPU step (same seed, same parameters, deterministic kernels: bit-identical
+        # updates, no collectives) and the ranks only prove every `replica_proof_every` steps that they still hold the same
+        # table.  Measured break-even of the four-call sharded step (tools/scaling_model.py, one GPU, collectives assumed at
+        # 80 us): N2 at 1.1 k samples loses at every world size (0.36 vs 0.21 ms), Li2O at 20 k samples wins down to 2.5 k rows
+        # per rank (0.49 vs 0.81 ms at 8 ranks).  shard_min_rows = 0 forces sharding (tests).
+        self.shard_min_rows = int(os.environ.get("NAQS_SHARD_MIN_ROWS", "1024"))
+        self.shard_min_table = int(os.environ.get("NAQS_SHARD_MIN_TABLE", "8192"))
         self.replica_proof_every = int(os.environ.get("NAQS_REPLICA_PROOF_EVERY", "64"))
         self._dist_mode, self._last_M, self.dist_mode_log = None, None, []
         self.reset_log()
@@ -248,8 +252,9 @@ class OptimizerBase:
             mode = "single"
         else:
             world = dist.get_world_size()
-            rows = (self._last_M // world) if self._last_M is not None else 0
-            mode = "sharded" if rows >= self.shard_min_rows else "replicated"
+            M = self._last_M if self._last_M is not None else 0
+            big_enough = self.shard_min_rows <= 0 or (M >= self.shard_min_table and M // world >= self.shard_min_rows)
+            mode = "sharded" if big_enough else "replicated"
         if mode != self._dist_mode:
             if dist is not None:
                 self.dist_mode_log.append((self.n_steps, mode))
@@ -257,7 +262,8 @@ class OptimizerBase:
                     what = ("row-sharded step (all-gather of log psi shards, all-reduce of accumulators and gradient)"
                             if mode == "sharded" else "every rank runs the identical single-GPU step (no collectives)")
                     print(f"\tdistributed step at epoch {self.n_epochs}: {self._last_M} unique samples over "
-                          f"{dist.get_world_size()} ranks, shard_min_rows={self.shard_min_rows} --> {what}")
+                          f"{dist.get_world_size()} ranks (shard_min_table={self.shard_min_table}, "
+                          f"shard_min_rows={self.shard_min_rows}) --> {what}")
             self._dist_mode = mode
             self._onecall_cached = None
         return mode
@@ -739,6 +745,101 @@ class PartialSamplingOptimizer(OptimizerBase):
             self.scheduler.step()
         return counts, weights, ev
 
+    def _can_shard_onecall(self):
+        """The sharded step as four library calls (``FusedLogPsi.shard_*``): the one-call step's conditions with a process
+        group in place of the single process."""
+        from .flat_adam import FlatAdam
+        if self._active_dist() is None or os.environ.get("NAQS_TRAIN_ONECALL", "1") != "1":
+            return False
+        if not self.use_fused or self.normalize_grads or self.bug_compat_full_sample_order or self.grad_clip_factor is not None:
+            return False
+        if not isinstance(self.optimizer, FlatAdam):
+            return False
+        wf = self.wavefunction
+        fused = wf.fused(need_phase=True)
+        flat = getattr(wf, "_flat_params", None)
+        return (fused is not None and fused.train_mode == "hip" and not fused.aggregate and flat is not None
+                and flat.data_ptr() == self.optimizer._flat.data_ptr() and wf._views_of(flat, wf.param_list())
+                and all(p.grad is None for p in wf.param_list()))
+
+    def _sharded_onecall_step(self):
+        """One row-sharded VMC step = four library calls and three collectives (include/naqs_hip.h): sampler +
+        forward of my rows | all-gather | E_loc of my rows + sums + proof | all-reduce | backward | all-reduce | Adam + re-pack.
+        The adaptive sample count is ``_onecall_step``'s.  -> (counts, weights, ev)."""
+        dist = self._active_dist()
+        world, rank = dist.get_world_size(), dist.get_rank()
+        wf = self.wavefunction
+        fused = wf.fused(need_phase=True)
+        last_action = 0
+        while True:
+            free = (self.n_samples != self.n_unq_samples_min) and (self.n_samples != self.n_samples_max)
+            m_lo = self.n_unq_samples_min if (free and last_action >= 0) else 0
+            seed = wf._next_sample_seed(self.generator)
+            slot = self._sampled_ring_slot(int(self.n_unq_samples_max)) if self.track_sampled_idxs else None
+            taken, n_unq, overflow, sb = fused.shard_sample_forward(self.n_samples, seed, self.n_unq_samples_max, m_lo,
+                                                                    self.n_unq_samples_max, rank, world, keys_out=slot)
+            if taken:
+                break
+            action = 0
+            if overflow:
+                print("MaxBatchSizeExceededError")
+                n_unq, action = self.n_unq_samples_max + 1, -1
+            if free or overflow:
+                if n_unq < self.n_unq_samples_min and last_action >= 0:
+                    action = 1
+                    self.n_samples = int(min(self.n_samples * 10, self.n_samples_max))
+                    print(f"\t...{n_unq} unique samples generated --> increasing batch size to "
+                          f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
+                elif n_unq > self.n_unq_samples_max and last_action <= 0:
+                    action = -1
+                    self.n_samples = int(max(self.n_samples / 10, self.n_unq_samples_min))
+                    print(f"\t...{n_unq} unique samples generated --> decreasing batch size to "
+                          f"{self.n_samples / 1e6:.1f}M at epoch {self.n_epochs}.")
+            if action == 0:
+                raise RuntimeError(f"VMC step abandoned without a reason to re-sample (M={n_unq})")
+            last_action = action
+        M = n_unq
+        prof = os.environ.get("NAQS_SHARD_PROFILE") == "1"             # developer aid: synchronised per-stage wall times
+        if prof:
+            torch.cuda.synchronize(); t_ = [time.perf_counter()]
+            def mark():
+                torch.cuda.synchronize(); t_.append(time.perf_counter())
+        else:
+            def mark():
+                pass
+        dist.all_gather_into_tensor(sb["table"], sb["mine"])           # equal padded shards: [world][S_pad][2]
+        mark()
+        b, e = fused.shard_eloc(self.pauli_hamiltonian, sb, M, rank, world)
+        mark()
+        ext = sb["ext"]
+        dist.all_reduce(ext)
+        shard_ok = (world * ext[5] == ext[4] * ext[4]) & (world * ext[7] == ext[6] * ext[6])
+        self._shard_mismatch = (~shard_ok if self._shard_mismatch is None else self._shard_mismatch | ~shard_ok)
+        mark()
+        fused.shard_backward(sb, b, e)
+        mark()
+        dist.all_reduce(fused._grad_flat)                              # shards SUM to the full-batch gradient
+        fused.shard_update(self.optimizer)
+        mark()
+        if prof:
+            acc = self.__dict__.setdefault("_shard_prof", [0.0] * 6)
+            for i_ in range(5):
+                acc[i_] += t_[i_ + 1] - t_[i_]
+            acc[5] += 1
+            if acc[5] % 20 == 0:
+                print("[shard profile] gather %.0f us | eloc+proof %.0f | reduce+check %.0f | backward %.0f | reduce+update %.0f (rows %d of %d)"
+                      % tuple([a_ / acc[5] * 1e6 for a_ in acc[:5]] + [e - b, M]), flush=True)
+        wf.fused_repacked()
+        keys = sb["keys_used"][:M]
+        self._sample_keys, self._sample_weights, self._prefused = keys, sb["weights"][:M], None
+        if self.track_sampled_idxs:
+            self._sampled_ring_off += M
+        self._loss_terms, self._last_loss = (sb["g"][:e - b], sb["mine"][:e - b]), None
+        if self.scheduler is not None:
+            self.scheduler.step()
+        ev = torch.where(shard_ok, sb["ev"], torch.full_like(sb["ev"], float("nan")))
+        return sb["counts"][:M], sb["weights"][:M], ev
+
     def get_samples(self, last_action=0, lazy=False):
         """Adaptive sample count (energy.py:936-971): x10 while too few unique samples, /10 when too many
         or when the unique-prefix tree exceeds ``n_unq_samples_max``.  -> (states, counts, probs); the keys and the
@@ -836,8 +937,10 @@ class PartialSamplingOptimizer(OptimizerBase):
             self._choose_dist_mode()                 # multi-GPU: replicate or shard this step (resets the cache on a switch)
             onecall = getattr(self, "_onecall_cached", None)
             if onecall is None:
-                onecall = self._onecall_cached = self._can_onecall()
-            if onecall:
+                onecall = self._onecall_cached = (2 if self._can_shard_onecall() else (1 if self._can_onecall() else 0))
+            if onecall == 2:
+                counts, weights, ev = self._sharded_onecall_step()
+            elif onecall:
                 counts, weights, ev = self._onecall_step()
             else:
                 states, counts, probs = self.get_samples(lazy=True)

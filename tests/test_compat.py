@@ -163,7 +163,7 @@ def _mismatch_worker(rank, world, port, tmp, out):
         raised = "different tables" in str(e)
     # the replicated step proves the same thing with its own small all-reduce every `replica_proof_every` steps
     opt._shard_mismatch = None
-    opt.shard_min_rows, opt.replica_proof_every = 10 ** 9, 1
+    opt.shard_min_rows, opt.shard_min_table, opt.replica_proof_every = 10 ** 9, 10 ** 9, 1
     try:
         opt.run(2, output_freq=10 ** 6)
         raised_replicated = False

@@ -169,7 +169,7 @@ def test_flat_adam_follows_param_group_edits_after_load_state_dict():
     assert abs(step() - 5e-5) < 1e-7
 
 
-def _run_workers(tmp_path, backend, world, port, shard_min_rows=0, tag=""):
+def _run_workers(tmp_path, backend, world, port, shard_min_rows=0, tag="", extra_env=None):
     """Start ``world`` fresh child processes of tests/dist_step_worker.py on cuda:0 and collect what they wrote.
     shard_min_rows = 0: every distributed step shards (the branches under test); None: the library's own policy."""
     import subprocess
@@ -179,6 +179,7 @@ def _run_workers(tmp_path, backend, world, port, shard_min_rows=0, tag=""):
     env.pop("NAQS_SHARD_MIN_ROWS", None)
     if shard_min_rows is not None:
         env["NAQS_SHARD_MIN_ROWS"] = str(shard_min_rows)
+    env.update(extra_env or {})
     outs = [str(tmp_path / f"{backend}{tag}_{world}_{r}.pt") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_step_worker.py"), backend, str(r), str(world),
                                str(port), outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -213,6 +214,18 @@ def test_distributed_step_on_one_gpu(tmp_path):
     d = np.abs(np.array(gloo2[0]["energies"]) - e0)
     assert d[:20].max() < 1e-6 and d.max() < 5e-3, d
     assert torch.max(torch.abs(gloo2[0]["params"] - single["params"])).item() < 2e-2
+
+
+def test_sharded_step_as_four_library_calls_equals_the_call_by_call_path(tmp_path):
+    """The row-sharded step runs as four library calls with the three collectives between them (naqs_vmc_shard_sample_forward
+    | all-gather | naqs_eloc_gathered | all-reduce | naqs_net_train_backward_vmc | all-reduce | naqs_vmc_shard_update); round
+    3's call-by-call path (NAQS_TRAIN_ONECALL=0) launches the same kernels on the same data with the interpreter in between:
+    gloo world 2 on one GPU, every energy and every parameter identical."""
+    a = _run_workers(tmp_path, "gloo", 2, 29590, tag="_four")
+    b = _run_workers(tmp_path, "gloo", 2, 29591, tag="_cbc", extra_env={"NAQS_TRAIN_ONECALL": "0"})
+    assert a[0]["energies"] == b[0]["energies"] and a[1]["energies"] == b[1]["energies"]
+    assert torch.equal(a[0]["params"], b[0]["params"]) and torch.equal(a[0]["params"], a[1]["params"])
+    assert [m for _, m in a[0]["dist_modes"]] == ["sharded"]
 
 
 def test_small_tables_are_replicated_not_sharded(tmp_path):

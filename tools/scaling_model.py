@@ -50,6 +50,9 @@ class FakeDist:
 
     def all_gather_into_tensor(self, out, mine):
         fused = self.fused_ref()
+        if self.keys is None or getattr(fused, "_last_shard_M", None) is not None:
+            # the four-call sharded step: the keys of this step sit in the step's buffers (recorded by the wrapper below)
+            self.keys = fused._shard_bufs["keys_used"][:fused._last_shard_M]
         lp = fused.log_psi(self.keys)                                   # what the other ranks would have delivered
         S = mine.shape[0]
         M = lp.shape[0]
@@ -70,7 +73,11 @@ def build():
     wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, use_amp_spin_sym=True, use_phase_spin_sym=False,
                                    n_alpha_electrons=na, n_beta_electrons=nb, device=dev, amp_hidden_size=[64],
                                    phase_hidden_size=[512, 512], aggregate_phase=False)
-    opt = O.PartialSamplingOptimizer(n_samples=1000000, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5, wavefunction=wf,
+    # NAQS_SCALING_PUBLISHED=1: the sample counts of experiments/run.py (1e7 samples, 1e4 .. 1e5 unique) — the regime in which the
+    # step is meant to shard (tables of >= 10^4 rows); default: a part-trained network's ~10^3-row tables
+    pub = os.environ.get("NAQS_SCALING_PUBLISHED") == "1"
+    opt = O.PartialSamplingOptimizer(n_samples=10000000 if pub else 1000000, n_samples_max=1e12, n_unq_samples_min=10000 if pub else 1000,
+                                     n_unq_samples_max=1e5, wavefunction=wf,
                                      qubit_hamiltonian=qh, pre_compute_H=False, n_electrons=mol.n_electrons, n_alpha_electrons=na,
                                      n_beta_electrons=nb, optimizer=torch.optim.Adam,
                                      optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'eps': 1e-15}, {'lr': 1e-2}],
@@ -78,6 +85,34 @@ def build():
                                      pauli_hamiltonian_dtype=np.float64, normalise_psi=True)
     return wf, opt
 
+
+WORLDS = [int(x) for x in os.environ.get("NAQS_SCALING_WORLDS", "1,2,4,8").split(",")]
+if len(WORLDS) > 1:
+    # one fresh process per world size (a real run never changes its world size either: buffers, modes and the sampler's
+    # launch hints of one size must not leak into the timing of the next), results merged here
+    import subprocess
+    rows = []
+    for W in WORLDS:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), mol_f, str(steps)], env=dict(os.environ, NAQS_SCALING_WORLDS=str(W)),
+                             capture_output=True, text=True, timeout=900)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('{"what"')]
+        if not line:
+            raise SystemExit(f"world {W} failed:\n{out.stdout[-2000:]}\n{out.stderr[-2000:]}")
+        sub = json.loads(line[-1])
+        rows += sub["per_world"]
+        print(sub["per_world"][0], flush=True)
+    base = rows[0]["rank0_ms_per_step"]
+    coll = sum(ASSUMED_US.values()) * 1e-3
+    for r in rows:
+        r["kernel_only_speedup"] = base / r["rank0_ms_per_step"]
+        r["model_ms_per_step"] = r["rank0_ms_per_step"] + (coll if (r["world"] > 1 and r["mode"] == "sharded") else 0.0)
+        r["model_speedup"] = base / r["model_ms_per_step"]
+    res = dict(sub, per_world=rows)
+    print(json.dumps(res))
+    if out_f:
+        with open(out_f, "w") as f:
+            json.dump(res, f, indent=1)
+    raise SystemExit(0)
 
 rows = []
 train_first = int(os.environ.get("NAQS_SCALING_TRAIN_FIRST", "1000"))
@@ -87,7 +122,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 for g in opt.optimizer.param_groups:                 # ... then frozen (lr = 0), so that every world size times the SAME workload
     g["lr"] = 0.0
 real_dist, real_step = O._dist, opt._SGD_step
-for W in (1, 2, 4, 8):
+for W in WORLDS:
     fake = FakeDist(W, lambda: wf.fused(need_phase=True)) if W > 1 else None
     if fake is not None:
         O._dist = lambda: fake
@@ -96,6 +131,15 @@ for W in (1, 2, 4, 8):
             fake.keys = O.keys_to_device(states_idx, dev)
             return real_step(states, states_idx, *a, **k)
         opt._SGD_step = step
+        fz = wf.fused(need_phase=True)
+        if not hasattr(fz, "_real_ssf"):
+            fz._real_ssf = fz.shard_sample_forward
+
+            def ssf(*a, **k):
+                r = fz._real_ssf(*a, **k)
+                fz._last_shard_M = r[1]
+                return r
+            fz.shard_sample_forward = ssf
     try:
         with contextlib.redirect_stdout(io.StringIO()):
             opt.run(40, output_freq=10 ** 9)
@@ -106,7 +150,7 @@ for W in (1, 2, 4, 8):
         n_unq = float(np.mean([x[1] for x in opt.log[O.LogKey.N_UNIQUE_SAMP][-steps:]]))
         # the stand-in's table evaluation (inference kernel on all M rows + the copies), timed alone on the same table size
         t_tab = 0.0
-        if fake is not None:
+        if fake is not None and fake.keys is not None and opt._dist_mode == "sharded":
             keys = fake.keys
             mine = torch.zeros((-(-len(keys) // W), 2), dtype=torch.float32, device=dev)
             out = torch.empty((mine.shape[0] * W, 2), dtype=torch.float32, device=dev)
@@ -118,18 +162,23 @@ for W in (1, 2, 4, 8):
             torch.cuda.synchronize(); t_tab = (time.perf_counter() - t1) / 200
     finally:
         O._dist, opt._SGD_step = real_dist, real_step
+    mode = opt._dist_mode                                  # the optimiser's own policy picked it (shard_min_rows)
+    if mode != "sharded":
+        t_tab = 0.0                                        # no all-gather happened: nothing to subtract
     rows.append({"world": W, "wall_ms_per_step_incl_standin": dt * 1e3, "standin_table_ms": t_tab * 1e3,
-                 "rank0_ms_per_step": (dt - t_tab) * 1e3, "mean_unique_samples": n_unq,
-                 "path": "single-process step (forward + E_loc in one library call)" if W == 1 else
-                         "sharded step (forward of my rows, all-gather, E_loc of my rows, two all-reduces)"})
+                 "rank0_ms_per_step": (dt - t_tab) * 1e3, "mean_unique_samples": n_unq, "mode": mode,
+                 "path": {"single": "single-process step (one library call)",
+                          "replicated": "every rank runs the single-GPU step (one library call; 32-byte proof every 64 steps)",
+                          "sharded": "sharded step (forward of my rows, all-gather, E_loc of my rows, two all-reduces)"}[mode]})
     print(rows[-1], flush=True)
 base = rows[0]["rank0_ms_per_step"]
 coll = sum(ASSUMED_US.values()) * 1e-3
 for r in rows:
     r["kernel_only_speedup"] = base / r["rank0_ms_per_step"]
-    r["model_ms_per_step"] = r["rank0_ms_per_step"] + (coll if r["world"] > 1 else 0.0)
+    r["model_ms_per_step"] = r["rank0_ms_per_step"] + (coll if (r["world"] > 1 and r["mode"] == "sharded") else 0.0)
     r["model_speedup"] = base / r["model_ms_per_step"]
-res = {"what": "training step (published N2 network), rank 0's share per world size, measured on ONE GPU; collectives NOT issued",
+res = {"what": "training step (published network), rank 0's share per world size, measured on ONE GPU; collectives NOT issued",
+       "shard_min_rows": opt.shard_min_rows, "shard_min_table": opt.shard_min_table,
        "molecule": os.path.basename(mol_f), "steps": steps, "unmeasured_on_hardware": True,
        "assumed_collective_latency_us": ASSUMED_US, "per_world": rows}
 print(json.dumps(res))
