@@ -406,12 +406,15 @@ class FusedLogPsi:
         keys = keys_out if keys_out is not None else torch.empty(cap, dtype=torch.int64, device=dev)
         if keys.dtype != torch.int64 or keys.numel() < cap or not keys.is_contiguous():
             raise ValueError("vmc_step: keys_out must be a contiguous int64 tensor of at least max_unique elements")
-        counts = torch.empty(cap, dtype=torch.int64, device=dev)
-        probs = torch.empty(cap, dtype=torch.float32, device=dev)
-        weights = torch.empty(cap, dtype=torch.float64, device=dev)
-        log_psi = torch.empty((cap, 2), dtype=torch.float32, device=dev)
-        eloc = torch.empty((cap, 2), dtype=torch.float64, device=dev)
-        g = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        # the step's cap-sized outputs live in per-handle buffers (allocated once per cap: eight allocator calls per step were
+        # ~15 us of host time on a 0.2 ms step); they are valid until the next step of this handle — what the optimiser keeps
+        # across steps are the two device scalars (<E>, Var), which therefore get fresh storage every step
+        ob = getattr(self, "_onecall_bufs", None)
+        if ob is None or ob[0] != cap:
+            ob = self._onecall_bufs = (cap, torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.float32, device=dev),
+                                       torch.empty(cap, dtype=torch.float64, device=dev), torch.empty((cap, 2), dtype=torch.float32, device=dev),
+                                       torch.empty((cap, 2), dtype=torch.float64, device=dev), torch.empty((cap, 2), dtype=torch.float32, device=dev))
+        _, counts, probs, weights, log_psi, eloc, g = ob
         small = torch.empty(6, dtype=torch.float64, device=dev)
         sums, ev = small[:4], small[4:]
         if self._grad_flat is None:

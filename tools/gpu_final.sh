@@ -1,10 +1,10 @@
 #!/bin/bash
 # final bench lines of the round, AFTER tools/collect_evidence.sh has put the counter files of this library build under
-# profiles/ (bench.py replays them when the source hash matches): ROUND=r03 bash tools/gpu_final.sh -> gpurun_out/$ROUND_final/
-ROUND=${ROUND:-r03}; G=gpurun_out/${ROUND}_final; mkdir -p $G
-python bench.py > $G/bench.log 2>/dev/null
-python bench.py --steps 20 --warmup 5 > $G/bench_driver_like.log 2>/dev/null
-python bench.py --shard rows --molecule Li2O --samples 50000 --steps 100 --warmup 10 > $G/bench_li2o.log 2>/dev/null
+# profiles/ (bench.py replays them when the source hash matches): ROUND=r04 bash tools/gpu_final.sh -> gpurun_out/$ROUND_final/
+ROUND=${ROUND:-r04}; G=gpurun_out/${ROUND}_final; mkdir -p $G
+timeout 600 python bench.py > $G/bench.log 2>/dev/null
+timeout 600 python bench.py --steps 20 --warmup 5 > $G/bench_driver_like.log 2>/dev/null
+timeout 600 python bench.py --shard rows --molecule Li2O --samples 50000 --steps 100 --warmup 10 > $G/bench_li2o.log 2>/dev/null
 ROUND=$ROUND bash tools/n2_sweep.sh > $G/n2_sweep.log 2>&1
 cp gpurun_out/$ROUND/n2_sweep.txt $G/n2_sweep.txt
 python - <<PY
