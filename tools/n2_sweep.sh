@@ -9,9 +9,9 @@ GEOMS="0.75 0.9 1.05 1.2 1.35 1.5 1.65 1.8 1.95 2.1 2.25"
 MOLS=$(for r in $GEOMS; do printf "%s," "$R/tests/golden/ham_N2_$r.npz"; done); MOLS=${MOLS%,}
 rm -rf /tmp/sweep
 cd naqs-for-quantum-chemistry_amd
-t0=$(date +%s.%N)
+t0=$(date +%s%N)
 timeout 900 python -u -m experiments.run --farm --per-gpu ${PER_GPU:-2} --gpus 1 --seeds 111,222,333 -m $MOLS -o /tmp/sweep -single_phase -n1 -n_layer 1 -n_hid 64 -n_layer_phase 2 -n_hid_phase 512 -full_mask_psi -n_train 10000 -output_freq 5000 -save_freq -1 > /tmp/sweep.log 2>&1
-t1=$(date +%s.%N)
+t1=$(date +%s%N)
 echo "r(A) seed time(s) final_E(Ha) FCI(Ha) error(mHa)" > $OUT
 for r in $GEOMS; do
   for s in 111 222 333; do
@@ -23,5 +23,5 @@ for r in $GEOMS; do
     echo "$r $s $t $e $c $m" >> $OUT
   done
 done
-echo "33 runs of 10 000 steps in $(echo "$t1 - $t0" | bc) s of wall time (one process, --per-gpu ${PER_GPU:-2}; training time per run is measured while two share the GPU)" >> $OUT
+echo "33 runs of 10 000 steps in $(( (t1 - t0) / 1000000 )) ms of wall time (one process, --per-gpu ${PER_GPU:-2}; training time per run is measured while two share the GPU)" >> $OUT
 cat $OUT
