@@ -565,3 +565,45 @@ def test_device_lanczos_reproduces_fci_on_the_whole_space(mol):
     assert abs(val - fci) < 1e-8, (val, fci)
     hv = ham.matvec(keys, vec)
     assert float((hv - val * vec).norm()) < 1e-6
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_eloc_from_the_gathered_table_equals_the_compact_call(env, world):
+    """ABI 6, the sharded training step's second call: `naqs_eloc_gathered` reads (log|psi|, phase) straight from the
+    all-gather's layout — `world` equal padded shards [world][S_pad][2], shard r = rows r S .. of the table — and returns
+    my rows' E_loc, the weighted sums and the same-table proof.  Against `naqs_eloc_reduced` on the compacted table: the
+    same E_loc bit for bit and the same four sums; ext8[4:8] = (M, M^2, c, c^2) with c = 20 low bits of the key sum."""
+    import ctypes
+    from naqs_amd.fused import _stream_ptr
+    lib = env["lib"].load_library()
+    z = golden("eloc_N2.npz")
+    ham = dev_ham(env, "N2")
+    keys_np = z["small_keys"]
+    M = len(keys_np)
+    rs = np.random.RandomState(5)
+    lp = np.stack([rs.normal(-0.5 * np.log(M), 1.5, M), rs.uniform(0, 2 * np.pi, M)], -1).astype(np.float32)
+    w = rs.uniform(0.1, 1.0, M)
+    w /= w.sum()
+    dev = ham.device
+    keys = env["H"].keys_to_device(keys_np, dev)
+    lp_d = torch.as_tensor(lp, device=dev)
+    w_d = torch.as_tensor(w, dtype=torch.float64, device=dev)
+    S = -(-M // world)
+    S_pad = S + 37                                             # padded contributions, as sized from n_unq_samples_max
+    table = torch.full((world, S_pad, 2), float("nan"), dtype=torch.float32, device=dev)     # padding must never be read
+    for r in range(world):
+        b, e = min(M, r * S), min(M, (r + 1) * S)
+        table[r, :e - b] = lp_d[b:e]
+    for rank in range(world):
+        b, e = min(M, rank * S), min(M, (rank + 1) * S)
+        e_ref, sums_ref = ham.local_energy(keys, lp_d, kind="log_psi", row_begin=b, n_rows=e - b, weights=w_d[b:e])
+        eloc = torch.zeros((max(e - b, 1), 2), dtype=torch.float64, device=dev)
+        ext = torch.zeros(8, dtype=torch.float64, device=dev)
+        st = lib.naqs_eloc_gathered(ham._h, M, keys.data_ptr(), table.data_ptr(), S, S_pad, b, e - b,
+                                    w_d[b:].data_ptr() if e > b else None, eloc.data_ptr(), ext.data_ptr(), _stream_ptr(dev))
+        env["lib"].check(st, "naqs_eloc_gathered")
+        torch.cuda.synchronize()
+        assert torch.equal(eloc[:e - b], e_ref)
+        assert torch.equal(ext[:4], sums_ref if e > b else torch.zeros(4, dtype=torch.float64, device=dev))
+        c = float(int(keys_np.astype(np.uint64).sum(dtype=np.uint64)) & 0xFFFFF)
+        assert ext[4:].tolist() == [float(M), float(M) ** 2, c, c * c]
