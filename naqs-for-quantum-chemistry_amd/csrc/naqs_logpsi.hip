@@ -1870,6 +1870,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMalloc((void **)&net->d_scales, sizeof(naqs::PhaseScales)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMemset(net->d_raw, 0, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_HIP;
+        if (st == NAQS_OK && hipDeviceSynchronize() != hipSuccess) st = NAQS_ERR_HIP;     // null-stream fill: done before any non-blocking stream writes there
     }
     if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
     *out = net;

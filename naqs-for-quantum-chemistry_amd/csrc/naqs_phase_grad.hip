@@ -484,6 +484,7 @@ int ensure_train_scratch(naqs_net *net, int64_t M) {
     const TrainLayout L = train_layout(net, cap);
     HIP_TRY(hipMalloc(&net->d_train, L.total));
     HIP_TRY(hipMemset(net->d_train, 0, L.total));          // padding columns of x stay zero for good
+    HIP_TRY(hipDeviceSynchronize());                       // (null-stream fill: finished before the caller's non-blocking stream writes there)
     net->train_cap = cap;
     return NAQS_OK;
 }

@@ -337,6 +337,10 @@ def _farm_launch(args, argv):
     for g in range(n_gpus):
         mine = ",".join(str(j) for j in range(g, len(jobs), n_gpus))
         env = dict(os.environ, WORLD_SIZE=str(n_gpus), RANK=str(g), LOCAL_RANK=str(g), NAQS_FARM_DEVICE=str(g), NAQS_FARM_JOBS=mine)
+        if args.per_gpu > 2:
+            # more than two ACTIVE hardware queues are time-sliced in multi-millisecond quanta on this pool (k = 4 threads on
+            # four queues: 3 000-step runs take 40-130 s instead of 9): let the runtime map the threads' streams onto two
+            env.setdefault("GPU_MAX_HW_QUEUES", "2")
         procs.append(subprocess.Popen([sys.executable, "-m", "experiments.run"] + argv, env=env))
     rcs = [pr.wait() for pr in procs]
     print(f"farm: {len(jobs)} runs on {n_gpus} GPU(s) x {max(1, args.per_gpu)} per GPU in {time.time() - t0:.1f} s")

@@ -607,3 +607,25 @@ def test_eloc_from_the_gathered_table_equals_the_compact_call(env, world):
         assert torch.equal(ext[:4], sums_ref if e > b else torch.zeros(4, dtype=torch.float64, device=dev))
         c = float(int(keys_np.astype(np.uint64).sum(dtype=np.uint64)) & 0xFFFFF)
         assert ext[4:].tolist() == [float(M), float(M) ** 2, c, c * c]
+
+
+def test_first_call_on_a_side_stream_of_a_busy_gpu(env):
+    """A handle's allocation-time zero fills (hash table, training scratch) run on the null stream, which is not ordered
+    against torch's non-blocking side streams: unless the library waits for them, a fill that is late because the GPU is
+    busy wipes what the first call's kernels have already written (found as a wrong FIRST energy in one of ~80 runs of
+    `experiments.run --farm --per-gpu 4`).  First call of a fresh handle on a side stream, under load from another stream,
+    must be the answer of a quiet GPU."""
+    z = golden("eloc_N2.npz")
+    keys, psi = z["c2_keys"], z["c2_psi_f32"]
+    quiet = run_eloc(env, dev_ham(env, "N2"), keys, psi)
+    load = torch.randn(6144, 6144, device="cuda")
+    busy, side = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(6):
+        ham = dev_ham(env, "N2")                              # fresh handle: the first call allocates and zero-fills
+        with torch.cuda.stream(busy):
+            for _ in range(12):
+                load @ load
+        with torch.cuda.stream(side):
+            got = run_eloc(env, ham, keys, psi)
+        assert np.array_equal(got, quiet), rep
+    torch.cuda.synchronize()

@@ -399,3 +399,33 @@ def test_backward_as_one_launch_equals_its_pieces(mol, n_samples, monkeypatch):
         grads[mode] = torch.cat([p.grad.reshape(-1) for p in wf.model.parameters()]).clone()
         assert fused.last_kernel() is not None
     assert torch.equal(grads["1"], grads["0"]) and float(grads["1"].abs().max()) > 0
+
+
+def test_fresh_network_on_a_side_stream_of_a_busy_gpu():
+    """The handle's allocation-time zero fills (weight-range words at creation, the training scratch at the first training
+    forward) run on the null stream; a side stream is not ordered against it, so the library has to wait for them itself —
+    otherwise a fill that is late (busy GPU) wipes the ranges / activations the side stream's kernels have just written.
+    A fresh network used for the first time on a side stream, under load from another stream, gives the quiet GPU's answer
+    (see test_first_call_on_a_side_stream_of_a_busy_gpu for E_loc's table)."""
+    from test_nade import make_wf
+    z = golden("nade_N2.npz")
+    s = torch.tensor(z["eval_states"], device="cuda")
+    hil, wf = make_wf("N2", z, device="cuda")
+    with torch.no_grad():
+        quiet = wf.log_psi(s).clone()
+    quiet_train = wf.log_psi(s).detach().clone()              # (with autograd: the training forward)
+    load = torch.randn(6144, 6144, device="cuda")
+    busy, side = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(4):
+        with torch.cuda.stream(busy):
+            for _ in range(12):
+                load @ load
+        with torch.cuda.stream(side):
+            hil, wf2 = make_wf("N2", z, device="cuda")        # fresh handle, created and first used on the side stream
+            with torch.no_grad():
+                got = wf2.log_psi(s)
+            got_train = wf2.log_psi(s).detach()
+            side.synchronize()
+        assert torch.equal(got, quiet) and torch.equal(got_train, quiet_train), rep
+    torch.cuda.synchronize()

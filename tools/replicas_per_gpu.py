@@ -75,7 +75,13 @@ for k in ks:
         if k == ks[0]:
             ref[d] = e
         else:
-            same = same and len(e) == len(ref[d]) and bool((e == ref[d]).all())
+            ok = len(e) == len(ref[d]) and bool((e == ref[d]).all())
+            if not ok:                                   # where a trajectory leaves its reference run
+                n = min(len(e), len(ref[d]))
+                first = next((i for i in range(n) if e[i] != ref[d][i]), n)
+                say(f"   {d}: {len(e)} vs {len(ref[d])} logged energies, first difference at entry {first}"
+                    + (f" ({e[first]!r} vs {ref[d][first]!r})" if first < n else ""))
+            same = same and ok
     base = base or wall
     say(f"{k}  {wall:.1f}  {n_jobs * 3600 / wall:.0f}  {base / wall:.2f}  {sum(tt) / len(tt):.2f}  {same if k != ks[0] else '-'}")
 if out_f:
