@@ -1058,11 +1058,11 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_h(const NetDims d, co
 constexpr int WS_MW = 4;                         // matrix waves (0 .. WS_MW - 1); the others are the amplitude waves
 constexpr int WS_NCT = 8;                        // column tiles of a matrix wave in the big layer: 4 x 8 x 16 = 512 columns
 
-template <int RB, int DBG = 0>
+template <int RB, int DBG = 0, int NC = WS_NCT>
 __device__ __forceinline__ void ws_accumulate(const ushort_t *__restrict__ a_ptr, int ldh, int plane_stride,
                                               const ushort_t *__restrict__ w_ptr, int Kh_pad, size_t wplane,
-                                              f32x4 (&acc)[RB][WS_NCT]) {
-    bf16x8 b[2][WS_NCT], a0[2][RB], a1[2][RB];
+                                              f32x4 (&acc)[RB][NC]) {
+    bf16x8 b[2][NC], a0[2][RB], a1[2][RB];
     auto load_b2 = [&](int k0, int c0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -1095,13 +1095,13 @@ __device__ __forceinline__ void ws_accumulate(const ushort_t *__restrict__ a_ptr
             }
     };
 #pragma unroll
-    for (int c0 = 0; c0 < WS_NCT; c0 += 2) load_b2(0, c0);
+    for (int c0 = 0; c0 < NC; c0 += 2) load_b2(0, c0);
     load_a(0, a0);
     int k0 = 0;
     for (; k0 + 64 <= Kh_pad; k0 += 64) {
         load_a(k0 + 32, a1);
 #pragma unroll
-        for (int c0 = 0; c0 < WS_NCT; c0 += 2) {
+        for (int c0 = 0; c0 < NC; c0 += 2) {
             __builtin_amdgcn_sched_barrier(0);
             mma2(a0, c0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void ws_accumulate(const ushort_t *__restrict__ a_ptr
         const int kn = min(k0 + 64, Kh_pad - 32);          // unconditional (clamped): a branch makes the s_waitcnt merge conservative
         load_a(kn, a0);
 #pragma unroll
-        for (int c0 = 0; c0 < WS_NCT; c0 += 2) {
+        for (int c0 = 0; c0 < NC; c0 += 2) {
             __builtin_amdgcn_sched_barrier(0);
             mma2(a1, c0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void ws_accumulate(const ushort_t *__restrict__ a_ptr
     }
     if (k0 < Kh_pad) {                                      // odd number of chunks: the last one is already loaded
 #pragma unroll
-        for (int c0 = 0; c0 < WS_NCT; c0 += 2) mma2(a0, c0);
+        for (int c0 = 0; c0 < NC; c0 += 2) mma2(a0, c0);
     }
 }
 
@@ -1157,12 +1157,12 @@ template <int CT, int RB>
 __device__ __forceinline__ void ws_amp_work(const NetDims &d, const ushort_t *__restrict__ wamp, int64_t M, int64_t row0,
                                             const uint64_t *__restrict__ keys, const ElocFeed &feed, const uint32_t *s_ab,
                                             float (*s_lan)[RB * 16], float *__restrict__ s_o, AmpFrag<CT> &f0, int aw, int lane,
-                                            long long *clk, int wave) {
+                                            long long *clk, int wave, int qlo, int qhi, bool do_feed) {
+    // [qlo, qhi): the workgroup's items (all of them, or its half of a tile shared by two workgroups)
     constexpr int BM = RB * 16;
     constexpr int AW = PH_WAVES - WS_MW;
     const size_t pair_elems = amp_mfma_pair_elems(CT * 16);
-    const int P = d.P, items = RB * P;
-    const int q0 = items * aw / AW, q1 = items * (aw + 1) / AW;
+    const int q0 = qlo + (qhi - qlo) * aw / AW, q1 = qlo + (qhi - qlo) * (aw + 1) / AW;
     AmpFrag<CT> f1;
     int na = q0 < q1 ? q0 / RB : -1, nb = -1;                   // f0 holds pair na (requested by the caller before the first barrier)
     const int n_last = q0 < q1 ? (q1 - 1) / RB : -1;
@@ -1185,7 +1185,7 @@ __device__ __forceinline__ void ws_amp_work(const NetDims &d, const ushort_t *__
     // that nothing in this kernel waits for)
     {
         const int r = aw * WAVE + lane;
-        if (r < BM && feed.tab != nullptr && row0 + r < M) {
+        if (do_feed && r < BM && feed.tab != nullptr && row0 + r < M) {
             const uint64_t key = keys[row0 + r];
             if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, row0 + r, key);
             else naqs::feed_key<uint64_t>(feed, row0 + r, key);
@@ -1208,25 +1208,42 @@ __device__ __forceinline__ void ws_amp_work(const NetDims &d, const ushort_t *__
     if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 15] = clock64();
 }
 
-template <int RB, bool SAVE>
+// SPLIT (small tables: twice the tiles still fit the chip, one workgroup per CU): the big layer of a tile is shared by TWO
+// workgroups — it is bound by the 1 MB weight stream through ONE CU's vector-memory path whatever the tile's height, and a
+// training step's ~1 200 rows are 75 tiles on 256 CUs.  Workgroup `tile` (the producer: lower index, dispatched first) takes
+// columns 256 .. 511, workgroup `n_tiles + tile` (the consumer) columns 0 .. 255, the amplitude items and the epilogue; each
+// matrix wave owns one group of 64 columns.  The amplitude items are shared too (lower pairs: consumer, upper: producer).  The
+// producer's output-layer partial rows (BM x 4 floats) and its conditionals travel as 64-bit words (call tag << 32 | float
+// bits; relaxed agent-scope store / polled load: value and flag are one word, so no fence and no L2 write-back — the
+// sampler's look-back words, naqs_sample.hip); the consumer adds the partial rows last:
+// ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)), a fixed order, but not the unsplit kernel's (last-bit differences of the
+// phase between the two forms; every other value — log|psi|, saved activations — is the same).
+struct WsSplit { unsigned long long *xchg; uint32_t tag; };
+
+template <int RB, bool SAVE, bool SPLIT = false>
 __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, const float *__restrict__ w,
                                                               const ushort_t *__restrict__ wh, int64_t M,
                                                               const uint64_t *__restrict__ keys,
                                                               const float *__restrict__ scratch, float2 *__restrict__ out,
                                                               const ElocFeed feed, const naqs::PhaseSave save,
                                                               const ushort_t *__restrict__ wamp,
-                                                              const naqs::PhaseScales *__restrict__ scales, const int flags) {
+                                                              const naqs::PhaseScales *__restrict__ scales, const int flags,
+                                                              const WsSplit split) {
     // wamp == nullptr: the amplitude conditionals were computed by a kernel of their own (scratch[n][i]); waves 4-7 then
     // only wait at the barrier
     extern __shared__ __attribute__((aligned(16))) ushort_t planes[];
     __shared__ uint32_t s_ab[RB * 16];                 // model-order occupation strings of the tile's samples
     __shared__ float s_lan[MAXP][RB * 16];             // conditional log-amplitudes, pair-major
     __shared__ __attribute__((aligned(16))) float s_part[WS_MW][RB * 16][4];   // the output layer's partial rows, per matrix wave
+    __shared__ float s_recv[SPLIT ? RB * 16 : 1][4];                           // SPLIT: the producer's partial rows
     constexpr int BM = RB * 16;
     constexpr int FMT = 2, NP = 2;
     constexpr int AW = PH_WAVES - WS_MW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int n_tiles = SPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const bool producer = SPLIT && (int)blockIdx.x < n_tiles;                   // (workgroup-uniform)
+    const int tile = SPLIT && !producer ? (int)blockIdx.x - n_tiles : (int)blockIdx.x;
+    const int64_t row0 = (int64_t)tile * BM;
     const int P = d.P, ldh = d.ldh;
     float *s_o = reinterpret_cast<float *>(planes + (size_t)NP * BM * ldh);     // [P][BM][8] raw outputs of the items
     const bool ha64 = d.Ha == 64;
@@ -1248,7 +1265,11 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     if (tid < BM && row0 + tid < M) key = keys[row0 + tid];
     const int aw = wave >= WS_MW ? wave - WS_MW : 0;
     const int items = RB * P;
-    const int first_pair = (items * aw / AW) / RB;
+    // a shared tile's items: the lower pairs with the consumer (which also has the hand-over and the epilogue), the upper with
+    // the producer, whose conditionals travel like its partial rows
+    const int q_split = SPLIT ? (P / 2) * RB : items;
+    const int qlo = producer ? q_split : 0, qhi = producer ? items : q_split;
+    const int first_pair = (qlo + (qhi - qlo) * aw / AW) / RB;
     AmpFrag<4> f4;
     AmpFrag<2> f2;
     if (wamp != nullptr && wave >= WS_MW) {                // (wave-uniform)
@@ -1307,7 +1328,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
                 acc0[rb][c] = v;
             }
         }
-        if (SAVE && save.x != nullptr) {                                   // training forward: the inputs also go to HBM
+        if (SAVE && save.x != nullptr && !producer) {                      // training forward: the inputs also go to HBM
             const int nin = 2 * (P - 1);
             for (int e = tid; e < BM * nin; e += PH_THREADS) {
                 const int r = e / nin, k = e - r * nin;
@@ -1318,7 +1339,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
                 }
             }
         }
-        ws_writeback4<RB, SAVE, CBT, 0>(planes, ldh, acc0, bvs0, (cb0 >> 2) * 64 + 4 * m, lane, save.act[0], save.act_ld[0], row0, M, sc);
+        ws_writeback4<RB, SAVE, CBT, 0>(planes, ldh, acc0, bvs0, (cb0 >> 2) * 64 + 4 * m, lane, producer ? nullptr : save.act[0], save.act_ld[0],
+                                        row0, M, sc);
     }
     asm volatile("" ::"v"(warm0), "v"(warm1));
     __syncthreads();
@@ -1328,25 +1350,27 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     sc.c = scales->c[1]; sc.sn = scales->sn[1]; sc.isn = scales->isn[1];
     const int N1 = d.N_pad[1], Kh1 = d.Kh_pad[1];
     if (wave < WS_MW) {
-        f32x4 acc[RB][WS_NCT];
-        float bvs[WS_NCT];
+        constexpr int NCT = SPLIT ? WS_NCT / 2 : WS_NCT;                   // column tiles of this wave: one or two groups of 64 columns
+        constexpr int NG = NCT / 4;
+        f32x4 acc[RB][NCT];
+        float bvs[NCT];
         if (flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int c = 0; c < WS_NCT; ++c) acc[rb][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int cb0 = wave * WS_NCT;
+            for (int c = 0; c < NCT; ++c) acc[rb][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int cb0 = (producer ? WS_MW * NCT : 0) + wave * NCT;
         const float *bias = w + d.b_off[1];
 #pragma unroll
-        for (int c = 0; c < WS_NCT; ++c) bvs[c] = bias[tile_col(cb0 + c, m, N1)] * sc.sn;
+        for (int c = 0; c < NCT; ++c) bvs[c] = bias[tile_col(cb0 + c, m, N1)] * sc.sn;
         // (developer aid: bits 4 / 8 skip the amplitude / the matrix work, 16 / 32 the MFMAs / the stream — timing only, wrong results)
         const ushort_t *a_ptr = planes + m * ldh + 8 * kg, *w_ptr = wh + d.wh_off[1] + (size_t)cb0 * Kh1 * 16 + lane * 8;
         if (flags & 8) {}
 #ifdef NAQS_WS_DEBUG
-        else if (flags & 16) ws_accumulate<RB, 1>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
-        else if (flags & 32) ws_accumulate<RB, 2>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
+        else if (flags & 16) ws_accumulate<RB, 1, NCT>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
+        else if (flags & 32) ws_accumulate<RB, 2, NCT>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
 #endif
-        else ws_accumulate<RB>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
+        else ws_accumulate<RB, 0, NCT>(a_ptr, ldh, BM * ldh, w_ptr, Kh1, (size_t)N1 * Kh1, acc);
         if (flags & 1) __builtin_amdgcn_s_setprio(0);
         NAQS_MARK(9);
         // the output layer (512 -> 4) straight from the accumulators, in f32: h = max(acc c + sn b, 0) is sn x the hidden
@@ -1357,9 +1381,9 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
         const float *W2 = w + d.w_off[2];
         const int K2 = d.K_pad[2];
         const int g0 = cb0 >> 2;
-        f32x4 wv[2][4];                                                    // [group][output]: four adjacent columns each
+        f32x4 wv[NG][4];                                                   // [group][output]: four adjacent columns each
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int o = 0; o < 4; ++o) wv[g][o] = *reinterpret_cast<const f32x4 *>(W2 + (size_t)o * K2 + (g0 + g) * 64 + 4 * m);
 #pragma unroll
@@ -1369,7 +1393,7 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
                 const int row = rb * 16 + kg * 4 + r;
                 float po[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < NG; ++g) {
                     float h[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) h[c] = fmaxf(fmaf(acc[rb][4 * g + c][r], sc.c, bvs[4 * g + c]), 0.0f);
@@ -1397,14 +1421,48 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     } else {
         if (flags & 2) __builtin_amdgcn_s_setprio(1);
         if ((flags & 4) || wamp == nullptr) {}
-        else if (ha64) ws_amp_work<4, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f4, aw, lane, save.clk, wave);
-        else ws_amp_work<2, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f2, aw, lane, save.clk, wave);
+        else if (ha64) ws_amp_work<4, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f4, aw, lane, save.clk, wave, qlo, qhi, !producer);
+        else ws_amp_work<2, RB>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f2, aw, lane, save.clk, wave, qlo, qhi, !producer);
         if (flags & 2) __builtin_amdgcn_s_setprio(0);
     }
     NAQS_MARK(10);
     __syncthreads();                                      // the output partials and s_lan are complete
     NAQS_MARK(6);
 
+    if constexpr (SPLIT) {
+        // words of a tile: [BM][4] partial rows of the output layer, then [pairs of the producer][BM] conditional log-amplitudes
+        constexpr int TILE_WORDS = BM * 4 + MAXP * BM;
+        unsigned long long *xw = split.xchg + (size_t)tile * TILE_WORDS;
+        const int n_split = q_split / RB, n_amp = wamp != nullptr ? (P - n_split) * BM : 0;
+        const unsigned long long tagw = (unsigned long long)split.tag << 32;
+        if (producer) {                                   // hand the upper columns' partial rows and the upper pairs to the consumer, and done
+            for (int x = tid; x < BM * 4 + n_amp; x += PH_THREADS) {
+                float v;
+                if (x < BM * 4) {
+                    const int r = x >> 2, o = x & 3;
+                    v = (s_part[0][r][o] + s_part[1][r][o]) + (s_part[2][r][o] + s_part[3][r][o]);
+                } else {
+                    const int e = x - BM * 4;
+                    v = s_lan[n_split + e / BM][e % BM];
+                }
+                __hip_atomic_store(&xw[x], tagw | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // the consumer: a word per thread (and round), all requests in flight together.  The producer has a lower workgroup
+        // index: it was dispatched before this workgroup, so it is running or has finished
+        for (int x = tid; x < BM * 4 + n_amp; x += PH_THREADS) {
+            unsigned long long word = __hip_atomic_load(&xw[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((word & 0xFFFFFFFF00000000ull) != tagw) {
+                __builtin_amdgcn_s_sleep(2);
+                word = __hip_atomic_load(&xw[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float v = __uint_as_float((uint32_t)word);
+            if (x < BM * 4) s_recv[x >> 2][x & 3] = v;
+            else { const int e = x - BM * 4; s_lan[n_split + e / BM][e % BM] = v; }
+        }
+        __syncthreads();
+    }
     if (tid < BM) {
         const int64_t i = row0 + tid;
         if (i < M) {
@@ -1413,8 +1471,9 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
             else for (int n = 0; n < P; ++n) la += scratch[(int64_t)n * M + i];
             const uint32_t ab = s_ab[tid];
             const int occ = (int)((ab >> (P - 1)) & 1u) + 2 * (int)((ab >> (16 + P - 1)) & 1u);
-            const float ph = fmaf((s_part[0][tid][occ] + s_part[1][tid][occ]) + (s_part[2][tid][occ] + s_part[3][tid][occ]), sc.isn,
-                                  (w + d.b_off[2])[occ]);
+            float psum = (s_part[0][tid][occ] + s_part[1][tid][occ]) + (s_part[2][tid][occ] + s_part[3][tid][occ]);
+            if constexpr (SPLIT) psum += s_recv[tid][occ];
+            const float ph = fmaf(psum, sc.isn, (w + d.b_off[2])[occ]);
             out[i] = make_float2(la, ph);
             if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
         }
@@ -1862,7 +1921,9 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
 #undef NAQS_PH_ATTR
 #define NAQS_WS_ATTR(RB)                                                                                                                 \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all);
             NAQS_WS_ATTR(1) NAQS_WS_ATTR(2) NAQS_WS_ATTR(3)
 #undef NAQS_WS_ATTR
             (void)hipGetLastError();            // a refused attribute must not stay behind as the runtime's "last error"
@@ -1898,6 +1959,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->side_stream) (void)hipStreamDestroy(net->side_stream);
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_scales) (void)hipFree(net->d_scales);
+    if (net->d_ws_xchg) (void)hipFree(net->d_ws_xchg);
     delete net;
     return NAQS_OK;
 }
@@ -2171,13 +2233,38 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         if (rb_ws * lds_h16 + (size_t)d.P * rb_ws * 16 * 8 * sizeof(float) > 155 * 1024) ws = false;
         else rb = rb_ws;
     }
+    // small tables: two workgroups per tile share the big layer (phase_kernel_ws<RB, SAVE, true>) while both halves of every
+    // tile are resident together, one workgroup per CU; NAQS_WS_SPLIT=0: never; NAQS_WS_SPLIT_RB: the tile height of that form
+    bool ws_split = false;
+    if (ws && naqs::env_int("NAQS_WS_SPLIT", 1) != 0) {
+        int rbs = naqs::env_int("NAQS_WS_SPLIT_RB", 0);
+        if (rbs < 1 || rbs > 3) rbs = 1;
+        const int64_t tiles = (M + 16 * rbs - 1) / (16 * rbs);
+        if (2 * tiles <= net->cu_count && rbs * lds_h16 + (size_t)d.P * rbs * 16 * 8 * sizeof(float) <= 155 * 1024) { ws_split = true; rb = rbs; }
+    }
     const int bm = rb * 16;
     const unsigned grid = (unsigned)((M + bm - 1) / bm);
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
+    WsSplit split{nullptr, 0u};
+    if (ws_split) {
+        const size_t words = (size_t)(net->cu_count / 2) * (48 * 4 + MAXP * 48);      // per tile (of up to 48 rows): partial rows + the producer's conditionals
+        if (!net->d_ws_xchg) {
+            HIP_TRY(hipMalloc((void **)&net->d_ws_xchg, words * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(net->d_ws_xchg, 0, words * sizeof(unsigned long long)));      // tag 0 = never written
+            HIP_TRY(hipDeviceSynchronize());               // (a null-stream fill is not ordered against the callers' streams)
+            net->ws_seq = 0;
+        }
+        if (++net->ws_seq == 0u) {                         // the 32-bit call tag is about to repeat: forget every old word
+            HIP_TRY(hipMemsetAsync(net->d_ws_xchg, 0, words * sizeof(unsigned long long), s));
+            net->ws_seq = 1u;
+        }
+        split.xchg = net->d_ws_xchg;
+        split.tag = net->ws_seq;
+    }
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
-    if (ws) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_ws<RB=%d, SAVE=%d> (f16x2%s)", rb,
-                          save.x != nullptr ? 1 : 0, amp_in_phase ? ", amplitude waves beside the matrix waves" : "");
+    if (ws) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_ws<RB=%d, SAVE=%d%s> (f16x2%s)", rb,
+                          save.x != nullptr ? 1 : 0, ws_split ? ", SPLIT=1" : "", amp_in_phase ? ", amplitude waves beside the matrix waves" : "");
     else if (use_h) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_h<RB=%d, SAVE=%d, FMT=%d (%s)>%s", rb, save.x != nullptr ? 1 : 0,
                              fmt, fmt == 2 ? "f16x2" : "bf16x3", amp_in_phase ? " incl. amplitude prologue" : "");
     else std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel<RB=%d> (f32 MFMA)", rb);
@@ -2186,14 +2273,28 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         const int flags = naqs::env_int("NAQS_WS_FLAGS", 0);
 #define NAQS_WS_LAUNCH(RB)                                                                                                              \
         do {                                                                                                                            \
-            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_ws<RB, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags); \
-            else hipLaunchKernelGGL((phase_kernel_ws<RB, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags); \
+            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_ws<RB, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            else hipLaunchKernelGGL((phase_kernel_ws<RB, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
         } while (0)
-        switch (rb) {
-            case 1: NAQS_WS_LAUNCH(1); break;
-            case 2: NAQS_WS_LAUNCH(2); break;
-            default: NAQS_WS_LAUNCH(3); break;
+#define NAQS_WS_LAUNCH_SPLIT(RB)                                                                                                        \
+        do {                                                                                                                            \
+            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_ws<RB, true, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            else hipLaunchKernelGGL((phase_kernel_ws<RB, false, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+        } while (0)
+        if (ws_split) {
+            switch (rb) {
+                case 1: NAQS_WS_LAUNCH_SPLIT(1); break;
+                case 2: NAQS_WS_LAUNCH_SPLIT(2); break;
+                default: NAQS_WS_LAUNCH_SPLIT(3); break;
+            }
+        } else {
+            switch (rb) {
+                case 1: NAQS_WS_LAUNCH(1); break;
+                case 2: NAQS_WS_LAUNCH(2); break;
+                default: NAQS_WS_LAUNCH(3); break;
+            }
         }
+#undef NAQS_WS_LAUNCH_SPLIT
 #undef NAQS_WS_LAUNCH
     } else if (use_h) {
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);

@@ -186,6 +186,8 @@ struct naqs_net {
     int packed_fmt = 0;                     // split format of d_wh: 1 = three bf16 planes, 2 = two scaled f16 planes
     naqs::PhaseRaw *d_raw = nullptr;        // partial weight maxima of the phase layers (net_bounds_kernel -> pack_net_kernel)
     naqs::PhaseScales *d_scales = nullptr;  // the f16x2 scales of the current weights
+    unsigned long long *d_ws_xchg = nullptr;   // phase_kernel_ws<.., SPLIT>: the producers' partial rows (tag << 32 | float), [cu_count / 2][64]
+    uint32_t ws_seq = 0;                       // call tag of the last split launch (0 = no word written yet)
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)

@@ -429,3 +429,52 @@ def test_fresh_network_on_a_side_stream_of_a_busy_gpu():
             side.synchronize()
         assert torch.equal(got, quiet) and torch.equal(got_train, quiet_train), rep
     torch.cuda.synchronize()
+
+
+def test_big_layer_shared_by_two_workgroups_agrees_with_one(monkeypatch):
+    """Small tables (two workgroups per 16-row tile still fit the chip): phase_kernel_ws<1, SAVE, SPLIT> halves the big layer's
+    weight stream per workgroup; the producer's partial rows reach the consumer as tagged words.  Against the one-workgroup
+    form (NAQS_WS_SPLIT=0), inference and training forward alike: log|psi| identical, the phase within rounding of the
+    different final add (2e-6), gradients (they read the activations the two halves saved) to 1e-5 of their scale; repeated
+    calls (the call tag moves on) and ragged / single-row / just-too-large tables included."""
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    from naqs_amd.hamiltonian import keys_to_device
+    from test_eloc_gpu import random_physical_keys
+    z = golden("nade_N2.npz")
+    hil, wf = make_wf("N2", z, device="cuda")
+    fused = FusedLogPsi(wf)
+    assert fused.train_mode == "hip"
+    cu = torch.cuda.get_device_properties(0).multi_processor_count
+    all_keys = random_physical_keys(20, 7, 7, 16 * (cu // 2) + 40, 11).astype(np.int64)
+    params = list(wf.model.parameters())
+    for rep, M in enumerate([1, 15, 16, 17, 333, 1200, 16 * (cu // 2), 16 * (cu // 2) + 1, 1200, 1200, 1200]):
+        keys = keys_to_device(np.sort(np.roll(all_keys, 7 * rep)[:M]), "cuda")
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        g = torch.randn((M, 2), device="cuda", generator=gen) / M
+        res = {}
+        for split in ("1", "0"):
+            monkeypatch.setenv("NAQS_WS_SPLIT", split)
+            lp = fused.log_psi(keys).clone()
+            name = fused.last_kernel()
+            for p in params:
+                p.grad = None
+            lpt, saved = fused.forward_saved(keys)
+            name_t = fused.last_kernel()
+            fused.backward_saved(saved, g)
+            res[split] = (lp, lpt.clone(), [None if p.grad is None else p.grad.clone() for p in params], name, name_t)
+        fits = 2 * ((M + 15) // 16) <= cu
+        assert ("SPLIT=1" in res["1"][3]) == fits and ("SPLIT=1" in res["1"][4]) == fits, (M, res["1"][3], res["1"][4])
+        assert "SAVE=0" in res["1"][3] and "SAVE=1" in res["1"][4]
+        assert "SPLIT" not in res["0"][3] and "SPLIT" not in res["0"][4] and "phase_kernel_ws<RB=1" in res["0"][3]
+        for a, b in ((res["1"][0], res["0"][0]), (res["1"][1], res["0"][1])):
+            assert torch.equal(a[:, 0], b[:, 0])
+            assert torch.max(torch.abs(a[:, 1] - b[:, 1])).item() < 2e-6
+            assert fits or torch.equal(a, b)
+        assert torch.equal(res["1"][0], res["1"][1])           # inference and training forward: the same kernel, the same values
+        for (pname, _), a, b in zip(wf.model.named_parameters(), res["1"][2], res["0"][2]):
+            if b is None:
+                assert a is None
+                continue
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) < 1e-5 * scale + 1e-10, (M, pname)
