@@ -27,7 +27,7 @@ def _energies(run_dir):
 def test_replicas_sharing_a_gpu_reproduce_their_solo_runs(tmp_path):
     mols = ",".join(os.path.join(GOLDEN, f"ham_{m}.npz") for m in ("LiH", "H2O"))
     runs = {}
-    for k in (1, 2):
+    for k in (1, 2, 4):                 # (k > 2: the farm caps the runtime at two hardware queues, all four jobs start together)
         out = str(tmp_path / f"k{k}")
         subprocess.run([sys.executable, "-m", "experiments.run", "--farm", "--per-gpu", str(k), "--gpus", "1", "--seeds", "111,222",
                         "-m", mols, "-o", out] + FLAGS, cwd=PKG, check=True, stdout=subprocess.DEVNULL, timeout=300)
@@ -36,5 +36,5 @@ def test_replicas_sharing_a_gpu_reproduce_their_solo_runs(tmp_path):
         runs[k] = {n: _energies(os.path.join(out, n)) for n in names}
         assert all(os.path.exists(os.path.join(out, n, "summary.txt")) for n in names)
     for n, e in runs[1].items():
-        assert len(e) == 300 and (e == runs[2][n]).all(), n                    # bit-identical trajectories
+        assert len(e) == 300 and (e == runs[2][n]).all() and (e == runs[4][n]).all(), n      # bit-identical trajectories
     assert not (runs[1]["ham_LiH_s111"] == runs[1]["ham_LiH_s222"]).all()       # and the seeds do differ
