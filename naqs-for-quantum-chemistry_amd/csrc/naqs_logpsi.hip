@@ -1123,6 +1123,17 @@ __device__ __forceinline__ void ws_accumulate(const ushort_t *__restrict__ a_ptr
     }
 }
 
+// the training forward's saved activations: written once, read by a later launch
+#ifndef NAQS_SAVE_NT
+#define NAQS_SAVE_NT 1
+#endif
+__device__ __forceinline__ void save_store(f32x4 *ptr, const f32x4 val) {
+#if NAQS_SAVE_NT
+    __builtin_nontemporal_store(val, ptr);
+#else
+    *ptr = val;
+#endif
+}
 // write-back of four interleaved column tiles (64 adjacent columns: a lane owns four adjacent ones, tile_col) of a matrix wave
 template <int RB, bool SAVE, int NCT, int C0>
 __device__ __forceinline__ void ws_writeback4(ushort_t *__restrict__ planes, int ldh, f32x4 (&acc)[RB][NCT],
@@ -1140,8 +1151,8 @@ __device__ __forceinline__ void ws_writeback4(ushort_t *__restrict__ planes, int
             for (int c = 0; c < 4; ++c) h[c] = fmaxf(fmaf(acc[rb][C0 + c][r], sc.c, bvs[C0 + c]), 0.0f);
             const int row = rb * 16 + kg * 4 + r;
             if (SAVE && save != nullptr && row0 + row < M)
-                *reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0) =
-                    (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn};
+                save_store(reinterpret_cast<f32x4 *>(save + (row0 + row) * save_ld + col0),
+                           (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn});
             ushort_t *dst = planes + row * ldh + col0;                              // 8-byte aligned
             uint32_t a1, a2, b1, b2;
             split2_pair(h[0], h[1], a1, a2);
@@ -1398,8 +1409,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
 #pragma unroll
                     for (int c = 0; c < 4; ++c) h[c] = fmaxf(fmaf(acc[rb][4 * g + c][r], sc.c, bvs[4 * g + c]), 0.0f);
                     if (SAVE && save.act[1] != nullptr && row0 + row < M)
-                        *reinterpret_cast<f32x4 *>(save.act[1] + (row0 + row) * save.act_ld[1] + (g0 + g) * 64 + 4 * m) =
-                            (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn};
+                        save_store(reinterpret_cast<f32x4 *>(save.act[1] + (row0 + row) * save.act_ld[1] + (g0 + g) * 64 + 4 * m),
+                                   (f32x4){h[0] * sc.isn, h[1] * sc.isn, h[2] * sc.isn, h[3] * sc.isn});
 #pragma unroll
                     for (int o = 0; o < 4; ++o)
 #pragma unroll

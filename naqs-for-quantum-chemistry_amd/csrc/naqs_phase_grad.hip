@@ -317,29 +317,39 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, co
 }
 
 // Dout[i][k] = [In[i][k] > 0] * sum_n D[i][n] W[n][k]
-// (bx, by: sample tile and column tile; Ds: [TB * LDD], Ws: [CH * LDT] floats of LDS)
+// (bx, by: sample tile and column tile; Ds: [TBM * LDD], Ws: [CH * LDT] floats of LDS)
+// TBM = 64 or 32 samples per tile (a wave owns TBM / 2 of them x 32 columns).  The kernel is a chain of Np / CH chunks of
+// load -> barrier -> MFMAs -> barrier; at a training step's ~1 200 rows the 64-row form is 160 workgroups of 16 chunks x 32
+// exact-f32 MFMAs each (20.8 us as a launch of its own), the 32-row form twice the workgroups of half the MFMAs per chunk.
+// Every output element accumulates over n in the same order in both: identical results.
+template <int TBM>
 __device__ __forceinline__ void grad_in_body(const float *__restrict__ D, const float *__restrict__ W,
                                              const float *__restrict__ In, const int64_t M, const int Np, const int Kp,
                                              float *__restrict__ Dout, const int bx, const int by, float *Ds, float *Ws) {
-    const int64_t i0 = (int64_t)bx * TB;
+    static_assert(TBM == 64 || TBM == 32, "two or one 16-row MFMA tiles per wave");
+    constexpr int RA = TBM / 32;                        // 16-row tiles of a wave
+    constexpr int UD = TBM / 32;                        // float4 of the delta tile per thread and chunk
+    const int64_t i0 = (int64_t)bx * TBM;
     const int k0 = by * TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wk = wave & 1, lm = lane & 15, lq = lane >> 4;
-    f32x4 acc[2][2];
+    f32x4 acc[RA][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // next chunk's tiles in registers while this chunk's MFMAs run (see grad_w_kernel)
-    f32x4 vd[2], vw[2];
+    f32x4 vd[UD], vw[2];
     auto fetch = [&](int nn0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
-            const int r = e >> 3, c4 = e & 7;
-            const int64_t i = i0 + r;
-            vd[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (i < M) vd[u] = *reinterpret_cast<const f32x4 *>(D + i * Np + nn0 + 4 * c4);
+            if (u < UD) {
+                const int r = e >> 3, c4 = e & 7;
+                const int64_t i = i0 + r;
+                vd[u < UD ? u : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < M) vd[u < UD ? u : 0] = *reinterpret_cast<const f32x4 *>(D + i * Np + nn0 + 4 * c4);
+            }
             const int rw = e >> 4, cw = e & 15;
             vw[u] = *reinterpret_cast<const f32x4 *>(W + (int64_t)(nn0 + rw) * Kp + k0 + 4 * cw);
         }
@@ -349,11 +359,11 @@ __device__ __forceinline__ void grad_in_body(const float *__restrict__ D, const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
-            {   // delta tile: 64 samples x 32 n
+            if (u < UD) {   // delta tile: TBM samples x 32 n
                 const int r = e >> 3, c4 = e & 7;
                 float2 *dst = reinterpret_cast<float2 *>(Ds + r * LDD + 4 * c4);     // LDD even: 8-byte aligned
-                dst[0] = make_float2(vd[u][0], vd[u][1]);
-                dst[1] = make_float2(vd[u][2], vd[u][3]);
+                dst[0] = make_float2(vd[u < UD ? u : 0][0], vd[u < UD ? u : 0][1]);
+                dst[1] = make_float2(vd[u < UD ? u : 0][2], vd[u < UD ? u : 0][3]);
             }
             {   // weight tile: 32 n x 64 k
                 const int r = e >> 4, c4 = e & 15;
@@ -365,22 +375,23 @@ __device__ __forceinline__ void grad_in_body(const float *__restrict__ D, const 
 #pragma unroll
         for (int ks = 0; ks < CH / 4; ++ks) {
             const int kk = ks * 4 + lq;
-            const float a0 = Ds[(wi * 32 + lm) * LDD + kk], a1 = Ds[(wi * 32 + 16 + lm) * LDD + kk];
             const float b0 = Ws[kk * LDT + wk * 32 + lm], b1 = Ws[kk * LDT + wk * 32 + 16 + lm];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                const float av = Ds[(wi * (TBM / 2) + a * 16 + lm) * LDD + kk];
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[a][1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < RA; ++ti)
 #pragma unroll
         for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t i = i0 + wi * 32 + ti * 16 + 4 * lq + r;
+                const int64_t i = i0 + wi * (TBM / 2) + ti * 16 + 4 * lq + r;
                 const int k = k0 + wk * 32 + tk * 16 + lm;
                 if (i < M) Dout[i * Kp + k] = In[i * Kp + k] > 0.0f ? acc[ti][tk][r] : 0.0f;
             }
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
                                                       float *__restrict__ Dout) {
     __shared__ __attribute__((aligned(16))) float Ds[TB * LDD];
     __shared__ __attribute__((aligned(16))) float Ws[CH * LDT];
-    grad_in_body(D, W, In, M, Np, Kp, Dout, (int)blockIdx.x, (int)blockIdx.y, Ds, Ws);
+    grad_in_body<TB>(D, W, In, M, Np, Kp, Dout, (int)blockIdx.x, (int)blockIdx.y, Ds, Ws);
 }
 
 // The three independent pieces of the backward pass below the seeds, as ONE launch (the training step's usual network: two
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
 // (Measured and rejected: the first layer's blocks inside this launch too, waiting on a device-scope count of the finished
 // grad_in blocks — the fences and the polling cost 12-18 us per step more than the 7 us launch they replace.)
 struct MegaArgs {
-    int n_gin, gin_tiles_i, n_amp, amp_wgs;
+    int n_gin, gin_tiles_i, gin_tbm, n_amp, amp_wgs;      // gin_tbm: 64 or 32 samples per grad_in tile
     const float *D, *W, *In;
     float *Dout;
     int Np, Kp;
@@ -420,7 +431,8 @@ __global__ __launch_bounds__(256) void backward_mega_kernel(const MegaArgs A, co
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
     if (bid < A.n_gin) {
-        grad_in_body(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD);
+        if (A.gin_tbm == 32) grad_in_body<32>(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD);
+        else grad_in_body<TB>(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD);
         return;
     }
     bid -= A.n_gin;
@@ -783,7 +795,11 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
             continue;
         }
         if (mega) {                                       // (l == 1 here: part of the one launch below)
-            A.n_gin = (int)((M + TB - 1) / TB) * (Kp / TB); A.gin_tiles_i = (int)((M + TB - 1) / TB);
+            // 32-row tiles while even those leave CUs to spare beside the launch's other pieces (NAQS_GRAD_IN_TBM: 32 / 64 forces)
+            const int tbm_env = naqs::env_int("NAQS_GRAD_IN_TBM", 0);
+            A.gin_tbm = tbm_env == 32 || tbm_env == 64 ? tbm_env : ((M + 31) / 32 * (Kp / TB) <= 4ll * net->cu_count ? 32 : 64);
+            A.gin_tiles_i = (int)((M + A.gin_tbm - 1) / A.gin_tbm);
+            A.n_gin = A.gin_tiles_i * (Kp / TB);
             A.D = dl[l]; A.W = net->d_wb + wb_offset(net, l); A.In = in; A.Dout = dnext; A.Np = Np; A.Kp = Kp;
             dl[l - 1] = dnext;
             continue;
