@@ -41,6 +41,7 @@ constexpr int TB = 64;       // output block edge
 constexpr int CH = 32;       // reduction chunk staged in LDS
 constexpr int LDT = 80;      // row stride of a [CH][64] tile: 80 = 16 mod 32 -> lanes (k, k+1) x 16 columns cover 32 banks
 constexpr int LDD = 34;      // row stride of a [64][CH] tile: bank = 2 row + k -> conflict-free for 16 rows x 2 k
+constexpr int W0_FUSE_MAX_ROWS = 4096;   // tables up to this size: the first layer's weight gradient is formed by the grad_in blocks
 
 inline int pad64(int x) { return (x + 63) & ~63; }
 
@@ -322,10 +323,17 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, co
 // load -> barrier -> MFMAs -> barrier; at a training step's ~1 200 rows the 64-row form is 160 workgroups of 16 chunks x 32
 // exact-f32 MFMAs each (20.8 us as a launch of its own), the 32-row form twice the workgroups of half the MFMAs per chunk.
 // Every output element accumulates over n in the same order in both: identical results.
+// w0 (backward_mega_kernel, small tables): the tile's delta never leaves the workgroup — it is the P operand of the FIRST
+// layer's weight gradient dW0[n][j] = sum_i delta[i][n] x[i][j], whose slice `bx` (= this tile's rows) the workgroup forms
+// right here, chunk by chunk of 32 rows with grad_w_body's own loop (same operands, same MFMA order: the numbers of
+// grad_w_kernel on job 0 with rows_per_slice = TBM), instead of a launch of its own behind this one.
+struct W0Fuse { const float *x; int x_ld; float *cpart, *bpart; int Kp0; };
+
 template <int TBM>
 __device__ __forceinline__ void grad_in_body(const float *__restrict__ D, const float *__restrict__ W,
                                              const float *__restrict__ In, const int64_t M, const int Np, const int Kp,
-                                             float *__restrict__ Dout, const int bx, const int by, float *Ds, float *Ws) {
+                                             float *__restrict__ Dout, const int bx, const int by, float *Ds, float *Ws,
+                                             const W0Fuse *w0 = nullptr) {
     static_assert(TBM == 64 || TBM == 32, "two or one 16-row MFMA tiles per wave");
     constexpr int RA = TBM / 32;                        // 16-row tiles of a wave
     constexpr int UD = TBM / 32;                        // float4 of the delta tile per thread and chunk
@@ -385,16 +393,86 @@ __device__ __forceinline__ void grad_in_body(const float *__restrict__ D, const 
         }
         __syncthreads();
     }
+    if (w0 == nullptr) {
 #pragma unroll
-    for (int ti = 0; ti < RA; ++ti)
+        for (int ti = 0; ti < RA; ++ti)
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t i = i0 + wi * (TBM / 2) + ti * 16 + 4 * lq + r;
+                    const int k = k0 + wk * 32 + tk * 16 + lm;
+                    if (i < M) Dout[i * Kp + k] = In[i * Kp + k] > 0.0f ? acc[ti][tk][r] : 0.0f;
+                }
+        return;
+    }
+    // (the main loop ended with a barrier: the LDS tiles are free)
+    float *Ps = Ds, *Qs = Ds + CH * LDT;                  // [CH][LDT] each: masked delta rows x 64 columns, input rows x Kp0
+    const int wn = wave >> 1;
+    f32x4 acc2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < TBM / CH; ++c) {                  // chunk c: the tile's rows 32 c .. 32 c + 31
+        if (c > 0) __syncthreads();
+#pragma unroll
+        for (int ti = 0; ti < RA; ++ti)
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wi * (TBM / 2) + ti * 16 + 4 * lq + r;              // row of the tile this value belongs to
+                    if (row / CH == c) {
+                        const int64_t i = i0 + row;
+                        const int k = k0 + wk * 32 + tk * 16 + lm;
+                        Ps[(row - c * CH) * LDT + wk * 32 + tk * 16 + lm] = (i < M && In[i * Kp + k] > 0.0f) ? acc[ti][tk][r] : 0.0f;
+                    }
+                }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u, r = e >> 4, c4 = e & 15;
+            const int64_t i = i0 + c * CH + r;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i < M && 4 * c4 < w0->Kp0) v = *reinterpret_cast<const f32x4 *>(w0->x + i * w0->x_ld + 4 * c4);
+            *reinterpret_cast<f32x4 *>(Qs + r * LDT + 4 * c4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < CH / 4; ++ks) {
+            const int kk = ks * 4 + lq;
+            const float a0 = Ps[kk * LDT + wn * 32 + lm], a1 = Ps[kk * LDT + wn * 32 + 16 + lm];
+            const float b0 = Qs[kk * LDT + wk * 32 + lm], b1 = Qs[kk * LDT + wk * 32 + 16 + lm];
+            acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc2[0][0], 0, 0, 0);
+            acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc2[0][1], 0, 0, 0);
+            acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc2[1][0], 0, 0, 0);
+            acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2[1][1], 0, 0, 0);
+            bsum[0] += a0;
+            bsum[1] += a1;
+        }
+    }
+    // slice bx of job 0's partials: rows n = this tile's delta columns, columns k = the Kp0 (padded) inputs
+    const int Kp0 = w0->Kp0;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t i = i0 + wi * (TBM / 2) + ti * 16 + 4 * lq + r;
-                const int k = k0 + wk * 32 + tk * 16 + lm;
-                if (i < M) Dout[i * Kp + k] = In[i * Kp + k] > 0.0f ? acc[ti][tk][r] : 0.0f;
+                const int n = k0 + wn * 32 + tn * 16 + 4 * lq + r, k = wk * 32 + tk * 16 + lm;
+                if (k < Kp0) w0->cpart[((int64_t)bx * Kp + n) * Kp0 + k] = acc2[tn][tk][r];
             }
+    if (wk == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = bsum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) w0->bpart[(int64_t)bx * Kp + k0 + wn * 32 + t * 16 + lane] = v;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ D, const float *__restrict__ W,
@@ -415,6 +493,8 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float *__restrict__ 
 // grad_in blocks — the fences and the polling cost 12-18 us per step more than the 7 us launch they replace.)
 struct MegaArgs {
     int n_gin, gin_tiles_i, gin_tbm, n_amp, amp_wgs;      // gin_tbm: 64 or 32 samples per grad_in tile
+    int fuse_w0;                                          // the grad_in blocks also form the first layer's weight gradient
+    W0Fuse w0;
     const float *D, *W, *In;
     float *Dout;
     int Np, Kp;
@@ -431,8 +511,9 @@ __global__ __launch_bounds__(256) void backward_mega_kernel(const MegaArgs A, co
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
     if (bid < A.n_gin) {
-        if (A.gin_tbm == 32) grad_in_body<32>(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD);
-        else grad_in_body<TB>(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD);
+        const W0Fuse *w0 = A.fuse_w0 ? &A.w0 : nullptr;
+        if (A.gin_tbm == 32) grad_in_body<32>(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD, w0);
+        else grad_in_body<TB>(A.D, A.W, A.In, A.M, A.Np, A.Kp, A.Dout, bid % A.gin_tiles_i, bid / A.gin_tiles_i, smem, smem + TB * LDD, w0);
         return;
     }
     bid -= A.n_gin;
@@ -476,7 +557,8 @@ TrainLayout train_layout(const naqs_net *net, int64_t cap) {
     for (int l = 0; l <= H; ++l) {
         const int64_t Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
         const int64_t blocks = (Np / TB) * (Kp / TB);
-        const int64_t slices = std::max<int64_t>(1, 512 / blocks);
+        int64_t slices = std::max<int64_t>(1, 512 / blocks);
+        if (l == 0) slices = std::max<int64_t>(slices, W0_FUSE_MAX_ROWS / 32);      // one slice per 32-row tile of the fused form
         worst += slices * Np * Kp;
         worst_b += slices * Np;
     }
@@ -781,6 +863,14 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     const float *dl[MAXL];                            // delta of linear layer l's output
     dl[H] = top;
     MegaArgs A{};
+    // tile height of the first hidden layer's delta (grad_in): 32 rows while even those leave CUs to spare beside the launch's
+    // other pieces (NAQS_GRAD_IN_TBM: 32 / 64 forces).  Small tables: the same workgroups form the first layer's weight
+    // gradient (W0Fuse; NAQS_FUSE_W0=0: a launch of its own) — job 0 is then sliced by those tiles in EITHER form of the
+    // backward pass, so that the one launch and its pieces stay bit-identical
+    const int tbm_env = naqs::env_int("NAQS_GRAD_IN_TBM", 0);
+    const int gin_tbm = tbm_env == 32 || tbm_env == 64 ? tbm_env
+                                                       : ((M + 31) / 32 * (pad64(net->phase_K[(size_t)(H >= 1 ? 1 : 0)]) / TB) <= 4ll * net->cu_count ? 32 : 64);
+    const bool w0_tiles = H == 2 && d.Ha == 64 && M <= W0_FUSE_MAX_ROWS && pad64(net->phase_K[0]) == TB;
     for (int l = H; l > 0; --l) {
         const int Np = pad64(net->phase_N[(size_t)l]), Kp = pad64(net->phase_K[(size_t)l]);
         const float *in = reinterpret_cast<const float *>(base + L.act[l - 1]);
@@ -795,9 +885,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
             continue;
         }
         if (mega) {                                       // (l == 1 here: part of the one launch below)
-            // 32-row tiles while even those leave CUs to spare beside the launch's other pieces (NAQS_GRAD_IN_TBM: 32 / 64 forces)
-            const int tbm_env = naqs::env_int("NAQS_GRAD_IN_TBM", 0);
-            A.gin_tbm = tbm_env == 32 || tbm_env == 64 ? tbm_env : ((M + 31) / 32 * (Kp / TB) <= 4ll * net->cu_count ? 32 : 64);
+            A.gin_tbm = gin_tbm;
             A.gin_tiles_i = (int)((M + A.gin_tbm - 1) / A.gin_tbm);
             A.n_gin = A.gin_tiles_i * (Kp / TB);
             A.D = dl[l]; A.W = net->d_wb + wb_offset(net, l); A.In = in; A.Dout = dnext; A.Np = Np; A.Kp = Kp;
@@ -819,7 +907,8 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         const int blocks = (Np / TB) * (Kp / TB);
         int slices = (int)std::min<int64_t>(std::max(1, 512 / blocks), (M + 127) / 128);
         slices = std::max(1, slices);
-        const int64_t rows = ((M + slices - 1) / slices + CH - 1) / CH * CH;
+        int64_t rows = ((M + slices - 1) / slices + CH - 1) / CH * CH;
+        if (l == 0 && w0_tiles) rows = gin_tbm;                                      // one slice per grad_in row tile
         slices = (int)((M + rows - 1) / rows);
         J.P[l] = dl[l]; J.ldp[l] = Np;
         J.Q[l] = l == 0 ? x : reinterpret_cast<const float *>(base + L.act[l - 1]);
@@ -838,13 +927,17 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         A.amp_wgs = F.set[0].n_partials; A.n_amp = A.amp_wgs * d.P;
         A.amp_w = net->d_w; A.g_amp = g_amp; A.keys = keys_dev;
         A.amp_partial = const_cast<float *>(F.set[0].partial); A.amp_stride = F.set[0].stride;
-        const size_t lds = std::max(naqs::ampbw::smem_floats(d), (size_t)(TB * LDD + CH * LDT)) * sizeof(float);
+        const size_t lds = std::max(naqs::ampbw::smem_floats(d), (size_t)std::max(TB * LDD + CH * LDT, 2 * CH * LDT)) * sizeof(float);
         if (lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
+        A.fuse_w0 = w0_tiles && naqs::env_int("NAQS_FUSE_W0", 1) != 0 ? 1 : 0;
+        A.w0 = W0Fuse{x, L.x_ld, cpart + J.cpart_off[0], bpart + J.bpart_off[0], J.Kp[0]};
         hipLaunchKernelGGL(backward_mega_kernel, dim3((unsigned)(A.n_gin + A.n_amp + blocks_total - J.block_end[0])), dim3(256), lds, s,
                            A, d, J, amp_src);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, s, J, M, cpart, bpart, 0);
-        HIP_TRY(hipGetLastError());
+        if (!A.fuse_w0) {
+            hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, s, J, M, cpart, bpart, 0);
+            HIP_TRY(hipGetLastError());
+        }
     } else {
         hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart, 0);
         HIP_TRY(hipGetLastError());
