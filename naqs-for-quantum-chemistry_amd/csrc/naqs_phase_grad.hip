@@ -259,15 +259,17 @@ __global__ __launch_bounds__(256) void grad_w_kernel(const GradWJobs J, const in
 }
 
 // sum_{b < n} p[b * stride], added in the order b = 0, 1, ... (the result every reduction of this file has always had), the
-// loads issued eight at a time so that the chain is not one memory round trip per term
+// loads issued sixteen at a time so that the chain is not one memory round trip per term (eight until the first layer's
+// weight gradient came in one slice per row tile: 40 slices at a training step's size; 32 at a time measured slower: 10.5 us against 9.2)
 __device__ __forceinline__ float ordered_sum(const float *__restrict__ p, const int64_t stride, const int n) {
+    constexpr int U = 16;
     float s = 0.0f;
-    for (int b0 = 0; b0 < n; b0 += 8) {
-        float v[8];
+    for (int b0 = 0; b0 < n; b0 += U) {
+        float v[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = b0 + j < n ? p[(int64_t)(b0 + j) * stride] : 0.0f;
+        for (int j = 0; j < U; ++j) v[j] = b0 + j < n ? p[(int64_t)(b0 + j) * stride] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < U; ++j)
             if (b0 + j < n) s += v[j];
     }
     return s;
