@@ -1942,6 +1942,8 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMalloc((void **)&net->d_scales, sizeof(naqs::PhaseScales)) != hipSuccess) st = NAQS_ERR_NOMEM;
         if (st == NAQS_OK && hipMemset(net->d_raw, 0, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_HIP;
+        if (st == NAQS_OK && hipMalloc((void **)&net->d_sum_words, 8 * sizeof(unsigned long long)) != hipSuccess) st = NAQS_ERR_NOMEM;
+        if (st == NAQS_OK && hipMemset(net->d_sum_words, 0, 8 * sizeof(unsigned long long)) != hipSuccess) st = NAQS_ERR_HIP;
         if (st == NAQS_OK && hipDeviceSynchronize() != hipSuccess) st = NAQS_ERR_HIP;     // null-stream fill: done before any non-blocking stream writes there
     }
     if (st != NAQS_OK) { naqs_net_destroy(net); return st; }
@@ -1971,6 +1973,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_scales) (void)hipFree(net->d_scales);
     if (net->d_ws_xchg) (void)hipFree(net->d_ws_xchg);
+    if (net->d_sum_words) (void)hipFree(net->d_sum_words);
     delete net;
     return NAQS_OK;
 }

@@ -188,6 +188,8 @@ struct naqs_net {
     naqs::PhaseScales *d_scales = nullptr;  // the f16x2 scales of the current weights
     unsigned long long *d_ws_xchg = nullptr;   // phase_kernel_ws<.., SPLIT>: the producers' partial rows (tag << 32 | float), [cu_count / 2][64]
     uint32_t ws_seq = 0;                       // call tag of the last split launch (0 = no word written yet)
+    unsigned long long *d_sum_words = nullptr; // vmc_seed_delta_kernel<true>: the four weighted sums as eight tagged words (tag << 32 | half a double)
+    uint32_t sums_seq = 0;
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)

@@ -29,6 +29,7 @@
 #include "naqs_hash.hpp"
 #include "naqs_net.hpp"
 #include "naqs_amp_backward.hpp"
+#include "naqs_reduce.hpp"
 
 namespace {
 
@@ -42,6 +43,7 @@ constexpr int CH = 32;       // reduction chunk staged in LDS
 constexpr int LDT = 80;      // row stride of a [CH][64] tile: 80 = 16 mod 32 -> lanes (k, k+1) x 16 columns cover 32 banks
 constexpr int LDD = 34;      // row stride of a [64][CH] tile: bank = 2 row + k -> conflict-free for 16 rows x 2 k
 constexpr int W0_FUSE_MAX_ROWS = 4096;   // tables up to this size: the first layer's weight gradient is formed by the grad_in blocks
+constexpr int SUMS_FUSE_MAX_ROWS = 4096; // ... and the weighted sums of E_loc by the seed kernel's first workgroup (naqs_vmc_step)
 
 inline int pad64(int x) { return (x + 63) & ~63; }
 
@@ -110,12 +112,49 @@ __global__ __launch_bounds__(256) void delta_below_top_kernel(const NetDims d, c
 // layer): thread (sample i, column quad q) forms g_i itself from (E_loc_i, w_i, sums) — the same float32 expressions, so
 // every value is the one the two launches produce — writes its four columns of the last hidden layer's delta, and the
 // first threads of a sample's row also write the output layer's delta, g_i, its amplitude component and (<E>, Var).
+// SUMS (naqs_vmc_step at small tables): the weighted sums the seeds need are formed HERE, by workgroup 0 — reduce_kernel's
+// own arithmetic in reduce_kernel's own order (naqs_reduce.hpp: bit-identical) — instead of by a launch in front of this
+// one; it stores them to sums_out and hands them to the other workgroups as eight tagged words (call tag << 32 | half a
+// double; relaxed agent-scope store / polled load: value and flag are one word — §4.5's hand-over).  Every other workgroup
+// has a higher index than the one it waits for.
+template <bool SUMS>
 __global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, const int64_t M, const uint64_t *__restrict__ keys,
                                                              const double2 *__restrict__ eloc, const double *__restrict__ w,
-                                                             const double *__restrict__ sums, float2 *__restrict__ g,
+                                                             const double *__restrict__ sums_in, float2 *__restrict__ g,
                                                              float *__restrict__ g_amp, float *__restrict__ delta, const int ld,
                                                              double *__restrict__ ev, const float *__restrict__ Wtop,
-                                                             const float *__restrict__ act, const int Kp, float *__restrict__ dout) {
+                                                             const float *__restrict__ act, const int Kp, float *__restrict__ dout,
+                                                             double *__restrict__ sums_out, unsigned long long *__restrict__ words,
+                                                             const uint32_t tag) {
+    __shared__ double s_red[4][naqs::RED_BLOCK / 64];
+    __shared__ double s_sums[4];
+    __shared__ uint32_t s_half[8];
+    const double *sums = sums_in;
+    if (SUMS) {
+        if (blockIdx.x == 0) {
+            naqs::weighted_sums_block<256>(M, w, eloc, s_red, s_sums);
+            __syncthreads();
+            if (threadIdx.x < 8) {
+                const double v = s_sums[threadIdx.x >> 1];
+                const uint32_t half = (threadIdx.x & 1) ? (uint32_t)__double2loint(v) : (uint32_t)__double2hiint(v);
+                __hip_atomic_store(&words[threadIdx.x], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x < 4) sums_out[threadIdx.x] = s_sums[threadIdx.x];
+            }
+        } else {
+            if (threadIdx.x < 8) {
+                unsigned long long word = __hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((uint32_t)(word >> 32) != tag) {
+                    __builtin_amdgcn_s_sleep(2);
+                    word = __hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_half[threadIdx.x] = (uint32_t)word;
+            }
+            __syncthreads();
+            if (threadIdx.x < 4) s_sums[threadIdx.x] = __hiloint2double((int)s_half[2 * threadIdx.x], (int)s_half[2 * threadIdx.x + 1]);
+            __syncthreads();
+        }
+        sums = s_sums;
+    }
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e == 0) {
         const double e_mean = sums[0] / sums[3];
@@ -749,7 +788,7 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
 
 // seeds: nullptr = g_dev holds the loss gradient (naqs_net_train_backward); else the loss gradient is formed here from
 // (E_loc, w, sums) together with its amplitude column and the output delta (naqs_net_train_backward_vmc, single-phase only)
-struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; };
+struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; bool form_sums = false; };   // form_sums: `sums` is an OUTPUT of the seed kernel
 static int launch_grad_finish(const GradFinish &F, const GradWJobs &J, const float *cpart, const float *bpart, float *grad_dev,
                               const naqs::AdamArgs *adam, hipStream_t s) {
     hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)((F.total + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
@@ -829,10 +868,23 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     const bool seed_delta = seeds != nullptr && H >= 1;   // the seeds and the last hidden layer's delta from one launch
     if (seed_delta) {
         const int Kp = pad64(net->phase_K[(size_t)H]);
-        hipLaunchKernelGGL(vmc_seed_delta_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
-                           reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
-                           g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
-                           reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]));
+        if (seeds->form_sums) {
+            if (++net->sums_seq == 0u) {                   // the 32-bit tag is about to repeat: forget the old words
+                HIP_TRY(hipMemsetAsync(net->d_sum_words, 0, 8 * sizeof(unsigned long long), s));
+                net->sums_seq = 1u;
+            }
+            hipLaunchKernelGGL(vmc_seed_delta_kernel<true>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+                               reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, nullptr, reinterpret_cast<float2 *>(seeds->g_out),
+                               g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
+                               reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]),
+                               const_cast<double *>(seeds->sums), net->d_sum_words, net->sums_seq);
+        } else {
+            hipLaunchKernelGGL(vmc_seed_delta_kernel<false>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+                               reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
+                               g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
+                               reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]),
+                               nullptr, nullptr, 0u);
+        }
         HIP_TRY(hipGetLastError());
         if (side) { HIP_TRY(hipEventRecord(net->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0)); }
     } else if (seeds != nullptr) {
@@ -951,7 +1003,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
 
 static int train_backward_vmc_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
                                    const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
-                                   void *stream, const naqs::AdamArgs *adam);
+                                   void *stream, const naqs::AdamArgs *adam, bool form_sums = false);
 
 NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
                            int64_t m_hi, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
@@ -974,12 +1026,17 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
     info_host[0] = info2[0]; info_host[1] = info2[1];
     const int64_t M = info2[0];
     if (info2[1] != 0 || M <= 0 || M < m_lo || M > m_hi) return NAQS_OK;        // abandoned: the caller adapts n_samples
-    st = naqs_net_train_forward_eloc(net, ham, M, keys_dev, weights_dev, logpsi_dev, eloc_dev, sums_dev, stream);
+    // small tables: the weighted sums of E_loc are formed by the first workgroup of the backward pass's seed kernel (same
+    // arithmetic, same order: naqs_reduce.hpp) instead of by a launch between E_loc and the seeds (NAQS_FUSE_SUMS=0: the launch)
+    const bool form_sums = !net->aggregate && net->dims.n_lin >= 2 && M <= SUMS_FUSE_MAX_ROWS && sums_dev != nullptr &&
+                           net->d_sum_words != nullptr && naqs::env_int("NAQS_FUSE_SUMS", 1) != 0;
+    st = naqs_net_train_forward_eloc(net, ham, M, keys_dev, form_sums ? nullptr : weights_dev, logpsi_dev, eloc_dev,
+                                     form_sums ? nullptr : sums_dev, stream);
     if (st != NAQS_OK) return st;
     naqs::AdamArgs adam;
     if (adam_step >= 1) adam = naqs::adam_args(param_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay, adam_step);
     st = train_backward_vmc_impl(net, M, keys_dev, eloc_dev, weights_dev, sums_dev, g_dev, ev_dev, grad_dev, stream,
-                                 adam_step >= 1 ? &adam : nullptr);
+                                 adam_step >= 1 ? &adam : nullptr, form_sums);
     if (st != NAQS_OK) return st;
     if (adam_step >= 1) {
         st = naqs_net_set_weights(net, param_dev, net->n_params, stream);           // the next sampling call reads these
@@ -1036,14 +1093,15 @@ NAQS_API int naqs_net_train_backward(naqs_net_t *net, int64_t M, const uint64_t 
 
 static int train_backward_vmc_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
                                    const double *w_dev, const double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
-                                   void *stream, const naqs::AdamArgs *adam) {
+                                   void *stream, const naqs::AdamArgs *adam, bool form_sums) {
     if (!net || !sums_dev || !ev_dev || !g_dev || (M > 0 && (!eloc_dev || !w_dev))) return NAQS_ERR_INVALID;
     if (net->aggregate || M == 0) {                   // per-pair phase blocks (or nothing to do): the two separate calls
         int st = naqs_vmc_loss_grad_ev(M, eloc_dev, w_dev, sums_dev, g_dev, ev_dev, stream);
         if (st != NAQS_OK) return st;
         return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, nullptr, adam);
     }
-    const VmcSeeds seeds{eloc_dev, w_dev, sums_dev, g_dev, ev_dev};
+    if (form_sums && net->dims.n_lin < 2) return NAQS_ERR_INVALID;              // (the caller's condition: the seed + delta kernel runs)
+    const VmcSeeds seeds{eloc_dev, w_dev, sums_dev, g_dev, ev_dev, form_sums};
     return train_backward_impl(net, M, keys_dev, g_dev, grad_dev, stream, &seeds, adam);
 }
 
