@@ -34,6 +34,7 @@
 #include "naqs_hash.hpp"
 #include "naqs_net.hpp"
 #include "naqs_amp_mfma.hpp"
+#include "naqs_pack.hpp"
 
 namespace {
 
@@ -402,12 +403,7 @@ __device__ __forceinline__ void split3t(float x, ushort_t &h1, ushort_t &h2, ush
     h3 = (ushort_t)(__float_as_uint(r2) >> 16);
 }
 
-// Output column of MFMA tile cb, tile column nn.  When a layer's width is a multiple of 64 the four tiles of a wave are
-// interleaved (column = 64 (cb / 4) + 4 nn + cb % 4): a lane then owns four ADJACENT columns of every row, and the
-// write-back packs them into one 8-byte LDS store per plane with no cross-lane traffic.
-__host__ __device__ __forceinline__ int tile_col(int cb, int nn, int N_pad) {
-    return (CBT == 4 && (N_pad & 63) == 0) ? ((cb >> 2) << 6) + 4 * nn + (cb & 3) : cb * 16 + nn;
-}
+using naqs::tile_col;              // naqs_pack.hpp
 
 // The split formats of the phase MLP.  FMT 1 ("bf16x3"): three bf16 planes, six cross terms per product.  FMT 2 ("f16x2"):
 // two f16 planes of the power-of-two-scaled value (naqs::PhaseScales) — hi = f16(s v) carries 11 significant bits, lo =
@@ -1492,69 +1488,12 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     NAQS_MARK(7);
 }
 
-// the weight maxima the f16x2 scales are derived from: per phase layer max |W|, max_j sum_k |W[j][k]|, max |b| — one wave per
-// row (a 512 x 512 layer: 512 waves, one load round trip each), per-workgroup partials stored plainly
-struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
-constexpr int BOUNDS_WAVES = 8;
-__global__ __launch_bounds__(BOUNDS_WAVES * 64) void net_bounds_kernel(const float *__restrict__ flat, const PhasePackJobs jobs,
-                                                                       naqs::PhaseRaw *__restrict__ raw) {
-    __shared__ float s_red[3][BOUNDS_WAVES];
-    const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = jobs.K[l], N = jobs.N[l];
-    const float *W = flat + jobs.src_off[l], *b = W + (size_t)N * K;
-    float mw = 0.0f, mr = 0.0f, mb = 0.0f;
-    for (int j = blockIdx.x * BOUNDS_WAVES + wave; j < N; j += gridDim.x * BOUNDS_WAVES) {
-        float sum = 0.0f;
-#pragma unroll 8
-        for (int k = lane; k < K; k += 64) { const float v = fabsf(W[(size_t)j * K + k]); sum += v; mw = fmaxf(mw, v); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        mr = fmaxf(mr, sum);
-        mb = fmaxf(mb, fabsf(b[j]));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
-    if (lane == 0) { s_red[0][wave] = mw; s_red[1][wave] = mr; s_red[2][wave] = mb; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        float m = 0.0f;
-        for (int w = 0; w < BOUNDS_WAVES; ++w) m = fmaxf(m, s_red[threadIdx.x][w]);
-        float *dst = threadIdx.x == 0 ? raw->max_w[l] : (threadIdx.x == 1 ? raw->max_rowsum[l] : raw->max_b[l]);
-        dst[blockIdx.x] = m;
-    }
-}
-
-// maximum of the BOUNDS_WG (= 64) per-workgroup partials: one load per lane + a wave reduction, every lane gets the result.
-// (A serial loop over the 64 entries — by one thread for the scale chain, by every workgroup for its weight scale — made
-// the packing launch 36 us instead of 8.)  Must be called by whole waves.
-static_assert(naqs::BOUNDS_WG == 64, "one partial per lane");
-__device__ __forceinline__ float bounds_max(const float (&part)[naqs::BOUNDS_WG]) {
-    float m = part[threadIdx.x & 63];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    return m;
-}
-
-// weight scale of layer l: max |W| sw in [2^13, 2^14)
-__device__ __forceinline__ float phase_weight_scale(const naqs::PhaseRaw &raw, int l) {
-    return pow2_clamped(13 - exp_of(bounds_max(raw.max_w[l])));
-}
-// all scales of the network (called by one whole wave; lane 0 writes): activation bound chain
-// |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
-__device__ __forceinline__ void phase_scales_fill(const naqs::PhaseRaw &raw, int n_lin, naqs::PhaseScales *out) {
-    float bound = 1.0f, s_in = 1.0f;
-    for (int l = 0; l < n_lin; ++l) {
-        bound = bounds_max(raw.max_rowsum[l]) * bound + bounds_max(raw.max_b[l]);
-        const float sw = phase_weight_scale(raw, l);
-        const float sn = l + 1 < n_lin ? pow2_clamped(14 - exp_of(bound)) : 1.0f;          // bound sn < 2^15
-        if ((threadIdx.x & 63) == 0) {
-            out->sw[l] = sw;
-            out->sn[l] = sn;
-            out->isn[l] = 1.0f / sn;
-            out->c[l] = (sn / s_in) / sw;            // powers of two: exact
-        }
-        s_in = sn;
-    }
+// the weight maxima, their reduction and the scales derived from them: naqs_pack.hpp
+using naqs::PhasePackJobs;
+using naqs::phase_weight_scale;
+__global__ __launch_bounds__(256) void net_bounds_kernel(const float *__restrict__ flat, const PhasePackJobs jobs,
+                                                         naqs::PhaseRaw *__restrict__ raw, const uint32_t tag) {
+    naqs::net_bounds_body(flat, jobs, raw, blockIdx.y, tag, blockIdx.x);
 }
 
 // f32 [N][K] -> three bf16 planes, zero-padded and tiled [plane][N_pad/16][Kh_pad/32][64 lanes][8]
@@ -1572,21 +1511,6 @@ __device__ __forceinline__ void pack_phase_bf16(const float *__restrict__ src, i
         Wd[e] = h1; Wd[(size_t)total + e] = h2; Wd[2 * (size_t)total + e] = h3;
     }
 }
-// the same tiling as two f16 planes of sw * W (f16x2 format)
-__device__ __forceinline__ void pack_phase_f16(const float *__restrict__ src, int K, int N, int Kh_pad,
-                                               int N_pad, ushort_t *__restrict__ Wd, const float sw) {
-    const int total = N_pad * Kh_pad;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int j = e & 7, nn = (e >> 3) & 15, kg = (e >> 7) & 3, blk = e >> 9;
-        const int KC = Kh_pad >> 5, cb = blk / KC, kc = blk - cb * KC;
-        const int n = tile_col(cb, nn, N_pad), k = kc * 32 + kg * 8 + j;
-        const float x = (n < N && k < K) ? src[n * K + k] * sw : 0.0f;
-        ushort_t h1, h2;
-        split2(x, h1, h2);
-        Wd[e] = h1; Wd[(size_t)total + e] = h2;
-    }
-}
-
 // re-pack the flat state_dict-order parameters into the kernels' layout
 // amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]] ->
 // Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
@@ -1724,7 +1648,12 @@ __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, in
 // one phase layer: f32 MFMA tiles + bias, and the split planes (fmt 1: three bf16, fmt 2: two scaled f16)
 __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
                                                 float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32, const int l,
-                                                const int fmt, const naqs::PhaseRaw *__restrict__ raw) {
+                                                const int fmt, const naqs::PhaseRaw *__restrict__ raw,
+                                                naqs::PhaseScales *__restrict__ scales, const uint32_t tag) {
+    if (fmt == 2 && !with_f32) {                        // (the training step's format: shared with the sampler's first launch)
+        naqs::pack_phase_job_f16x2(flat, d, jobs, w, wh, l, raw, scales, tag, blockIdx.x, gridDim.x);
+        return;
+    }
     const float *src = flat + jobs.src_off[l];
     if (with_f32) pack_phase_f32(src, jobs.K[l], jobs.N[l], d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l]);
     else {                                              // the split kernels only need the (padded) bias from this buffer ...
@@ -1739,42 +1668,31 @@ __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, 
             }
         }
     }
-    if (fmt == 2) pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l));
+    if (fmt == 2) naqs::pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l, tag),
+                                       blockIdx.x, gridDim.x);
     else pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
 }
 // naqs_net_set_weights of the single-phase network in ONE launch (it runs once per training step, and every launch of a
 // few thousand elements costs its 4-5 us): blockIdx.y walks the amplitude rows (P jobs), the amplitude fragments (P), the
 // phase layers (n_lin) and the row-major copies the backward GEMMs read (naqs::WbPackJobs, from naqs_phase_grad.hip).
-// fmt 2: raw holds the partial weight maxima of net_bounds_kernel (launched just before); the first phase job also writes
-// the scales the phase kernel reads.
+// fmt 2: raw holds the partial weight maxima of net_bounds_kernel (launched just before; tagged words); the first phase job
+// also writes the scales the phase kernel reads.  y_base: the launch covers the jobs from there on (all of them, or — the
+// phase share a training step left pending and nobody hosted — the phase jobs alone).
 __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
                                                        const PhasePackJobs jobs, const naqs::WbPackJobs wb, float *__restrict__ w,
                                                        ushort_t *__restrict__ wh, ushort_t *__restrict__ wamp, const int with_f32,
                                                        const int fmt, const naqs::PhaseRaw *__restrict__ raw,
-                                                       naqs::PhaseScales *__restrict__ scales) {
-    int y = blockIdx.y;
+                                                       naqs::PhaseScales *__restrict__ scales, const int y_base, const uint32_t tag) {
+    int y = blockIdx.y + y_base;
     if (y < d.P) { pack_amp_body(flat, d, so, w, y); return; }
     y -= d.P;
     if (wamp != nullptr) {
         if (y < d.P) { pack_amp_mfma_body(flat, d, so, wamp, y); return; }
         y -= d.P;
     }
-    if (y < d.n_lin) {
-        if (fmt == 2 && y == 0 && blockIdx.x == 0) {
-            if (threadIdx.x < 64) phase_scales_fill(*raw, d.n_lin, scales);
-        }
-        pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw);
-        return;
-    }
+    if (y < d.n_lin) { pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw, scales, tag); return; }
     y -= d.n_lin;
-    if (y < wb.n) {
-        const int total = wb.Np[y] * wb.Kp[y];
-        const float *src = flat + wb.src_off[y];
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-            const int n = e / wb.Kp[y], k = e - n * wb.Kp[y];
-            wb.dst[y][e] = (n < wb.N[y] && k < wb.K[y]) ? src[n * wb.K[y] + k] : 0.0f;
-        }
-    }
+    if (y < wb.n) naqs::pack_wb_job(flat, wb, y, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -2053,6 +1971,91 @@ NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, in
     return NAQS_OK;
 }
 
+// The single-phase network's re-pack.  PACK_ALL: everything on `s` (weight maxima, then one launch for all jobs).  PACK_AMP
+// (naqs_vmc_step, f16x2 format): the amplitude jobs only — what the next sampler call reads — and the phase share stays
+// PENDING: the sampler's first launch hosts it (PACK_TAKE fills the arguments: naqs_pack.hpp), or whoever reads the phase
+// layers first starts it in order (PACK_PHASE).
+enum PackMode { PACK_ALL = 0, PACK_AMP = 1, PACK_PHASE = 2, PACK_TAKE = 3 };
+static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s, const PackMode mode, naqs::PackPhaseArgs *take) {
+    const NetDims &d = net->dims;
+    PhasePackJobs jobs{};
+    int biggest = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;                 // an amplitude block's packed rows
+    const int amp_biggest = std::max(biggest, (d.Ha / 16 + d.Ha / 32) * 512);
+    for (int l = 0; l < d.n_lin; ++l) {
+        jobs.src_off[l] = net->phase_src_off[(size_t)l];
+        jobs.K[l] = net->phase_K[(size_t)l];
+        jobs.N[l] = net->phase_N[(size_t)l];
+        biggest = std::max(biggest, d.N_pad[l] * std::max(d.K_pad[l], d.Kh_pad[l]));
+    }
+    // the f32-MFMA weight tiles are only read by phase_kernel (NAQS_PHASE_MODE=0)
+    const int fmt = phase_format(d);
+    const int with_f32 = fmt == 0 ? 1 : 0;
+    naqs::WbPackJobs wb{};
+    int st = naqs::net_backward_pack_jobs(net, &wb);
+    if (st != NAQS_OK) return st;
+    for (int i = 0; i < wb.n; ++i) biggest = std::max(biggest, wb.Np[i] * wb.Kp[i]);
+    AmpSrcOff so;
+    for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
+    const int gx = std::min(256, (biggest + 255) / 256);
+    const int gy_amp = d.P + (net->d_wamp ? d.P : 0), gy_phase = d.n_lin + wb.n;
+    naqs::PhaseRaw *raw = net->d_raw;
+    if (mode == PACK_ALL || mode == PACK_AMP) {
+        net->packed_f32 = with_f32 != 0;
+        net->packed_fmt = fmt;
+        net->wamp_fresh = false;
+    }
+    const bool split = mode != PACK_ALL && fmt == 2;      // (PACK_AMP on another format: everything now, nothing pending)
+    if (fmt == 2 && (!split || mode >= PACK_PHASE)) {
+        if (++net->pack_seq == 0u) {                       // the 32-bit tag is about to repeat: forget every old word
+            HIP_TRY(hipMemsetAsync(raw, 0, sizeof(naqs::PhaseRaw), s));
+            net->pack_seq = 1u;
+        }
+    }
+    if (!split) {
+        if (fmt == 2) {
+            // weight maxima -> scales (device side; no host round trip)
+            hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy_amp + gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
+                           with_f32, fmt, raw, net->d_scales, 0, net->pack_seq);
+        HIP_TRY(hipGetLastError());
+        net->pack_pending = nullptr;
+    } else if (mode == PACK_AMP) {
+        hipLaunchKernelGGL(pack_net_kernel, dim3(std::min(256, (amp_biggest + 255) / 256), gy_amp), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w,
+                           net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u);
+        HIP_TRY(hipGetLastError());
+        net->pack_pending = flat_dev;
+    } else if (mode == PACK_PHASE) {
+        hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp, with_f32,
+                           fmt, raw, net->d_scales, gy_amp, net->pack_seq);
+        HIP_TRY(hipGetLastError());
+        net->pack_pending = nullptr;
+    } else {                                               // PACK_TAKE: the caller's launch hosts the jobs
+        take->flat = flat_dev; take->jobs = jobs; take->wb = wb; take->w = net->d_w; take->wh = net->d_wh; take->raw = raw;
+        take->scales = net->d_scales; take->tag = net->pack_seq; take->gx = gx;
+        take->n_wgs = d.n_lin * naqs::BOUNDS_WG + gy_phase * gx;
+        net->pack_pending = nullptr;
+    }
+    if (mode == PACK_ALL || mode == PACK_AMP) {
+        net->wamp_fresh = net->d_wamp != nullptr;
+        net->have_wb = true;
+    }
+    return NAQS_OK;
+}
+
+int naqs::net_take_pending_pack(naqs_net *net, hipStream_t s, naqs::PackPhaseArgs *out) {
+    *out = naqs::PackPhaseArgs{};
+    if (net->pack_pending == nullptr) return NAQS_OK;
+    return pack_single_phase(net, net->pack_pending, s, PACK_TAKE, out);
+}
+int naqs::net_flush_pack(naqs_net *net, hipStream_t s) {
+    if (net->pack_pending == nullptr) return NAQS_OK;
+    return pack_single_phase(net, net->pack_pending, s, PACK_PHASE, nullptr);
+}
+
 NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
     if (!net || !flat_dev || count != net->n_params) return NAQS_ERR_INVALID;
     DeviceGuard guard;
@@ -2061,6 +2064,7 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const NetDims &d = net->dims;
     net->have_weights = net->have_amp_weights = net->have_wb = false;
+    net->pack_pending = nullptr;                          // (whatever was pending is superseded by this re-pack)
     if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack
         if (net->dims.P == net->dph.P && (naqs::env_int("NAQS_AGG_MERGE", 7) & 4)) {
             AmpSrcOff so0, so1;
@@ -2085,41 +2089,8 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
         net->have_weights = net->have_amp_weights = net->have_wb = true;
         return NAQS_OK;
     }
-    {
-        PhasePackJobs jobs{};
-        int biggest = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;                 // an amplitude block's packed rows
-        for (int l = 0; l < d.n_lin; ++l) {
-            jobs.src_off[l] = net->phase_src_off[(size_t)l];
-            jobs.K[l] = net->phase_K[(size_t)l];
-            jobs.N[l] = net->phase_N[(size_t)l];
-            biggest = std::max(biggest, d.N_pad[l] * std::max(d.K_pad[l], d.Kh_pad[l]));
-        }
-        // the f32-MFMA weight tiles are only read by phase_kernel (NAQS_PHASE_MODE=0)
-        const int fmt = phase_format(d);
-        const int with_f32 = fmt == 0 ? 1 : 0;
-        net->packed_f32 = with_f32 != 0;
-        net->packed_fmt = fmt;
-        naqs::WbPackJobs wb{};
-        st = naqs::net_backward_pack_jobs(net, &wb);
-        if (st != NAQS_OK) return st;
-        for (int i = 0; i < wb.n; ++i) biggest = std::max(biggest, wb.Np[i] * wb.Kp[i]);
-        AmpSrcOff so;
-        for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
-        const int gx = std::min(256, (biggest + 255) / 256);
-        const int gy = d.P + (net->d_wamp ? d.P : 0) + d.n_lin + wb.n;
-        net->wamp_fresh = false;
-        naqs::PhaseRaw *raw = net->d_raw;
-        if (fmt == 2) {
-            // weight maxima -> scales (device side; no host round trip)
-            hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(BOUNDS_WAVES * 64), 0, s, flat_dev, jobs, raw);
-            HIP_TRY(hipGetLastError());
-        }
-        hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
-                           with_f32, fmt, raw, net->d_scales);
-        HIP_TRY(hipGetLastError());
-        net->wamp_fresh = net->d_wamp != nullptr;
-        net->have_wb = true;
-    }
+    st = pack_single_phase(net, flat_dev, s, net->overlap_next_pack ? PACK_AMP : PACK_ALL, nullptr);
+    if (st != NAQS_OK) return st;
     net->have_weights = net->have_amp_weights = true;
     return NAQS_OK;
 }
@@ -2209,6 +2180,8 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    st = naqs::net_flush_pack(net, s);                     // (the phase share of the last step's re-pack, if no launch hosted it)
+    if (st != NAQS_OK) return st;
     if (net->aggregate) return agg_logpsi(net, M, keys_dev, logpsi_dev, s, feed);
     const int fmt = phase_format(d);
     if (fmt != net->packed_fmt) return NAQS_ERR_INVALID;                       // NAQS_PHASE_MODE changed since naqs_net_set_weights

@@ -43,10 +43,12 @@ struct NetDims {
 // c = sn / (s_in sw) takes an accumulator to the scaled output, isn = 1 / sn.  Written by pack_net_kernel from the
 // weight-derived bounds of net_bounds_kernel (|h_l| <= rowsum_l * bound_{l-1} + max|b_l| < 2^15 / sn: no overflow).
 struct PhaseScales { float sw[MAXL], c[MAXL], sn[MAXL], isn[MAXL]; };
-// per-workgroup partial maxima of net_bounds_kernel: plain stores, every consumer reduces the BOUNDS_WG entries itself (no
-// atomics — ~10^3 atomic maxima on nine addresses were 13 of the kernel's 14 us — and nothing to zero between calls)
+// per-workgroup partial maxima of the weights (naqs_pack.hpp: net_bounds_body): every consumer reduces the BOUNDS_WG entries
+// itself (no atomic maxima — ~10^3 of them on nine addresses were 13 of the kernel's 14 us — and nothing to zero between
+// calls).  Each entry is a 64-bit word (pack tag << 32 | float bits) written with a relaxed agent-scope store and polled by its
+// readers, which may be workgroups of the SAME launch with higher block indices: value and flag are one word — no fence
 constexpr int BOUNDS_WG = 64;
-struct PhaseRaw { float max_w[MAXL][BOUNDS_WG], max_rowsum[MAXL][BOUNDS_WG], max_b[MAXL][BOUNDS_WG]; };
+struct PhaseRaw { unsigned long long max_w[MAXL][BOUNDS_WG], max_rowsum[MAXL][BOUNDS_WG], max_b[MAXL][BOUNDS_WG]; };
 
 // one packed row [W1[j][0..NIN) | b1[j] | W2[0..5)[j] | pad] from LDS as 16-byte reads (rows are 16-byte multiples);
 // element-wise `row[k]` reads compile to one ds_read_b32 each and those, not the FMAs, were the time of this loop
@@ -190,6 +192,9 @@ struct naqs_net {
     uint32_t ws_seq = 0;                       // call tag of the last split launch (0 = no word written yet)
     unsigned long long *d_sum_words = nullptr; // vmc_seed_delta_kernel<true>: the four weighted sums as eight tagged words (tag << 32 | half a double)
     uint32_t sums_seq = 0;
+    uint32_t pack_seq = 0;                     // tag of the last re-pack's PhaseRaw words
+    const float *pack_pending = nullptr;       // parameters whose phase share of the re-pack has not been started (naqs_vmc_step; naqs_pack.hpp)
+    bool overlap_next_pack = false;            // naqs_vmc_step -> naqs_net_set_weights: amplitude jobs now, phase jobs pending
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)

@@ -1,0 +1,175 @@
+// naqs_pack.hpp — the phase layers' share of the single-phase network's re-pack in the f16x2 format, as device functions two
+// kernels use: pack_net_kernel (naqs_logpsi.hip: naqs_net_set_weights, everything in one launch behind net_bounds_kernel) and
+// the sampler's first launch of a training step (naqs_sample.hip: sample_head_kernel<256, 4> is ONE workgroup for ~30 us and
+// reads nothing but the amplitude blocks — the workgroups behind it re-pack the phase layers of the last update meanwhile,
+// instead of 13 us of launches between the update and the sampler).  Inside that launch the weight maxima are the first jobs
+// and reach the packing jobs as tagged words (naqs_net.hpp: PhaseRaw): consumers have higher block indices than producers.
+// All functions are written for 256-thread workgroups and take the workgroup's index within its job (bx of nbx).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "naqs_amp_mfma.hpp"
+#include "naqs_net.hpp"
+
+#ifndef NAQS_PH_CBT
+#define NAQS_PH_CBT 4
+#endif
+
+namespace naqs {
+
+// Output column of MFMA tile cb, tile column nn.  When a layer's width is a multiple of 64 the four tiles of a wave are
+// interleaved (column = 64 (cb / 4) + 4 nn + cb % 4): a lane then owns four ADJACENT columns of every row, and the
+// write-back packs them into one 8-byte LDS store per plane with no cross-lane traffic.
+__host__ __device__ __forceinline__ int tile_col(int cb, int nn, int N_pad) {
+    return (NAQS_PH_CBT == 4 && (N_pad & 63) == 0) ? ((cb >> 2) << 6) + 4 * nn + (cb & 3) : cb * 16 + nn;
+}
+
+struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
+
+// the weight maxima the f16x2 scales are derived from: per phase layer max |W|, max_j sum_k |W[j][k]|, max |b| — one wave per
+// row (a 512 x 512 layer: 512 waves, one load round trip each); workgroups 0 .. BOUNDS_WG - 1 of job l publish their partials
+constexpr int BOUNDS_WAVES = 4;
+__device__ __forceinline__ void net_bounds_body(const float *__restrict__ flat, const PhasePackJobs &jobs, PhaseRaw *__restrict__ raw,
+                                                const int l, const uint32_t tag, const int bx) {
+    __shared__ float s_red[3][BOUNDS_WAVES];
+    if (bx >= BOUNDS_WG) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = jobs.K[l], N = jobs.N[l];
+    const float *W = flat + jobs.src_off[l], *b = W + (size_t)N * K;
+    float mw = 0.0f, mr = 0.0f, mb = 0.0f;
+    for (int j = bx * BOUNDS_WAVES + wave; j < N; j += BOUNDS_WG * BOUNDS_WAVES) {
+        float sum = 0.0f;
+#pragma unroll 8
+        for (int k = lane; k < K; k += 64) { const float v = fabsf(W[(size_t)j * K + k]); sum += v; mw = fmaxf(mw, v); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        mr = fmaxf(mr, sum);
+        mb = fmaxf(mb, fabsf(b[j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    if (lane == 0) { s_red[0][wave] = mw; s_red[1][wave] = mr; s_red[2][wave] = mb; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float m = 0.0f;
+        for (int w = 0; w < BOUNDS_WAVES; ++w) m = fmaxf(m, s_red[threadIdx.x][w]);
+        unsigned long long *dst = threadIdx.x == 0 ? raw->max_w[l] : (threadIdx.x == 1 ? raw->max_rowsum[l] : raw->max_b[l]);
+        __hip_atomic_store(&dst[bx], ((unsigned long long)tag << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// maximum of the BOUNDS_WG (= 64) per-workgroup partials: one polled load per lane + a wave reduction, every lane gets the
+// result.  (A serial loop over the 64 entries — by one thread for the scale chain, by every workgroup for its weight scale —
+// made the packing launch 36 us instead of 8.)  Must be called by whole waves.
+static_assert(BOUNDS_WG == 64, "one partial per lane");
+__device__ __forceinline__ float bounds_max(const unsigned long long (&part)[BOUNDS_WG], const uint32_t tag) {
+    const unsigned long long *src = &part[threadIdx.x & 63];
+    unsigned long long word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((uint32_t)(word >> 32) != tag) {
+        __builtin_amdgcn_s_sleep(2);
+        word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float m = __uint_as_float((uint32_t)word);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+}
+
+// weight scale of layer l: max |W| sw in [2^13, 2^14)
+__device__ __forceinline__ float phase_weight_scale(const PhaseRaw &raw, int l, const uint32_t tag) {
+    return pow2_clamped(13 - exp_of(bounds_max(raw.max_w[l], tag)));
+}
+// all scales of the network (called by one whole wave; lane 0 writes): activation bound chain
+// |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
+__device__ __forceinline__ void phase_scales_fill(const PhaseRaw &raw, int n_lin, PhaseScales *out, const uint32_t tag) {
+    float bound = 1.0f, s_in = 1.0f;
+    for (int l = 0; l < n_lin; ++l) {
+        bound = bounds_max(raw.max_rowsum[l], tag) * bound + bounds_max(raw.max_b[l], tag);
+        const float sw = phase_weight_scale(raw, l, tag);
+        const float sn = l + 1 < n_lin ? pow2_clamped(14 - exp_of(bound)) : 1.0f;          // bound sn < 2^15
+        if ((threadIdx.x & 63) == 0) {
+            out->sw[l] = sw;
+            out->sn[l] = sn;
+            out->isn[l] = 1.0f / sn;
+            out->c[l] = (sn / s_in) / sw;            // powers of two: exact
+        }
+        s_in = sn;
+    }
+}
+
+// f32 [N][K] -> two f16 planes of sw * W, zero-padded and tiled [plane][N_pad/16][Kh_pad/32][64 lanes][8]
+__device__ __forceinline__ void pack_phase_f16(const float *__restrict__ src, int K, int N, int Kh_pad, int N_pad,
+                                               ushort_t *__restrict__ Wd, const float sw, const int bx, const int nbx) {
+    const int total = N_pad * Kh_pad;
+    for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+        // e = ((cb * KC + kc) * 64 + kg * 16 + nn) * 8 + j   <-   W[cb*16 + nn][kc*32 + kg*8 + j]
+        const int j = e & 7, nn = (e >> 3) & 15, kg = (e >> 7) & 3, blk = e >> 9;
+        const int KC = Kh_pad >> 5, cb = blk / KC, kc = blk - cb * KC;
+        const int n = tile_col(cb, nn, N_pad), k = kc * 32 + kg * 8 + j;
+        const float x = (n < N && k < K) ? src[n * K + k] * sw : 0.0f;
+        ushort_t h1, h2;
+        split2(x, h1, h2);
+        Wd[e] = h1; Wd[(size_t)total + e] = h2;
+    }
+}
+
+// one phase layer in the f16x2 format: the (padded) bias, the output layer also as plain row-major f32 [N_pad][K_pad]
+// (phase_kernel_ws multiplies by it on the VALU), the two scaled planes; workgroup 0 of layer 0 also writes the scales
+__device__ __forceinline__ void pack_phase_job_f16x2(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
+                                                     float *__restrict__ w, ushort_t *__restrict__ wh, const int l,
+                                                     const PhaseRaw *__restrict__ raw, PhaseScales *__restrict__ scales,
+                                                     const uint32_t tag, const int bx, const int nbx) {
+    if (l == 0 && bx == 0 && threadIdx.x < 64) phase_scales_fill(*raw, d.n_lin, scales, tag);
+    const float *src = flat + jobs.src_off[l];
+    for (int n = bx * 256 + threadIdx.x; n < d.N_pad[l]; n += nbx * 256)
+        w[d.b_off[l] + n] = n < jobs.N[l] ? src[jobs.N[l] * jobs.K[l] + n] : 0.0f;
+    if (l == d.n_lin - 1) {
+        const int Kp = d.K_pad[l], total = d.N_pad[l] * Kp;
+        for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+            const int n = e / Kp, k = e - n * Kp;
+            w[d.w_off[l] + e] = (n < jobs.N[l] && k < jobs.K[l]) ? src[n * jobs.K[l] + k] : 0.0f;
+        }
+    }
+    pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l, tag), bx, nbx);
+}
+
+// row-major zero-padded copy y of the phase weights (what the backward GEMMs read)
+__device__ __forceinline__ void pack_wb_job(const float *__restrict__ flat, const WbPackJobs &wb, const int y, const int bx, const int nbx) {
+    const int total = wb.Np[y] * wb.Kp[y];
+    const float *src = flat + wb.src_off[y];
+    for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+        const int n = e / wb.Kp[y], k = e - n * wb.Kp[y];
+        wb.dst[y][e] = (n < wb.N[y] && k < wb.K[y]) ? src[n * wb.K[y] + k] : 0.0f;
+    }
+}
+
+// the phase share of a re-pack as a flat range of n_wgs workgroups: [maxima: n_lin x BOUNDS_WG][layers: n_lin x gx][copies: wb.n x gx]
+struct PackPhaseArgs {
+    const float *flat = nullptr;       // nullptr: nothing to do
+    PhasePackJobs jobs;
+    WbPackJobs wb;
+    float *w = nullptr;
+    ushort_t *wh = nullptr;
+    PhaseRaw *raw = nullptr;
+    PhaseScales *scales = nullptr;
+    uint32_t tag = 0;
+    int gx = 0, n_wgs = 0;
+};
+__device__ __forceinline__ void pack_phase_dispatch(const NetDims &d, const PackPhaseArgs &a, int bid) {
+    const int nb = d.n_lin * BOUNDS_WG;
+    if (bid < nb) { net_bounds_body(a.flat, a.jobs, a.raw, bid / BOUNDS_WG, a.tag, bid % BOUNDS_WG); return; }
+    bid -= nb;
+    const int y = bid / a.gx, x = bid - y * a.gx;
+    if (y < d.n_lin) pack_phase_job_f16x2(a.flat, d, a.jobs, a.w, a.wh, y, a.raw, a.scales, a.tag, x, a.gx);
+    else if (y - d.n_lin < a.wb.n) pack_wb_job(a.flat, a.wb, y - d.n_lin, x, a.gx);
+}
+
+// naqs_logpsi.hip: the pending phase share of the last re-pack (naqs_vmc_step), for a launch that can host it (`out` filled,
+// nothing pending afterwards) ...
+int net_take_pending_pack(naqs_net *net, hipStream_t s, PackPhaseArgs *out);
+// ... or as launches of its own, in order on `s` (any other reader of the phase layers)
+int net_flush_pack(naqs_net *net, hipStream_t s);
+
+}  // namespace naqs

@@ -30,6 +30,7 @@
 #include "naqs_net.hpp"
 #include "naqs_amp_backward.hpp"
 #include "naqs_reduce.hpp"
+#include "naqs_pack.hpp"
 
 namespace {
 
@@ -801,6 +802,10 @@ static int launch_grad_finish(const GradFinish &F, const GradWJobs &J, const flo
 static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const float *g_dev, float *grad_dev, void *stream,
                                const VmcSeeds *seeds, const naqs::AdamArgs *adam = nullptr) {
     if (!net || M < 0 || !grad_dev || (M > 0 && (!keys_dev || !g_dev))) return NAQS_ERR_INVALID;
+    {   // (the row-major weight copies this pass reads belong to the phase share of the re-pack)
+        const int stj = naqs::net_flush_pack(net, reinterpret_cast<hipStream_t>(stream));
+        if (stj != NAQS_OK) return stj;
+    }
     if (!net->have_weights || !net->have_wb) return NAQS_ERR_INVALID;
     if (!net->aggregate && (M > net->train_cap || !net->d_train)) return NAQS_ERR_INVALID;   // naqs_net_train_forward of the same batch comes first
     DeviceGuard guard;
@@ -1039,7 +1044,11 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
                                  adam_step >= 1 ? &adam : nullptr, form_sums);
     if (st != NAQS_OK) return st;
     if (adam_step >= 1) {
-        st = naqs_net_set_weights(net, param_dev, net->n_params, stream);           // the next sampling call reads these
+        // the next sampling call reads the amplitude blocks; the phase layers' share of the re-pack rides in that call's
+        // first launch (naqs_pack.hpp; NAQS_PACK_OVERLAP=0: everything here, in order)
+        net->overlap_next_pack = naqs::env_int("NAQS_PACK_OVERLAP", 1) != 0;
+        st = naqs_net_set_weights(net, param_dev, net->n_params, stream);
+        net->overlap_next_pack = false;
         if (st != NAQS_OK) return st;
     }
     info_host[2] = 1;

@@ -30,6 +30,7 @@
 #include "naqs_net.hpp"
 #include "naqs_amp_mfma.hpp"
 #include "naqs_rng.hpp"
+#include "naqs_pack.hpp"
 
 namespace {
 
@@ -620,10 +621,19 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
 // latency (~30 us each as separate expand + scatter launches whatever their size).  Leaves the level-HL prefixes
 // (<= HT) in the global ping-pong arrays where the per-level kernels continue.  HT = 1024 keeps five levels in the
 // launch, HT = 256 four (small max_unique).
+// Workgroups 1 .. pk.n_wgs of the 256-thread form (naqs_vmc_step): this launch is one workgroup for ~30 us that reads nothing but
+// the amplitude blocks, so the phase layers' share of the last update's re-pack — weight maxima, f16x2 planes, the backward's
+// row-major copies: 13 us as launches of their own between the update and this call — runs beside it (naqs_pack.hpp).
 template <int HT, int HL>
 __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const float *__restrict__ w, const SampleBufs b,
                                                          const int64_t n_samples, const uint32_t k0, const uint32_t k1,
-                                                         const naqs::ushort_t *__restrict__ wamp) {
+                                                         const naqs::ushort_t *__restrict__ wamp, const naqs::PackPhaseArgs pk) {
+    if constexpr (HT == 256) {
+        if (blockIdx.x > 0) {                              // (workgroup-uniform)
+            naqs::pack_phase_dispatch(d, pk, (int)blockIdx.x - 1);
+            return;
+        }
+    }
     constexpr int HP = HT / 4;                             // prefixes the workgroup can hold
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     __shared__ uint32_t s_ab[2][HP];
@@ -908,8 +918,14 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         if (big) {
             if (lds > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sample_head_kernel<1024, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp);
-        } else hipLaunchKernelGGL((sample_head_kernel<256, 4>), dim3(1), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp);
+            hipLaunchKernelGGL((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, naqs::PackPhaseArgs{});
+        } else {
+            // the phase share of the last update's re-pack, if a training step left it pending, rides in this launch
+            naqs::PackPhaseArgs pk;
+            st = naqs::net_take_pending_pack(net, s, &pk);
+            if (st != NAQS_OK) return st;
+            hipLaunchKernelGGL((sample_head_kernel<256, 4>), dim3(1 + (unsigned)pk.n_wgs), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, pk);
+        }
         HIP_TRY(hipGetLastError());
         n_first = hl;
         for (int n = 0; n < hl; ++n) bound *= 4;

@@ -327,3 +327,39 @@ def test_training_run_is_reproducible_at_large_tables(tmp_path, monkeypatch):
     assert logs[0][1][:, 1].max() > 20000
     for e, n in logs[1:]:
         assert np.array_equal(n, logs[0][1]) and np.array_equal(e, logs[0][0])
+
+
+def test_pending_phase_repack_is_finished_by_whoever_comes_next(tmp_path, monkeypatch):
+    """naqs_vmc_step re-packs the amplitude blocks at once and leaves the phase layers' share of the re-pack pending: the next
+    sampler call's first launch hosts it (workgroups beside the one that samples), any other reader of the phase layers starts
+    it first, a new re-pack supersedes it.  Each exit against NAQS_PACK_OVERLAP=0 (everything in order), bit for bit: log psi
+    right after training steps (reader first), after a sampler call (hosted), and after loading other parameters (superseded);
+    and the training trajectory itself."""
+    from naqs_amd.hamiltonian import keys_to_device
+    from naqs_amd.optimizer import LogKey
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NAQS_PACK_OVERLAP", mode)
+        z, hil, wf, opt = make_opt_gpu("N2", tmp_path / mode)
+        assert opt._can_onecall()
+        keys = keys_to_device(z["eval_keys"].astype(np.int64), "cuda")
+        fused = wf.fused()
+        opt.run(n_epochs=3, save_freq=None, save_final=False, output_freq=10 ** 9)
+        a = fused.log_psi(keys).clone()                                  # reader first: the pending jobs run in order on its stream
+        opt.run(n_epochs=2, save_freq=None, save_final=False, output_freq=10 ** 9)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        states, counts, probs, lp = wf.sample(100000, generator=g)       # a sampler call outside the step hosts them
+        b = fused.log_psi(keys).clone()
+        opt.run(n_epochs=2, save_freq=None, save_final=False, output_freq=10 ** 9)
+        p_now = wf.flatten_parameters().clone()
+        with torch.no_grad():
+            for p in wf.model.parameters():
+                p.mul_(0.5)
+        fused.refresh()                                                  # a new re-pack supersedes the pending one
+        c = fused.log_psi(keys).clone()
+        res[mode] = dict(a=a, b=b, c=c, e=np.array(opt.log[LogKey.E_LOC]), p=p_now, counts=counts.clone(), lp=lp.detach().clone())
+    x, y = res["1"], res["0"]
+    assert np.array_equal(x["e"], y["e"]) and torch.equal(x["p"], y["p"])
+    assert torch.equal(x["a"], y["a"]) and torch.equal(x["b"], y["b"]) and torch.equal(x["c"], y["c"])
+    assert torch.equal(x["counts"], y["counts"]) and torch.equal(x["lp"], y["lp"])
+    assert not torch.equal(x["a"], x["b"])                               # (the parameters did move between the read-outs)
