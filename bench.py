@@ -604,15 +604,26 @@ def worker(args):
     acc_all = torch.zeros((args.warmup + args.steps + n_serial + 12, 4), dtype=torch.float64, device=dev)
     n_done = [0]
 
+    # The step's ONE library call, naqs_logpsi_eloc(net, ham, M, keys, weights, log psi, E_loc, sums, stream) — phase kernel
+    # (amplitude conditionals + phase MLP on the matrix cores; builds the key hash and psi in f64) -> eloc_kernel ->
+    # reduce_kernel — through the C ABI with arguments prepared once: what FusedLogPsi.log_psi_and_local_energy does, without
+    # the per-call tensor views, stream context and pointer look-ups (~20 us of interpreter per step on a fast host, more than
+    # the 31 us step on a slow one: two of seven boxes read 47 us with `--steps 20` and 34 with the default through the wrapper)
+    import ctypes
+    from naqs_amd import _lib as _naqs_lib
+    _call = _naqs_lib.load_library().naqs_logpsi_eloc
+    _vp = ctypes.c_void_p
+    _acc0 = acc_all.data_ptr()
+    _prep = [[(nets[d_]._h, hams[d_]._h, M, _vp(key_sets[k_].data_ptr()), _vp(weight_sets[k_].data_ptr()), _vp(log_psis[d_].data_ptr()),
+               _vp(elocs[d_].data_ptr()), _vp(streams[d_].cuda_stream)) for k_ in range(N_KEY_SETS)] for d_ in range(depth)]
+
     def step(d_override=None):
         i = n_done[0]
-        row = acc_all[i]
         d = (i % depth) if d_override is None else d_override
-        with torch.cuda.stream(streams[d]):
-            # one library call: phase kernel (amplitude conditionals + phase MLP on the matrix cores; builds the key hash
-            # and psi in f64) -> eloc_kernel -> reduce_kernel
-            nets[d].log_psi_and_local_energy(hams[d], key_sets[i % N_KEY_SETS], weights=weight_sets[i % N_KEY_SETS],
-                                             log_psi_out=log_psis[d], eloc_out=elocs[d], sums_out=row)
+        nh, hh, m_, kp, wp, lp, ep, sp = _prep[d][i % N_KEY_SETS]
+        st = _call(nh, hh, m_, kp, wp, lp, ep, _vp(_acc0 + 32 * i), sp)      # sums -> row i of acc_all (4 doubles)
+        if st != 0:
+            _naqs_lib.check(st, "naqs_logpsi_eloc")
         n_done[0] += 1
 
     def fence(first_row=None):
@@ -659,6 +670,10 @@ def worker(args):
         h_.prof_enable(args.steps // stride + 1, stride)
         n_.prof_enable(args.steps // stride + 1, stride)
     first_timed = n_done[0]
+    # (a collector pause of a few hundred microseconds is a third of a 20-step region: none inside it)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -670,6 +685,7 @@ def worker(args):
         dist.all_reduce(acc_all[first_timed:n_done[0]])
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     if use_dist:
         dist.barrier()
     last_row = n_done[0] - 1
