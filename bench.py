@@ -643,6 +643,8 @@ def worker(args):
     # (an event pair costs ~4 us of queue time on its stream: at most every 10th launch of a handle is bracketed, and a
     # short region — the driver's `--steps 20` is 10 launches per handle — gets two brackets per handle, not one per step)
     stride = max(1, min(PROF_STRIDE, (args.steps // depth) // 2))
+    import gc
+    gc.collect()
     serial = None
     if depth > 1 and not args.no_serial_segment:
         for _ in range(min(args.warmup, 10)):
@@ -660,20 +662,27 @@ def worker(args):
         serial = {"ms_per_step": dts / n_serial * 1e3, "steps": n_serial, "eloc_kernel_us": e_ms / max(e_n, 1) * 1e3,
                   "logpsi_kernel_us": p_ms / max(p_n, 1) * 1e3, "measured": "this run, before the timed region"}
 
+    # As little host work as possible between the serial segment, the warm-up and the timed region: an idle GPU drops its clocks
+    # within a millisecond or so and takes milliseconds of load to come back.  The collector ran before the serial segment and is
+    # off until the region closes (a pause inside it would be a third of a 20-step region; a collector RUN between the warm-up
+    # and the region — tens of milliseconds — made `--steps 20 --warmup 5` read 39-48 us/step and the default 400 steps 32.6-34,
+    # where back-to-back regions of the same process read 32.9 and 30.0: tools/region_probe.py).  What is
+    # left between the opening synchronisation and the first timed launch is the creation of the event rings of the kernel-
+    # duration brackets (hipEvent pairs on the launch stream around every `stride`-th launch of a handle: a pair costs ~4 us of
+    # queue time, recording all of them slows the step by ~15 %): 25-80 us (NAQS_BENCH_VERBOSE=1 prints it).
+    gc.disable()                                 # (collected before the serial segment: a collector run here is milliseconds of idle GPU)
     first_warm = n_done[0]
     for _ in range(args.warmup):
         step()
     fence(first_row=first_warm)                  # (also sets the communicator up outside the timed region)
-    # kernel durations: hipEvent pairs on the launch stream around every PROF_STRIDE-th launch of the timed
-    # region (an event pair costs ~4 us of queue time; recording all of them slows the step by ~15 %)
-    for h_, n_ in zip(hams, nets):
-        h_.prof_enable(args.steps // stride + 1, stride)
-        n_.prof_enable(args.steps // stride + 1, stride)
+    t_prep = time.perf_counter()
+    if os.environ.get("NAQS_BENCH_NOPROF") != "1":      # (diagnostic: the timed region without the hipEvent brackets)
+        for h_, n_ in zip(hams, nets):
+            h_.prof_enable(args.steps // stride + 1, stride)
+            n_.prof_enable(args.steps // stride + 1, stride)
+    if os.environ.get("NAQS_BENCH_VERBOSE") == "1":
+        print(f"[bench] host time between the opening synchronisation and the first timed launch: {(time.perf_counter() - t_prep) * 1e6:.0f} us", file=sys.stderr)
     first_timed = n_done[0]
-    # (a collector pause of a few hundred microseconds is a third of a 20-step region: none inside it)
-    import gc
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -33,6 +33,19 @@ def step():
     with torch.cuda.stream(streams[d]):
         nets[d].log_psi_and_local_energy(hams[d], key_sets[i % 4], weights=weight_sets[i % 4], log_psi_out=lps[d], eloc_out=els[d], sums_out=acc[i % 4096])
     n[0] += 1
+if os.environ.get("NAQS_PROBE_LEAN") == "1":         # the step through the C ABI with prepared arguments (bench.py's way)
+    import ctypes
+    from naqs_amd import _lib as L
+    call = L.load_library().naqs_logpsi_eloc
+    vp = ctypes.c_void_p
+    prep = [[(nets[d]._h, hams[d]._h, M, vp(key_sets[k].data_ptr()), vp(weight_sets[k].data_ptr()), vp(lps[d].data_ptr()), vp(els[d].data_ptr()),
+              vp(streams[d].cuda_stream)) for k in range(4)] for d in range(depth)]
+    acc0 = acc.data_ptr()
+    def step():
+        i = n[0]; d = i % depth
+        a = prep[d][i % 4]
+        assert call(a[0], a[1], a[2], a[3], a[4], a[5], a[6], vp(acc0 + 32 * (i % 4096)), a[7]) == 0
+        n[0] += 1
 for _ in range(300): step()
 torch.cuda.synchronize()
 for K in (0, 1, 2, 4, 8, 20, 40, 100):
@@ -45,4 +58,5 @@ for K in (0, 1, 2, 4, 8, 20, 40, 100):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0, t_enq))
     a = np.median([t[0] for t in ts]) * 1e6; e = np.median([t[1] for t in ts]) * 1e6
-    print(f"K={K:4d}: region {a:8.1f} us  ({a / max(K, 1):6.2f} us/step)   host enqueue {e:8.1f} us ({e / max(K, 1):5.1f} per step)")
+    first = ts[0][0] * 1e6
+    print(f"K={K:4d}: region {a:8.1f} us  ({a / max(K, 1):6.2f} us/step; first repetition {first / max(K, 1):6.2f})   host enqueue {e:8.1f} us ({e / max(K, 1):5.1f} per step)")
