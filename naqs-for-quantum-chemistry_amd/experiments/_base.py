@@ -269,6 +269,10 @@ def _run_locked(locked, molecule_fname, hamiltonian_fname, exp_name, num_experim
                 print('\n----------Pre-training NAQS.----------\n')
             opt.pre_flatten(n_pretrain, n_samps, optimizer_args={'lr': 1e-3}, output_freq=output_freq, use_sampling=False,
                             max_batch_size=550000, flatten_phase=False)           # experiments/_base.py:284-289
+            if n_pretrain:
+                # pre-training runs through autograd on every rank by itself (randperm batches, backward kernels that may not
+                # be deterministic): the replicated step assumes bit-identical parameters, so rank 0's are sent again
+                _broadcast_parameters(wavefunction)
             opt.save()
         if reset_optimizer:
             opt.reset_optimizer()

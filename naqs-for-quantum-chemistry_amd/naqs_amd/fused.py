@@ -485,6 +485,8 @@ class FusedLogPsi:
         cap = int(max_unique)
         sb = self._step_buffers(cap, world)
         keys = keys_out if keys_out is not None else sb["keys"]
+        if keys.dtype != torch.int64 or keys.numel() < cap or not keys.is_contiguous():
+            raise ValueError("shard_sample_forward: keys_out must be a contiguous int64 tensor of at least max_unique elements")
         info = (ctypes.c_int64 * 3)(0, 0, 0)
         st = self._lib.naqs_vmc_shard_sample_forward(self._h, int(n_samples), int(seed) & (2 ** 64 - 1), cap, int(m_lo), int(m_hi),
                                                      int(rank), int(world), keys.data_ptr(), sb["counts"].data_ptr(),

@@ -180,6 +180,11 @@ class HilbertRestricted:
                      ret_states=True, ret_idxs=False, use_restricted_idxs=False):
         if N_occ not in (None, 0) or N_exc_max is not None:
             raise NotImplementedError("frozen-core / excitation-limited subspaces are out of scope")
+        # the space IS the (N_alpha, N_beta) sector: the reference's arguments (energy.py:93-97) select it again or nothing
+        for name, got, have in (("N_alpha", N_alpha, self.N_alpha), ("N_beta", N_beta, self.N_beta),
+                                ("N_up", N_up, self.N_alpha + self.N_beta)):
+            if got is not None and int(got) != int(have):
+                raise NotImplementedError(f"get_subspace({name}={got}) on a space restricted to {name}={have}")
         keys = torch.from_numpy(self._all_keys())
         idxs = self.to_idx_tensor(torch.arange(self.size)) if use_restricted_idxs else self.to_idx_tensor(keys)
         if ret_states and ret_idxs:

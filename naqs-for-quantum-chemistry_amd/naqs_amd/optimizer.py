@@ -123,7 +123,9 @@ class OptimizerBase:
         self.normalise_psi = normalise_psi
         self.n_electrons, self.n_alpha_electrons, self.n_beta_electrons = n_electrons, n_alpha_electrons, n_beta_electrons
         self.n_fixed_electrons, self.n_excitations_max = n_fixed_electrons, n_excitations_max
-        self.subspace_args = {}
+        # energy.py:93-97: what every get_subspace call of the optimiser carries (the restricted space validates them)
+        self.subspace_args = {"N_up": n_electrons, "N_alpha": n_alpha_electrons, "N_beta": n_beta_electrons,
+                              "N_occ": n_fixed_electrons, "N_exc_max": n_excitations_max}
         self.optimizer_callable, self.optimizer_args = optimizer, optimizer_args
         self.scheduler_callable, self.scheduler_args = scheduler, scheduler_args
         self.normalize_grads = normalize_grads
@@ -243,10 +245,18 @@ class OptimizerBase:
         replicates: ``_choose_dist_mode``)."""
         return _dist() if getattr(self, "_dist_mode", None) == "sharded" else None
 
-    def _choose_dist_mode(self):
-        """'single' | 'replicated' | 'sharded' for the next step, from the unique-sample count of the LAST step (the same on
-        every rank: they all drew the same table) — the count moves slowly, and the decision has to be made before sampling
-        because the replicated step is one library call that includes the sampler.  The first step replicates."""
+    def _choose_dist_mode(self, trust_local=False):
+        """'single' | 'replicated' | 'sharded' for the next step, from the unique-sample count of the LAST step — the count
+        moves slowly, and the decision has to be made before sampling because the replicated step is one library call that
+        includes the sampler.  The first step replicates.
+
+        Every rank must take the same decision (a rank that enters the sharded step's all-gather while another stays
+        replicated hangs the job), so a switch is only taken on a count the ranks have PROVEN to share:
+          * replicated -> sharded only right after a replica proof (every `replica_proof_every` steps, the same step number on
+            every rank), on the all-reduced M and parameter checksum of that proof — read on the host here, once per proof;
+          * sharded -> replicated only after `_check_shards()` has seen the last sharded steps' proof (same M, same keys).
+        ``trust_local`` (a direct `_SGD_step` call outside `run()`: the caller hands every rank the table) decides from the
+        table at hand."""
         dist = _dist()
         if dist is None:
             mode = "single"
@@ -255,6 +265,18 @@ class OptimizerBase:
             M = self._last_M if self._last_M is not None else 0
             big_enough = self.shard_min_rows <= 0 or (M >= self.shard_min_table and M // world >= self.shard_min_rows)
             mode = "sharded" if big_enough else "replicated"
+            if trust_local:
+                pass
+            elif self._dist_mode == "replicated" and self.replica_proof_every > 0 and self.shard_min_rows > 0:
+                proof = getattr(self, "_proof_at", None)
+                if proof is None or proof[0] != self.n_steps:
+                    mode = "replicated"                       # no agreed count for this step: stay (same rule on every rank)
+                else:
+                    self._check_shards()                      # raises when the proof failed (tables or parameters differ)
+                    M = int(round(float(proof[1][0].item()) / world))
+                    mode = "sharded" if (M >= self.shard_min_table and M // world >= self.shard_min_rows) else "replicated"
+            elif self._dist_mode == "sharded" and mode != "sharded":
+                self._check_shards()
         if mode != self._dist_mode:
             if dist is not None:
                 self.dist_mode_log.append((self.n_steps, mode))
@@ -269,19 +291,25 @@ class OptimizerBase:
         return mode
 
     def _replica_proof(self, keys):
-        """Replicated steps: every `replica_proof_every` steps one 32-byte all-reduce of (M, M^2, c, c^2), c = 20 low bits of
-        the key sum — W * sum x^2 == (sum x)^2 iff all ranks hold the same x (exact integers in float64).  A mismatch is
-        reported at the next log flush, like the sharded step's proof."""
+        """Replicated steps: every `replica_proof_every` steps one 48-byte all-reduce of (M, M^2, c, c^2, p, p^2), c = 20 low
+        bits of the key sum, p = 20 low bits of the sum of the parameters' bit patterns — W * sum x^2 == (sum x)^2 iff all
+        ranks hold the same x (exact integers in float64).  A mismatch is reported at the next log flush, like the sharded
+        step's proof, and before any switch to the sharded step (`_choose_dist_mode`)."""
         dist = _dist()
         if dist is None or self.replica_proof_every <= 0 or self.n_steps % self.replica_proof_every != 0:
             return
         world = dist.get_world_size()
         c = (keys.sum() & 0xFFFFF).double()
         m = torch.tensor(float(keys.shape[0]), dtype=torch.float64, device=self.device)
-        ext = torch.stack([m, m * m, c, c * c])
+        flat = getattr(self.wavefunction, "_flat_params", None)
+        if flat is None:
+            flat = torch.cat([p.detach().reshape(-1) for p in self.wavefunction.param_list()])
+        p = (flat.detach().view(torch.int32).sum(dtype=torch.int64) & 0xFFFFF).double()
+        ext = torch.stack([m, m * m, c, c * c, p, p * p])
         dist.all_reduce(ext)
-        bad = ~((world * ext[1] == ext[0] * ext[0]) & (world * ext[3] == ext[2] * ext[2]))
+        bad = ~((world * ext[1] == ext[0] * ext[0]) & (world * ext[3] == ext[2] * ext[2]) & (world * ext[5] == ext[4] * ext[4]))
         self._shard_mismatch = bad if self._shard_mismatch is None else self._shard_mismatch | bad
+        self._proof_at = (self.n_steps, ext)
 
     def reset_log(self):
         self._pending_log = []
@@ -290,6 +318,7 @@ class OptimizerBase:
         self.run_time = 0
 
     def reset_optimizer(self, cond_idx=None):
+        self._onecall_cached = None            # (a plain torch optimiser cannot take the one-call step)
         if isinstance(self.optimizer_args, dict):
             self.optimizer = self.optimizer_callable(self.wavefunction.conditional_parameters(cond_idx),
                                                      **self.optimizer_args)
@@ -357,7 +386,7 @@ class OptimizerBase:
         if self.bug_compat_full_sample_order and keys.shape[0] == self.hilbert.size:
             if getattr(self, "_restricted_order_keys", None) is None:
                 self._restricted_order_keys = keys_to_device(
-                    self.hilbert.get_subspace(ret_states=False, ret_idxs=True), self.device)
+                    self.hilbert.get_subspace(ret_states=False, ret_idxs=True, **self.subspace_args), self.device)
             return self._restricted_order_keys
         return keys
 
@@ -391,10 +420,10 @@ class OptimizerBase:
         """<psi|H|psi> over the whole restricted space (energy.py:189-217); small spaces only."""
         fused = self.wavefunction.fused(need_phase=True) if self.use_fused else None
         if fused is not None:               # keys in, one library call for log psi + E_loc
-            keys = keys_to_device(self.hilbert.get_subspace(ret_states=False, ret_idxs=True), self.device)
+            keys = keys_to_device(self.hilbert.get_subspace(ret_states=False, ret_idxs=True, **self.subspace_args), self.device)
             lp, e = fused.log_psi_and_local_energy(self.pauli_hamiltonian, keys)
         else:
-            states, idx = self.hilbert.get_subspace(ret_states=True, ret_idxs=True)
+            states, idx = self.hilbert.get_subspace(ret_states=True, ret_idxs=True, **self.subspace_args)
             keys = keys_to_device(idx, self.device)
             with torch.no_grad():
                 lp = self.wavefunction.log_psi(states.to(self.device)).reshape(-1, 2)
@@ -410,7 +439,7 @@ class OptimizerBase:
         2 Re sum w log psi (E_loc - <E>) -> backward -> optimiser step -> (<E>, Var)."""
         if not getattr(self, "_in_run", False):           # called outside run(): the policy decides from the table at hand
             self._last_M = int(keys_to_device(states_idx, self.device).shape[0])
-            self._choose_dist_mode()
+            self._choose_dist_mode(trust_local=True)
         dist = self._active_dist()
         world, rank = (dist.get_world_size(), dist.get_rank()) if dist else (1, 0)
         keys = keys_to_device(states_idx, self.device)
@@ -648,7 +677,7 @@ class PartialSamplingOptimizer(OptimizerBase):
         if use_sampling:
             raise NotImplementedError("pre_flatten(use_sampling=True): the reference's own branch fails (energy.py:880-887 returns None)")
         wf = self.wavefunction
-        states = self.hilbert.get_subspace(ret_states=True, ret_idxs=False).to(self.device)
+        states = self.hilbert.get_subspace(ret_states=True, ret_idxs=False, **self.subspace_args).to(self.device)   # energy.py:859
         opt = optimizer(wf.parameters(), **optimizer_args)
         log_amp_target = math.log(1 / math.sqrt(len(states)))
         if max_batch_size < 0:
@@ -676,22 +705,27 @@ class PartialSamplingOptimizer(OptimizerBase):
         wf.parameters_changed()                               # the fused kernels' packed weights follow
         print("done.")
 
-    def _can_prefuse(self):
-        """The conditions under which _SGD_step takes its single-GPU fused branch (forward + E_loc in one call) — known
-        before sampling, so that the sampler's call can include them."""
-        if not self.use_fused or self._active_dist() is not None or self.normalize_grads or self.bug_compat_full_sample_order:
+    def _fused_step_conditions(self):
+        """What the single-GPU fused branch of _SGD_step and every one-call form of the step (single process or sharded) have
+        in common — everything except who owns the rows: the fused HIP path with nothing between forward and E_loc, and the
+        A/B switches NAQS_TRAIN_FUSED_ELOC / NAQS_TRAIN_PREFUSE."""
+        if not self.use_fused or self.normalize_grads or self.bug_compat_full_sample_order:
             return False
         if os.environ.get("NAQS_TRAIN_FUSED_ELOC", "1") != "1" or os.environ.get("NAQS_TRAIN_PREFUSE", "1") != "1":
             return False
         fused = self.wavefunction.fused(need_phase=True)
         return fused is not None and fused.train_mode == "hip"
 
-    def _can_onecall(self):
-        """The conditions under which a whole training step is ONE library call (``FusedLogPsi.vmc_step``): the single-GPU
-        fused branch of _SGD_step, followed by FlatAdam on the network's own flat parameter vector with nothing in between
-        (no gradient clipping: experiments/_base.py:224 runs with grad_clip_factor=None)."""
+    def _can_prefuse(self):
+        """The conditions under which _SGD_step takes its single-GPU fused branch (forward + E_loc in one call) — known
+        before sampling, so that the sampler's call can include them."""
+        return self._active_dist() is None and self._fused_step_conditions()
+
+    def _onecall_update_conditions(self):
+        """The update half of a one-call step: FlatAdam on the network's own flat parameter vector with nothing between the
+        backward pass and the update (no gradient clipping: experiments/_base.py:224 runs with grad_clip_factor=None)."""
         from .flat_adam import FlatAdam
-        if os.environ.get("NAQS_TRAIN_ONECALL", "1") != "1" or not self._can_prefuse():
+        if os.environ.get("NAQS_TRAIN_ONECALL", "1") != "1":
             return False
         if self.grad_clip_factor is not None or not isinstance(self.optimizer, FlatAdam):
             return False
@@ -699,6 +733,11 @@ class PartialSamplingOptimizer(OptimizerBase):
         flat = getattr(wf, "_flat_params", None)
         return (flat is not None and flat.data_ptr() == self.optimizer._flat.data_ptr() and wf._views_of(flat, wf.param_list())
                 and all(p.grad is None for p in wf.param_list()))
+
+    def _can_onecall(self):
+        """The conditions under which a whole training step is ONE library call (``FusedLogPsi.vmc_step``): the single-GPU
+        fused branch of _SGD_step, followed by FlatAdam with nothing in between."""
+        return self._can_prefuse() and self._onecall_update_conditions()
 
     def _onecall_step(self):
         """get_samples (adaptive sample count, energy.py:936-971) + _SGD_step (energy.py:273-377) through
@@ -746,21 +785,11 @@ class PartialSamplingOptimizer(OptimizerBase):
         return counts, weights, ev
 
     def _can_shard_onecall(self):
-        """The sharded step as four library calls (``FusedLogPsi.shard_*``): the one-call step's conditions with a process
-        group in place of the single process."""
-        from .flat_adam import FlatAdam
-        if self._active_dist() is None or os.environ.get("NAQS_TRAIN_ONECALL", "1") != "1":
+        """The sharded step as four library calls (``FusedLogPsi.shard_*``): the one-call step's conditions (one shared
+        predicate, A/B switches included) with a process group in place of the single process."""
+        if self._active_dist() is None or not self._fused_step_conditions() or not self._onecall_update_conditions():
             return False
-        if not self.use_fused or self.normalize_grads or self.bug_compat_full_sample_order or self.grad_clip_factor is not None:
-            return False
-        if not isinstance(self.optimizer, FlatAdam):
-            return False
-        wf = self.wavefunction
-        fused = wf.fused(need_phase=True)
-        flat = getattr(wf, "_flat_params", None)
-        return (fused is not None and fused.train_mode == "hip" and not fused.aggregate and flat is not None
-                and flat.data_ptr() == self.optimizer._flat.data_ptr() and wf._views_of(flat, wf.param_list())
-                and all(p.grad is None for p in wf.param_list()))
+        return not self.wavefunction.fused(need_phase=True).aggregate
 
     def _sharded_onecall_step(self):
         """One row-sharded VMC step = four library calls and three collectives (include/naqs_hip.h): sampler +
@@ -918,6 +947,9 @@ class PartialSamplingOptimizer(OptimizerBase):
         if reset_optimizer:
             self.reset_optimizer()
         run_time_at_last_log, steps_at_last_log = self.run_time, self.n_steps
+        # the step form (one call / sharded one-call / pieces) is decided once per run() and on a distributed-mode switch:
+        # use_fused, grad_clip_factor, normalize_grads, the optimiser ... may all have changed since the last run()
+        self._onecall_cached = None
         _freeze_garbage_collector()
         print("Training NAQS energy.  Samples will be weighted by their frequency.")
         if self.n_steps == 0:

@@ -211,3 +211,63 @@ def test_one_call_loop_adapts_the_sample_count_like_get_samples(tmp_path, monkey
                 logs.append((calls, out, opt.n_samples))
             assert logs[0] == logs[1], (start, logs)
             assert len(logs[0][0]) >= 1
+
+
+def _switch_worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "naqs-for-quantum-chemistry_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle_backend
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle_backend.install(__import__("naqs_amd.optimizer").optimizer)
+    z, hil, wf, opt = make_opt("LiH", os.path.join(tmp, f"r{rank}"), None, seed=11, n_samples=5000)
+    # a policy under which LiH's table is "big enough" — the switch to the sharded step may then only happen on a count
+    # the ranks have proven to share: right after a replica proof (every 3rd step here), never in between
+    opt.shard_min_rows, opt.shard_min_table, opt.replica_proof_every = 1, 1, 3
+    opt.run(5, output_freq=10 ** 6)
+    modes_up = list(opt.dist_mode_log)
+    # and back: the table is now "too small"; leaving the sharded step needs the sharded proof to be clean (it is)
+    opt.shard_min_rows, opt.shard_min_table = 10 ** 9, 10 ** 9
+    opt.run(2, output_freq=10 ** 6)
+    params = torch.cat([p.detach().reshape(-1) for p in wf.model.parameters()])
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    torch.save({"modes_up": modes_up, "modes": list(opt.dist_mode_log), "same": all(torch.equal(g, gathered[0]) for g in gathered),
+                "n_steps": opt.n_steps}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_ranks_switch_between_replicated_and_sharded_steps_on_an_agreed_count(tmp_path):
+    """A rank that enters the sharded step's all-gather while the other still replicates would hang the job.  The
+    replicated -> sharded switch is therefore taken only on the all-reduced count of a replica proof (step 3 here, although
+    the table was big enough from step 1 on), and both ranks log the same switches at the same steps."""
+    import torch.multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sw")
+    mp.spawn(_switch_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in range(2))
+    assert r0["modes_up"] == r1["modes_up"] == [(0, "replicated"), (3, "sharded")], (r0, r1)
+    assert r0["modes"] == r1["modes"] == [(0, "replicated"), (3, "sharded"), (5, "replicated")], (r0, r1)
+    assert r0["same"] and r1["same"] and r0["n_steps"] == r1["n_steps"] == 7
+
+
+def test_step_form_is_decided_again_on_every_run_and_optimizer_reset(tmp_path, monkeypatch):
+    """The cached decision (one library call per step or the pieces) must not outlive a run(): use_fused, grad_clip_factor,
+    normalize_grads or the optimiser itself may have changed in between (a plain torch optimiser cannot take the one-call
+    step at all)."""
+    z, hil, wf, opt = make_opt("LiH", tmp_path, monkeypatch, n_samples=2000)
+    asked = []
+    monkeypatch.setattr(opt, "_can_onecall", lambda: asked.append(1) or False)
+    opt.run(2, output_freq=10 ** 6)
+    assert len(asked) == 1 and opt._onecall_cached == 0
+    opt.run(1, output_freq=10 ** 6)
+    assert len(asked) == 2
+    opt._onecall_cached = 1
+    opt.reset_optimizer()
+    assert opt._onecall_cached is None
