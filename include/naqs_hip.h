@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 6
+#define NAQS_ABI_VERSION 7
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -54,9 +54,19 @@ int naqs_abi_version(void);
  * exact kernels they were collected on. */
 const char *naqs_source_hash(void);
 const char *naqs_strerror(int status);
-/* hipError_t of the most recent failing HIP call on this thread (0 if none) and its text. */
+/* hipError_t of the most recent failing HIP call on this thread (0 if none) and its text.  When the failure was a
+ * device-side wait that ran out of its budget (naqs_device_check below), the text names the kernel site, the waiting
+ * workgroup and the index it waited for. */
 int naqs_last_hip_error(void);
 const char *naqs_last_hip_error_string(void);
+/* Kernels of this library that wait for a word another workgroup publishes (sampler look-back, column-split log-psi
+ * tiles, fused sums, re-pack scale chain) give up after NAQS_POLL_BUDGET_MS (default 2000) instead of hanging: the wave
+ * records the site in a per-device error word and leaves without writing results.  Every entry point looks at that word
+ * when it is called; this call looks at it on demand (e.g. after a stream synchronisation): NAQS_OK, or NAQS_ERR_HIP with
+ * naqs_last_hip_error_string() describing the wait.  The reference has no counterpart (its only failure path in the loop is
+ * MaxBatchSizeExceededError, src/naqs/network/nade.py:39-40, 710-712 -> src/optimizer/energy.py:939-946); a hang has to
+ * become an error somewhere. */
+int naqs_device_check(int device);
 
 /* Number of HIP devices visible to the library (0 when there is none); never fails. */
 int naqs_device_count(void);

@@ -1225,7 +1225,7 @@ __device__ __forceinline__ void ws_amp_work(const NetDims &d, const ushort_t *__
 // sampler's look-back words, naqs_sample.hip); the consumer adds the partial rows last:
 // ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)), a fixed order, but not the unsplit kernel's (last-bit differences of the
 // phase between the two forms; every other value — log|psi|, saved activations — is the same).
-struct WsSplit { unsigned long long *xchg; uint32_t tag; };
+struct WsSplit { unsigned long long *xchg; uint32_t tag; const naqs::PollCtl *ctl; };
 
 template <int RB, bool SAVE, bool SPLIT = false>
 __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, const float *__restrict__ w,
@@ -1452,23 +1452,23 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
                     const int e = x - BM * 4;
                     v = s_lan[n_split + e / BM][e % BM];
                 }
-                __hip_atomic_store(&xw[x], tagw | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(naqs::poll_drop(split.ctl, naqs::POLL_LOGPSI_SPLIT) && tile == 0 && x == 0))      // (debug knob: naqs_poll.hpp)
+                    __hip_atomic_store(&xw[x], tagw | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
         // the consumer: a word per thread (and round), all requests in flight together.  The producer has a lower workgroup
-        // index: it was dispatched before this workgroup, so it is running or has finished
+        // index: it was dispatched before this workgroup, so it is running or has finished; the wait is bounded all the same
+        // (naqs_poll.hpp): when it runs out the tile's results are not written and the host gets NAQS_ERR_HIP
+        bool ok = true;
         for (int x = tid; x < BM * 4 + n_amp; x += PH_THREADS) {
-            unsigned long long word = __hip_atomic_load(&xw[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((word & 0xFFFFFFFF00000000ull) != tagw) {
-                __builtin_amdgcn_s_sleep(2);
-                word = __hip_atomic_load(&xw[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            unsigned long long word;
+            ok = naqs::poll_tagged<2>(&xw[x], split.tag, word, split.ctl, naqs::POLL_LOGPSI_SPLIT, (uint32_t)x) && ok;
             const float v = __uint_as_float((uint32_t)word);
             if (x < BM * 4) s_recv[x >> 2][x & 3] = v;
             else { const int e = x - BM * 4; s_lan[n_split + e / BM][e % BM] = v; }
         }
-        __syncthreads();
+        if (__syncthreads_or(!ok)) return;
     }
     if (tid < BM) {
         const int64_t i = row0 + tid;
@@ -1492,8 +1492,9 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
 using naqs::PhasePackJobs;
 using naqs::phase_weight_scale;
 __global__ __launch_bounds__(256) void net_bounds_kernel(const float *__restrict__ flat, const PhasePackJobs jobs,
-                                                         naqs::PhaseRaw *__restrict__ raw, const uint32_t tag) {
-    naqs::net_bounds_body(flat, jobs, raw, blockIdx.y, tag, blockIdx.x);
+                                                         naqs::PhaseRaw *__restrict__ raw, const uint32_t tag,
+                                                         const naqs::PollCtl *ctl) {
+    naqs::net_bounds_body(flat, jobs, raw, blockIdx.y, tag, blockIdx.x, ctl);
 }
 
 // f32 [N][K] -> three bf16 planes, zero-padded and tiled [plane][N_pad/16][Kh_pad/32][64 lanes][8]
@@ -1649,10 +1650,17 @@ __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, in
 __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
                                                 float *__restrict__ w, ushort_t *__restrict__ wh, const int with_f32, const int l,
                                                 const int fmt, const naqs::PhaseRaw *__restrict__ raw,
-                                                naqs::PhaseScales *__restrict__ scales, const uint32_t tag) {
+                                                naqs::PhaseScales *__restrict__ scales, const uint32_t tag,
+                                                const naqs::PollCtl *ctl) {
     if (fmt == 2 && !with_f32) {                        // (the training step's format: shared with the sampler's first launch)
-        naqs::pack_phase_job_f16x2(flat, d, jobs, w, wh, l, raw, scales, tag, blockIdx.x, gridDim.x);
+        naqs::pack_phase_job_f16x2(flat, d, jobs, w, wh, l, raw, scales, tag, blockIdx.x, gridDim.x, ctl);
         return;
+    }
+    float sw = 1.0f;
+    if (fmt == 2) {                                     // (whole waves poll; a wait that ran out: nothing of this job is written)
+        bool ok = true;
+        sw = phase_weight_scale(*raw, l, tag, ctl, ok);
+        if (__syncthreads_or(!ok)) return;
     }
     const float *src = flat + jobs.src_off[l];
     if (with_f32) pack_phase_f32(src, jobs.K[l], jobs.N[l], d.K_pad[l], d.N_pad[l], w + d.w_off[l], w + d.b_off[l]);
@@ -1668,8 +1676,7 @@ __device__ __forceinline__ void pack_phase_body(const float *__restrict__ flat, 
             }
         }
     }
-    if (fmt == 2) naqs::pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l, tag),
-                                       blockIdx.x, gridDim.x);
+    if (fmt == 2) naqs::pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], sw, blockIdx.x, gridDim.x);
     else pack_phase_bf16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l]);
 }
 // naqs_net_set_weights of the single-phase network in ONE launch (it runs once per training step, and every launch of a
@@ -1682,7 +1689,8 @@ __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__
                                                        const PhasePackJobs jobs, const naqs::WbPackJobs wb, float *__restrict__ w,
                                                        ushort_t *__restrict__ wh, ushort_t *__restrict__ wamp, const int with_f32,
                                                        const int fmt, const naqs::PhaseRaw *__restrict__ raw,
-                                                       naqs::PhaseScales *__restrict__ scales, const int y_base, const uint32_t tag) {
+                                                       naqs::PhaseScales *__restrict__ scales, const int y_base, const uint32_t tag,
+                                                       const naqs::PollCtl *ctl) {
     int y = blockIdx.y + y_base;
     if (y < d.P) { pack_amp_body(flat, d, so, w, y); return; }
     y -= d.P;
@@ -1690,7 +1698,7 @@ __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__
         if (y < d.P) { pack_amp_mfma_body(flat, d, so, wamp, y); return; }
         y -= d.P;
     }
-    if (y < d.n_lin) { pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw, scales, tag); return; }
+    if (y < d.n_lin) { pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw, scales, tag, ctl); return; }
     y -= d.n_lin;
     if (y < wb.n) naqs::pack_wb_job(flat, wb, y, blockIdx.x, gridDim.x);
 }
@@ -1724,6 +1732,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     naqs_net *net = new (std::nothrow) naqs_net();
     if (!net) return NAQS_ERR_NOMEM;
     net->device = device;
+    net->ctl = naqs::poll_ctl(device);
     net->cfg = *cfg;
     NetDims &d = net->dims;
     d.P = P;
@@ -2014,28 +2023,28 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
     if (!split) {
         if (fmt == 2) {
             // weight maxima -> scales (device side; no host round trip)
-            hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq);
+            hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy_amp + gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
-                           with_f32, fmt, raw, net->d_scales, 0, net->pack_seq);
+                           with_f32, fmt, raw, net->d_scales, 0, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = nullptr;
     } else if (mode == PACK_AMP) {
         hipLaunchKernelGGL(pack_net_kernel, dim3(std::min(256, (amp_biggest + 255) / 256), gy_amp), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w,
-                           net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u);
+                           net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = flat_dev;
     } else if (mode == PACK_PHASE) {
-        hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq);
+        hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp, with_f32,
-                           fmt, raw, net->d_scales, gy_amp, net->pack_seq);
+                           fmt, raw, net->d_scales, gy_amp, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = nullptr;
     } else {                                               // PACK_TAKE: the caller's launch hosts the jobs
         take->flat = flat_dev; take->jobs = jobs; take->wb = wb; take->w = net->d_w; take->wh = net->d_wh; take->raw = raw;
-        take->scales = net->d_scales; take->tag = net->pack_seq; take->gx = gx;
+        take->scales = net->d_scales; take->tag = net->pack_seq; take->gx = gx; take->ctl = net->ctl;
         take->n_wgs = d.n_lin * naqs::BOUNDS_WG + gy_phase * gx;
         net->pack_pending = nullptr;
     }
@@ -2178,6 +2187,8 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
+    st = naqs::poll_check(net->device);                    // an earlier launch's device-side wait that gave up (naqs_poll.hpp)
+    if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     st = naqs::net_flush_pack(net, s);                     // (the phase share of the last step's re-pack, if no launch hosted it)
@@ -2232,7 +2243,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const int bm = rb * 16;
     const unsigned grid = (unsigned)((M + bm - 1) / bm);
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
-    WsSplit split{nullptr, 0u};
+    WsSplit split{nullptr, 0u, net->ctl};
     if (ws_split) {
         const size_t words = (size_t)(net->cu_count / 2) * (48 * 4 + MAXP * 48);      // per tile (of up to 48 rows): partial rows + the producer's conditionals
         if (!net->d_ws_xchg) {

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "naqs_common.hpp"
+#include "naqs_poll.hpp"
 
 namespace naqs {
 
@@ -208,6 +209,7 @@ struct naqs_net {
     int64_t *d_info_alias = nullptr;        // their device address
     int64_t *d_info2 = nullptr;             // device words for the sampler's plain (M, overflow) output of those calls
     int64_t info_seq = 0;                   // sampling calls that published there
+    const naqs::PollCtl *ctl = nullptr;     // the device's bounded-wait control block (naqs_poll.hpp); every kernel that polls gets it
     hipStream_t side_stream = nullptr;      // the amplitude blocks' backward runs here, beside the phase MLP's (naqs_phase_grad.hip)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

@@ -12,6 +12,7 @@
 
 #include "naqs_amp_mfma.hpp"
 #include "naqs_net.hpp"
+#include "naqs_poll.hpp"
 
 #ifndef NAQS_PH_CBT
 #define NAQS_PH_CBT 4
@@ -32,7 +33,7 @@ struct PhasePackJobs { int64_t src_off[MAXL]; int32_t K[MAXL], N[MAXL]; };
 // row (a 512 x 512 layer: 512 waves, one load round trip each); workgroups 0 .. BOUNDS_WG - 1 of job l publish their partials
 constexpr int BOUNDS_WAVES = 4;
 __device__ __forceinline__ void net_bounds_body(const float *__restrict__ flat, const PhasePackJobs &jobs, PhaseRaw *__restrict__ raw,
-                                                const int l, const uint32_t tag, const int bx) {
+                                                const int l, const uint32_t tag, const int bx, const PollCtl *ctl) {
     __shared__ float s_red[3][BOUNDS_WAVES];
     if (bx >= BOUNDS_WG) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -56,7 +57,8 @@ __device__ __forceinline__ void net_bounds_body(const float *__restrict__ flat, 
         float m = 0.0f;
         for (int w = 0; w < BOUNDS_WAVES; ++w) m = fmaxf(m, s_red[threadIdx.x][w]);
         unsigned long long *dst = threadIdx.x == 0 ? raw->max_w[l] : (threadIdx.x == 1 ? raw->max_rowsum[l] : raw->max_b[l]);
-        __hip_atomic_store(&dst[bx], ((unsigned long long)tag << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(poll_drop(ctl, POLL_PACK_BOUNDS) && l == 0 && bx == 0))
+            __hip_atomic_store(&dst[bx], ((unsigned long long)tag << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -64,13 +66,12 @@ __device__ __forceinline__ void net_bounds_body(const float *__restrict__ flat, 
 // result.  (A serial loop over the 64 entries — by one thread for the scale chain, by every workgroup for its weight scale —
 // made the packing launch 36 us instead of 8.)  Must be called by whole waves.
 static_assert(BOUNDS_WG == 64, "one partial per lane");
-__device__ __forceinline__ float bounds_max(const unsigned long long (&part)[BOUNDS_WG], const uint32_t tag) {
-    const unsigned long long *src = &part[threadIdx.x & 63];
-    unsigned long long word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((uint32_t)(word >> 32) != tag) {
-        __builtin_amdgcn_s_sleep(2);
-        word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+// (the wait is bounded — naqs_poll.hpp: `ok` turns false, for every lane of the wave, when a word did not arrive in time; the
+// callers then leave without writing anything)
+__device__ __forceinline__ float bounds_max(const unsigned long long (&part)[BOUNDS_WG], const uint32_t tag, const PollCtl *ctl, bool &ok) {
+    unsigned long long word;
+    const bool mine = poll_tagged<2>(&part[threadIdx.x & 63], tag, word, ctl, POLL_PACK_BOUNDS, threadIdx.x & 63);
+    if (!__all(mine)) ok = false;
     float m = __uint_as_float((uint32_t)word);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -78,25 +79,27 @@ __device__ __forceinline__ float bounds_max(const unsigned long long (&part)[BOU
 }
 
 // weight scale of layer l: max |W| sw in [2^13, 2^14)
-__device__ __forceinline__ float phase_weight_scale(const PhaseRaw &raw, int l, const uint32_t tag) {
-    return pow2_clamped(13 - exp_of(bounds_max(raw.max_w[l], tag)));
+__device__ __forceinline__ float phase_weight_scale(const PhaseRaw &raw, int l, const uint32_t tag, const PollCtl *ctl, bool &ok) {
+    return pow2_clamped(13 - exp_of(bounds_max(raw.max_w[l], tag, ctl, ok)));
 }
 // all scales of the network (called by one whole wave; lane 0 writes): activation bound chain
 // |h_l| <= rowsum_l bound_{l-1} + max|b_l|, inputs +-1
-__device__ __forceinline__ void phase_scales_fill(const PhaseRaw &raw, int n_lin, PhaseScales *out, const uint32_t tag) {
+__device__ __forceinline__ void phase_scales_fill(const PhaseRaw &raw, int n_lin, PhaseScales *out, const uint32_t tag, const PollCtl *ctl) {
     float bound = 1.0f, s_in = 1.0f;
+    PhaseScales v;
+    bool ok = true;
     for (int l = 0; l < n_lin; ++l) {
-        bound = bounds_max(raw.max_rowsum[l], tag) * bound + bounds_max(raw.max_b[l], tag);
-        const float sw = phase_weight_scale(raw, l, tag);
+        bound = bounds_max(raw.max_rowsum[l], tag, ctl, ok) * bound + bounds_max(raw.max_b[l], tag, ctl, ok);
+        const float sw = phase_weight_scale(raw, l, tag, ctl, ok);
         const float sn = l + 1 < n_lin ? pow2_clamped(14 - exp_of(bound)) : 1.0f;          // bound sn < 2^15
-        if ((threadIdx.x & 63) == 0) {
-            out->sw[l] = sw;
-            out->sn[l] = sn;
-            out->isn[l] = 1.0f / sn;
-            out->c[l] = (sn / s_in) / sw;            // powers of two: exact
-        }
+        v.sw[l] = sw;
+        v.sn[l] = sn;
+        v.isn[l] = 1.0f / sn;
+        v.c[l] = (sn / s_in) / sw;                   // powers of two: exact
         s_in = sn;
     }
+    if (ok && (threadIdx.x & 63) == 0)
+        for (int l = 0; l < n_lin; ++l) { out->sw[l] = v.sw[l]; out->sn[l] = v.sn[l]; out->isn[l] = v.isn[l]; out->c[l] = v.c[l]; }
 }
 
 // f32 [N][K] -> two f16 planes of sw * W, zero-padded and tiled [plane][N_pad/16][Kh_pad/32][64 lanes][8]
@@ -120,8 +123,11 @@ __device__ __forceinline__ void pack_phase_f16(const float *__restrict__ src, in
 __device__ __forceinline__ void pack_phase_job_f16x2(const float *__restrict__ flat, const NetDims &d, const PhasePackJobs &jobs,
                                                      float *__restrict__ w, ushort_t *__restrict__ wh, const int l,
                                                      const PhaseRaw *__restrict__ raw, PhaseScales *__restrict__ scales,
-                                                     const uint32_t tag, const int bx, const int nbx) {
-    if (l == 0 && bx == 0 && threadIdx.x < 64) phase_scales_fill(*raw, d.n_lin, scales, tag);
+                                                     const uint32_t tag, const int bx, const int nbx, const PollCtl *ctl) {
+    if (l == 0 && bx == 0 && threadIdx.x < 64) phase_scales_fill(*raw, d.n_lin, scales, tag, ctl);
+    bool ok = true;
+    const float sw = phase_weight_scale(*raw, l, tag, ctl, ok);        // (every wave of the workgroup: whole waves poll)
+    if (__syncthreads_or(!ok)) return;                                  // a wait ran out: nothing of this job is written
     const float *src = flat + jobs.src_off[l];
     for (int n = bx * 256 + threadIdx.x; n < d.N_pad[l]; n += nbx * 256)
         w[d.b_off[l] + n] = n < jobs.N[l] ? src[jobs.N[l] * jobs.K[l] + n] : 0.0f;
@@ -132,7 +138,7 @@ __device__ __forceinline__ void pack_phase_job_f16x2(const float *__restrict__ f
             w[d.w_off[l] + e] = (n < jobs.N[l] && k < jobs.K[l]) ? src[n * jobs.K[l] + k] : 0.0f;
         }
     }
-    pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], phase_weight_scale(*raw, l, tag), bx, nbx);
+    pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], sw, bx, nbx);
 }
 
 // row-major zero-padded copy y of the phase weights (what the backward GEMMs read)
@@ -156,13 +162,14 @@ struct PackPhaseArgs {
     PhaseScales *scales = nullptr;
     uint32_t tag = 0;
     int gx = 0, n_wgs = 0;
+    const PollCtl *ctl = nullptr;
 };
 __device__ __forceinline__ void pack_phase_dispatch(const NetDims &d, const PackPhaseArgs &a, int bid) {
     const int nb = d.n_lin * BOUNDS_WG;
-    if (bid < nb) { net_bounds_body(a.flat, a.jobs, a.raw, bid / BOUNDS_WG, a.tag, bid % BOUNDS_WG); return; }
+    if (bid < nb) { net_bounds_body(a.flat, a.jobs, a.raw, bid / BOUNDS_WG, a.tag, bid % BOUNDS_WG, a.ctl); return; }
     bid -= nb;
     const int y = bid / a.gx, x = bid - y * a.gx;
-    if (y < d.n_lin) pack_phase_job_f16x2(a.flat, d, a.jobs, a.w, a.wh, y, a.raw, a.scales, a.tag, x, a.gx);
+    if (y < d.n_lin) pack_phase_job_f16x2(a.flat, d, a.jobs, a.w, a.wh, y, a.raw, a.scales, a.tag, x, a.gx, a.ctl);
     else if (y - d.n_lin < a.wb.n) pack_wb_job(a.flat, a.wb, y - d.n_lin, x, a.gx);
 }
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, co
                                                              double *__restrict__ ev, const float *__restrict__ Wtop,
                                                              const float *__restrict__ act, const int Kp, float *__restrict__ dout,
                                                              double *__restrict__ sums_out, unsigned long long *__restrict__ words,
-                                                             const uint32_t tag) {
+                                                             const uint32_t tag, const naqs::PollCtl *ctl) {
     __shared__ double s_red[4][naqs::RED_BLOCK / 64];
     __shared__ double s_sums[4];
     __shared__ uint32_t s_half[8];
@@ -138,19 +138,18 @@ __global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, co
             if (threadIdx.x < 8) {
                 const double v = s_sums[threadIdx.x >> 1];
                 const uint32_t half = (threadIdx.x & 1) ? (uint32_t)__double2loint(v) : (uint32_t)__double2hiint(v);
-                __hip_atomic_store(&words[threadIdx.x], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(naqs::poll_drop(ctl, naqs::POLL_SEED_SUMS) && threadIdx.x == 0))
+                    __hip_atomic_store(&words[threadIdx.x], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (threadIdx.x < 4) sums_out[threadIdx.x] = s_sums[threadIdx.x];
             }
         } else {
+            bool ok = true;
             if (threadIdx.x < 8) {
-                unsigned long long word = __hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while ((uint32_t)(word >> 32) != tag) {
-                    __builtin_amdgcn_s_sleep(2);
-                    word = __hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                unsigned long long word;
+                ok = naqs::poll_tagged<2>(&words[threadIdx.x], tag, word, ctl, naqs::POLL_SEED_SUMS, threadIdx.x);
                 s_half[threadIdx.x] = (uint32_t)word;
             }
-            __syncthreads();
+            if (__syncthreads_or(!ok)) return;             // the wait ran out (naqs_poll.hpp): nothing of this workgroup is written
             if (threadIdx.x < 4) s_sums[threadIdx.x] = __hiloint2double((int)s_half[2 * threadIdx.x], (int)s_half[2 * threadIdx.x + 1]);
             __syncthreads();
         }
@@ -758,6 +757,7 @@ static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     } else {
         HIP_TRY(hipStreamSynchronize(s));
     }
+    { const int pc = naqs::poll_check(net->device); if (pc != NAQS_OK) return pc; }      // a look-back wait that gave up (naqs_poll.hpp)
     if (h[2] != seq) return NAQS_ERR_HIP;                   // the stream drained and nothing was published
     out[0] = h[0];
     out[1] = h[1];
@@ -882,13 +882,13 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
                                reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, nullptr, reinterpret_cast<float2 *>(seeds->g_out),
                                g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
                                reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]),
-                               const_cast<double *>(seeds->sums), net->d_sum_words, net->sums_seq);
+                               const_cast<double *>(seeds->sums), net->d_sum_words, net->sums_seq, net->ctl);
         } else {
             hipLaunchKernelGGL(vmc_seed_delta_kernel<false>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
                                reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
                                g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
                                reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]),
-                               nullptr, nullptr, 0u);
+                               nullptr, nullptr, 0u, nullptr);
         }
         HIP_TRY(hipGetLastError());
         if (side) { HIP_TRY(hipEventRecord(net->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0)); }

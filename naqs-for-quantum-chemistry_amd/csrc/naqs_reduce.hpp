@@ -31,22 +31,45 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 constexpr int RED_BLOCK = 1024;      // the order is that of 1024 threads striding the table
 // called by all NT threads of a workgroup (NT = 1024, 512 or 256: a thread plays RED_BLOCK / NT of the 1024, wave w the
-// waves w, w + NT / 64, ...); the four sums are in s[.][0 .. 15] -> out[0 .. 3] by threads 0 .. 3 after the barrier
+// waves w, w + NT / 64, ...); the four sums are in s[.][0 .. 15] -> out[0 .. 3] by threads 0 .. 3 after the barrier.
+// Each of the 1024 (virtual) threads adds its elements i, i + 1024, ... in ascending order — but the LOADS of eight
+// consecutive elements (over the Q virtual threads a real one plays) are issued together before any is used: the plain
+// grid-stride loop compiled to one dependent load round trip per element (ten of them for 10^4 rows: 4 of reduce_kernel's
+// 5.4 us, and 8 round trips at the head of the training step's backward pass, whose other workgroups wait for these sums).
 template <int NT>
 __device__ __forceinline__ void weighted_sums_block(const int64_t n, const double *__restrict__ w, const double2 *__restrict__ e,
                                                     double (*s)[RED_BLOCK / 64], double *out) {
     constexpr int Q = RED_BLOCK / NT;
+    constexpr int U = 8 / Q;             // elements per virtual thread and batch: Q * U = 8 (w, e) pairs in flight
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double a[Q], b[Q], c[Q], d[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) a[q] = b[q] = c[q] = d[q] = 0.0;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)RED_BLOCK * U) {
+        double wi[Q][U];
+        double2 ei[Q][U];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + q * NT + (int64_t)u * RED_BLOCK;
+                if (i < n) { wi[q][u] = w[i]; ei[q][u] = e[i]; }
+            }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + q * NT + (int64_t)u * RED_BLOCK;
+                if (i < n) {
+                    a[q] += wi[q][u] * ei[q][u].x; b[q] += wi[q][u] * ei[q][u].y;
+                    c[q] += wi[q][u] * ei[q][u].x * ei[q][u].x; d[q] += wi[q][u];
+                }
+            }
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        double a = 0, b = 0, c = 0, d = 0;
-        for (int64_t i = threadIdx.x + q * NT; i < n; i += RED_BLOCK) {
-            const double wi = w[i];
-            const double2 ei = e[i];
-            a += wi * ei.x; b += wi * ei.y; c += wi * ei.x * ei.x; d += wi;
-        }
-        a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
-        if (lane == 0) { s[0][wv + q * (NT / 64)] = a; s[1][wv + q * (NT / 64)] = b; s[2][wv + q * (NT / 64)] = c; s[3][wv + q * (NT / 64)] = d; }
+        const double ra = wave_sum(a[q]), rb = wave_sum(b[q]), rc = wave_sum(c[q]), rd = wave_sum(d[q]);
+        if (lane == 0) { s[0][wv + q * (NT / 64)] = ra; s[1][wv + q * (NT / 64)] = rb; s[2][wv + q * (NT / 64)] = rc; s[3][wv + q * (NT / 64)] = rd; }
     }
     __syncthreads();
     if (threadIdx.x < 4) {

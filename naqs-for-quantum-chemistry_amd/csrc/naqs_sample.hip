@@ -53,6 +53,7 @@ struct SampleBufs {
     uint32_t *wg_total;                     // survivors per workgroup of the current level
     unsigned long long *wg_state;           // fused level kernel: (tag << 32 | survivors) per workgroup, never cleared
     int64_t *U;
+    const naqs::PollCtl *ctl;               // bounded waits of the look-back (naqs_poll.hpp)
 };
 
 __global__ void sample_init_kernel(SampleBufs b, int64_t n_samples) {
@@ -355,29 +356,32 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
 #pragma unroll
     for (int i = 0; i < SB / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
     if (wave == 0) {
-        if (lane == 0)
+        if (lane == 0 && !(naqs::poll_drop(b.ctl, naqs::POLL_SAMPLE_LOOKBACK) && blockIdx.x == 0))
             __hip_atomic_store(&b.wg_state[blockIdx.x], ((unsigned long long)tag << 32) | total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        // look back: lanes poll the words of the preceding workgroups, 64 at a time
+        // look back: lanes poll the words of the preceding workgroups, 64 at a time (bounded: naqs_poll.hpp)
         long long part = 0;
+        bool ok = true;
         for (int64_t j0 = 0; j0 < (int64_t)blockIdx.x; j0 += WAVE) {
             const int64_t j = j0 + lane;
             if (j < (int64_t)blockIdx.x) {
                 unsigned long long v;
-                do {
-                    v = __hip_atomic_load(&b.wg_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(v >> 32) != tag) __builtin_amdgcn_s_sleep(1);
-                } while ((uint32_t)(v >> 32) != tag);
+                ok = naqs::poll_tagged<1>(&b.wg_state[j], tag, v, b.ctl, naqs::POLL_SAMPLE_LOOKBACK, (uint32_t)j) && ok;
                 part += (long long)(uint32_t)v;
             }
         }
+        const bool all_ok = __all(ok);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
-        if (lane == 0) s_base = part;
+        if (lane == 0) s_base = all_ok ? part : -1;
     }
     __syncthreads();
     SMARK(4);
     const int64_t base = s_base;
+    if (base < 0) {                                        // a look-back wait ran out: no children are written, the rest of the call
+        if (threadIdx.x == 0) b.U[MAXP + 1] = 1;           // falls through (overflow flag) and the host reports NAQS_ERR_HIP
+        return;
+    }
     int64_t pos = base + before + (incl - mine);
     if (owner && mine) {
         const int nxt = cur ^ 1;
@@ -533,11 +537,12 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         }
         // last level of the launch: place among the other workgroups' children (look-back over their words)
         if (wave == 0) {
-            if (lane == 0)
+            if (lane == 0 && !(naqs::poll_drop(b.ctl, naqs::POLL_SAMPLE_LOOKBACK_MULTI) && blockIdx.x == 0))
                 __hip_atomic_store(&b.wg_state[blockIdx.x],
                                    ((unsigned long long)tag << 32) | (unsigned long long)(total | (mid_a << 9) | (mid_b << 16) | (mid_c << 23)),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long part = 0, part_a = 0, part_b = 0, part_c = 0;
+            bool ok = true;
             for (int64_t j0 = 0; j0 < (int64_t)blockIdx.x; j0 += 4 * WAVE) {
                 unsigned long long v[4];
 #pragma unroll
@@ -549,10 +554,8 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t j = j0 + q * WAVE + lane;
-                    while ((uint32_t)(v[q] >> 32) != tag) {
-                        __builtin_amdgcn_s_sleep(1);
-                        v[q] = __hip_atomic_load(&b.wg_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    if ((uint32_t)(v[q] >> 32) != tag)         // not there yet: poll (bounded, naqs_poll.hpp)
+                        ok = naqs::poll_tagged<1>(&b.wg_state[j], tag, v[q], b.ctl, naqs::POLL_SAMPLE_LOOKBACK_MULTI, (uint32_t)j) && ok;
                     const uint32_t x = (uint32_t)v[q];
                     part += (long long)(x & 0x1ffu);
                     part_a += (long long)((x >> 9) & 0x7fu);
@@ -567,10 +570,15 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
                 part_b += __shfl_down(part_b, off, 64);
                 part_c += __shfl_down(part_c, off, 64);
             }
-            if (lane == 0) { s_base[0] = part; s_base[1] = part_a; s_base[2] = part_b; s_base[3] = part_c; }
+            const bool all_ok = __all(ok);
+            if (lane == 0) { s_base[0] = all_ok ? part : -1; s_base[1] = part_a; s_base[2] = part_b; s_base[3] = part_c; }
         }
         __syncthreads();
         const int64_t base = s_base[0];
+        if (base < 0) {                                    // a look-back wait ran out (see sample_level_kernel)
+            if (tid == 0) b.U[MAXP + 1] = 1;
+            return;
+        }
         int64_t pos = base + before + (incl - mine);
         if (owner && mine) {
             // the OTHER half of the global ping-pong arrays, whatever NL: this launch's workgroups read their entry prefixes
@@ -851,6 +859,8 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
+    st = naqs::poll_check(net->device);            // an earlier launch's device-side wait that gave up (naqs_poll.hpp)
+    if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     const int64_t cap = max_unique;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -897,6 +907,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     b.wg_total = reinterpret_cast<uint32_t *>(base + o_wg);
     b.wg_state = reinterpret_cast<unsigned long long *>(base + o_ws);
     b.U = reinterpret_cast<int64_t *>(base + o_U);
+    b.ctl = net->ctl;
 
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     int64_t bound = 1;                                     // worst-case prefixes entering level n: min(4^n, cap)
