@@ -215,6 +215,61 @@ def cpu_baseline(ham_p, keys, log_psi, wf_args, budget_s=16.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# the training step (what real runs execute: PartialSamplingOptimizer.run, src/optimizer/energy.py:902-1056)
+# ------------------------------------------------------------------------------------------------------------------
+def train_step_probe(dev, molecule, steps=300, warmup=40, n_samples=1000000):
+    """ms per VMC training step of the published ansatz on `molecule` through the optimiser's own loop (sampler -> forward +
+    E_loc -> backward -> Adam -> re-pack; `naqs_vmc_run` / `naqs_vmc_step`), after `warmup` steps from a random
+    initialisation (seed 1): the regime of a run's first few hundred steps, tables of 10^3 .. 10^4 unique samples.
+    Beside it: the sampler's share (HIP events around its launches on every 10th step: first sampler launch .. the launch that
+    writes the weights) and the kernel launches per step (the library's own counter over the timed region)."""
+    import contextlib
+    import io
+    import torch
+    from naqs_amd import _lib
+    from naqs_amd.hilbert import Encoding, Hilbert
+    from naqs_amd.nade import NadeMasking
+    from naqs_amd.optimizer import LogKey, PartialSamplingOptimizer
+    from naqs_amd.system import load_molecule, set_global_seed
+    from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
+    lib = _lib.load_library()
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        set_global_seed(1)
+        mol, qh = load_molecule(os.path.join(ROOT, "tests", "golden", f"ham_{molecule}.npz"))
+        na, nb = mol.get_n_alpha_electrons(), mol.get_n_beta_electrons()
+        hil = Hilbert.get(N=mol.n_qubits, N_alpha=na, N_beta=nb, encoding=Encoding.SIGNED)
+        wf = NAQSComplex_NADE_orbitals(hil, qubit_ordering=-1, masking=NadeMasking.PARTIAL, use_amp_spin_sym=True,
+                                       use_phase_spin_sym=False, n_alpha_electrons=na, n_beta_electrons=nb, device=dev,
+                                       amp_hidden_size=[64], phase_hidden_size=[512, 512], aggregate_phase=False)
+        opt = PartialSamplingOptimizer(n_samples=n_samples, n_samples_max=1e12, n_unq_samples_min=1000, n_unq_samples_max=1e5,
+                                       wavefunction=wf, qubit_hamiltonian=qh, pre_compute_H=False, n_electrons=mol.n_electrons,
+                                       n_alpha_electrons=na, n_beta_electrons=nb, optimizer=torch.optim.Adam,
+                                       optimizer_args=[{'lr': 1e-3, 'betas': (0.9, 0.99), 'eps': 1e-15}, {'lr': 1e-2}],
+                                       save_loc=os.path.join(os.environ.get("TMPDIR", "/tmp"), f"naqs_bench_train_{molecule}_{os.getpid()}"),
+                                       seed=1, grad_clip_factor=None, log_exact_energy=False, pauli_hamiltonian_dtype=np.float64,
+                                       normalise_psi=True)
+        opt.run(warmup, output_freq=10 ** 9)
+        fused = wf.fused(need_phase=True)
+        path = ("naqs_vmc_run (the loop in the library)" if opt._can_onecall() and opt._can_run_in_library()
+                else "naqs_vmc_step per step" if opt._can_onecall() else "library calls per stage")
+        _lib.check(lib.naqs_net_prof_select(fused._h, 1), "naqs_net_prof_select")
+        fused.prof_enable(steps // PROF_STRIDE + 2, PROF_STRIDE)
+        torch.cuda.synchronize()
+        l0, t0 = lib.naqs_launch_count(), time.perf_counter()
+        opt.run(steps, output_freq=10 ** 9)
+        torch.cuda.synchronize()
+        dt, l1 = time.perf_counter() - t0, lib.naqs_launch_count()
+        s_ms, s_n = fused.prof_read()
+        fused.prof_enable(0)
+        _lib.check(lib.naqs_net_prof_select(fused._h, 0), "naqs_net_prof_select")
+    m = [x[1] for x in opt.log[LogKey.N_UNIQUE_SAMP][-steps:]]
+    return {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "sampler_us": s_ms / max(s_n, 1) * 1e3,
+            "launches_per_step": (l1 - l0) / steps, "unique_samples_mean": float(np.mean(m)), "unique_samples_last": int(m[-1]),
+            "n_samples": int(opt.n_samples), "E_loc_last": float(opt.log[LogKey.E_LOC][-1][1]), "path": path}
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` with N > 1 and no launcher in the environment
 # ------------------------------------------------------------------------------------------------------------------
 def launch_ranks(n, argv):
@@ -772,6 +827,16 @@ def worker(args):
             out["serial"] = serial
         if config4 is not None:
             out["config4_row_sharded"] = config4
+        if not args.no_train_step and world == 1:
+            # the real workload's step, so that the driver's line carries it (three molecules, ~1 s each)
+            ts = {"what": "one VMC training step (sampler + forward + E_loc + backward + Adam + re-pack) of the published ansatz "
+                          "through PartialSamplingOptimizer.run, after 40 steps from a random initialisation"}
+            for mol_ in ("N2", "H2O", "Li2O"):
+                try:
+                    ts[mol_] = train_step_probe(dev, mol_)
+                except Exception as ex:                                       # the headline must survive a secondary failure
+                    ts[mol_] = {"error": f"{type(ex).__name__}: {ex}"}
+            out["train_step"] = ts
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np, wf_args)
     finish(out)
@@ -893,6 +958,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-segment", action="store_true",
                     help="skip the one-batch-at-a-time segment that precedes the timed region (`serial`, `roofline.isolated`)")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the training-step probe that follows the timed region (`train_step`: ms per VMC step of N2 / H2O / Li2O)")
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the secondary row-sharded Li2O 50 000 table that follows the timed region (`config4_row_sharded`)")
     ap.add_argument("--emulate-world", default=None, metavar="W[,W...]",

@@ -242,6 +242,13 @@ int naqs_logpsi_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t M, const uint64_t
 int naqs_net_prof_enable(naqs_net_t *net, int max_records);
 int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches);
 int naqs_net_prof_stride(naqs_net_t *net, int stride);
+/* What the three calls above bracket: 0 (default) the log-psi kernel, 1 the sampler's launches of a training step (first
+ * sampler launch .. the launch that writes the weights; naqs_vmc_step / naqs_vmc_run) — bench.py's `train_step.sampler_us`.
+ * Selecting disarms the ring (enable it again afterwards). */
+int naqs_net_prof_select(naqs_net_t *net, int which);
+/* Kernel launches this library has issued in this process so far (all handles, all streams): bench.py's `launches per step`
+ * is the difference over a timed region divided by its steps.  No counterpart in the reference. */
+int64_t naqs_launch_count(void);
 /* Name of the log-psi kernel the most recent naqs_net_logpsi / naqs_logpsi_eloc / training forward launched. */
 int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len);
 
@@ -344,6 +351,58 @@ int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t 
                   float *logpsi_dev, double *eloc_dev, double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,
                   float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int64_t adam_step, int64_t info_host[3], void *stream);
+/* The LOOP of PartialSamplingOptimizer.run (src/optimizer/energy.py:975-1008) around naqs_vmc_step, with get_samples'
+ * adaptive sample count (energy.py:936-971) in C: n_steps training steps in ONE call, nothing returns to the caller's
+ * interpreter in between.  Per step: draw with the current n_samples (seed of the k-th sampling call of the run =
+ * splitmix64(seed_base + 0x9E3779B97F4A7C15 k), the rule of naqs_amd.wavefunction._next_sample_seed); while the library's
+ * naqs_vmc_step abandons the draw — tree overflow (MaxBatchSizeExceededError, nade.py:710-712), or fewer than
+ * n_unq_samples_min unique samples while the count may still grow — adapt n_samples x10 / /10 exactly as get_samples does and
+ * draw again, recording an event per adaptation (the caller prints the reference's messages from them); then forward + E_loc,
+ * backward, Adam, re-pack.  Everything a step leaves behind is what naqs_vmc_step leaves: the `*_dev` row buffers (max_unique =
+ * n_unq_samples_max rows) hold the LAST step's table on return.  Per-step records: (<E>, Var) -> ev_log_dev[i][2] and the four
+ * weighted sums -> sums_log_dev[i][4] (device, written in stream order), M / n_samples / host seconds since the call began ->
+ * the three host arrays.  Sampled-state tracking (energy.py:300): with ring_elems > 0 step i's keys are written at
+ * keys_dev + ring_off and ring_off advances by M; the run stops early (stop_reason 1) when the next step's max_unique keys would
+ * not fit, so that the caller can fold the buffer.  stop_reason: 0 all n_steps taken, 1 tracking buffer full, 2 event buffer
+ * full, 3 a draw was abandoned without a rule to adapt by (an error in the reference too).  steps_done steps were taken in any
+ * case; Adam's step count, the sampling-call counter, n_samples and ring_off are updated in place.
+ * Results are bit-identical to calling naqs_vmc_step step by step with the same seeds (tests/test_optimizer_gpu.py). */
+typedef struct naqs_vmc_event {
+    int64_t step;            /* 0-based index (within this call) of the step whose draw was being adapted */
+    int64_t n_unique;        /* unique samples of the abandoned draw (n_unq_samples_max + 1 for an overflow) */
+    int32_t overflow;        /* 1: the tree overflowed (the reference prints "MaxBatchSizeExceededError") */
+    int32_t action;          /* +1 n_samples x10, -1 n_samples /10, 0 unchanged (overflow right after an increase) */
+    int64_t n_samples;       /* n_samples after the adaptation */
+} naqs_vmc_event_t;
+typedef struct naqs_vmc_run_args {
+    /* sampling policy (in/out: n_samples, sample_calls) */
+    int64_t n_samples, n_samples_max, n_unq_samples_min, n_unq_samples_max;
+    uint64_t seed_base;
+    int64_t sample_calls;
+    /* Adam on the flat parameter vector (in/out: adam_step = updates applied so far) */
+    float *param_dev, *exp_avg_dev, *exp_avg_sq_dev, *grad_dev;
+    double lr, beta1, beta2, eps, weight_decay;
+    int64_t adam_step;
+    /* row buffers, n_unq_samples_max rows each (keys_dev: ring_elems elements when tracking) */
+    uint64_t *keys_dev;
+    int64_t ring_elems, ring_off;
+    int64_t *counts_dev;
+    float *probs_dev;
+    double *weights_dev;
+    float *logpsi_dev;
+    double *eloc_dev;
+    float *g_dev;
+    /* per-step records, n_steps entries each */
+    double *ev_log_dev, *sums_log_dev;
+    int64_t *m_log_host, *ns_log_host;
+    double *t_log_host;
+    naqs_vmc_event_t *events;
+    int64_t events_cap;
+    /* out */
+    int64_t n_events, steps_done, last_keys_off;
+    int32_t stop_reason, pad;
+} naqs_vmc_run_args_t;
+int naqs_vmc_run(naqs_net_t *net, naqs_ham_t *ham, int64_t n_steps, naqs_vmc_run_args_t *args, void *stream);
 /* One Adam step on a flat float32 parameter vector (device pointers): torch.optim.Adam's rule without amsgrad —
  * the reference's optimiser, experiments/_base.py:228 (betas (0.9, 0.99), eps 1e-15).  `step` is the 1-based count
  * after this update (bias corrections 1 - beta^step are formed on the host in float64). */

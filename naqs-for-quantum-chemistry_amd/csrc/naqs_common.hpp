@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdint>
 #include <cstdlib>
 
 #include "naqs_hip.h"
@@ -22,6 +24,14 @@ extern thread_local hipError_t g_last_hip;   // defined in naqs_hip.hip
     } while (0)
 
 constexpr int WAVE = 64;
+
+// every kernel launch of the library goes through this (naqs_launch_count(): bench.py's launches per training step)
+extern std::atomic<int64_t> g_launches;      // defined in naqs_hip.hip
+#define NAQS_KLAUNCH(...)                                                  \
+    do {                                                                   \
+        ::naqs::g_launches.fetch_add(1, std::memory_order_relaxed);        \
+        hipLaunchKernelGGL(__VA_ARGS__);                                   \
+    } while (0)
 
 struct DeviceGuard {
     int prev = -1;

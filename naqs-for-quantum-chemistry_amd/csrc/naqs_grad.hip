@@ -131,7 +131,7 @@ NAQS_API int naqs_adam_step(int64_t n, float *param_dev, const float *grad_dev, 
                             void *stream) {
     if (n < 0 || step < 1 || (n > 0 && (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev))) return NAQS_ERR_INVALID;
     if (n == 0) return NAQS_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, grad_dev,
+    NAQS_KLAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, grad_dev,
                        naqs::adam_args(param_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay, step));
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -145,7 +145,7 @@ NAQS_API int naqs_net_phase_inputs(naqs_net_t *net, int64_t M, const uint64_t *k
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     const int64_t total = M * 2 * (net->dims.P - 1);
-    hipLaunchKernelGGL(phase_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    NAQS_KLAUNCH(phase_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        net->dims, M, keys_dev, x_dev, occ_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -156,7 +156,7 @@ static int vmc_loss_grad_impl(int64_t M, const double *eloc_dev, const double *w
     if (M < 0 || (M > 0 && (!eloc_dev || !w_dev || !sums_dev || !g_dev))) return NAQS_ERR_INVALID;
     if (M == 0 && ev_dev == nullptr) return NAQS_OK;
     if (!sums_dev) return NAQS_ERR_INVALID;
-    hipLaunchKernelGGL(vmc_grad_kernel, dim3((unsigned)std::max<int64_t>(1, (M + 255) / 256)), dim3(256), 0,
+    NAQS_KLAUNCH(vmc_grad_kernel, dim3((unsigned)std::max<int64_t>(1, (M + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), M, reinterpret_cast<const double2 *>(eloc_dev), w_dev, sums_dev,
                        reinterpret_cast<float2 *>(g_dev), ev_dev);
     HIP_TRY(hipGetLastError());
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void shard_proof_kernel(const int64_t M, cons
 
 NAQS_API int naqs_shard_proof(int64_t M, const uint64_t *keys_dev, const double *sums_dev, double *ext_dev, void *stream) {
     if (M < 0 || (M > 0 && !keys_dev) || !sums_dev || !ext_dev) return NAQS_ERR_INVALID;
-    hipLaunchKernelGGL(shard_proof_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), M, keys_dev, sums_dev, ext_dev);
+    NAQS_KLAUNCH(shard_proof_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), M, keys_dev, sums_dev, ext_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -217,7 +217,7 @@ NAQS_API int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     st = naqs::net_amp_forward(net, M, keys_dev, s);
     if (st != NAQS_OK) return st;
-    hipLaunchKernelGGL(logamp_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch,
+    NAQS_KLAUNCH(logamp_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch,
                        logamp_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -250,14 +250,14 @@ int naqs::net_blocks_backward(naqs_net *net, const NetDims &d, const float *w, c
     }
     AmpSrc src;
     for (int n = 0; n < MAXP; ++n) src.off[n] = src_off[n] - src_off[0];         // relative to this set's first parameter
-    hipLaunchKernelGGL(amp_backward_kernel, dim3((unsigned)n_wg, (unsigned)d.P), dim3((unsigned)(NW * WAVE)), lds, s, d, w, M, keys_dev,
+    NAQS_KLAUNCH(amp_backward_kernel, dim3((unsigned)n_wg, (unsigned)d.P), dim3((unsigned)(NW * WAVE)), lds, s, d, w, M, keys_dev,
                        g_dev, gpart, stride, src, raw);
     HIP_TRY(hipGetLastError());
     if (defer) {
         defer->count = n_block_params; defer->stride = stride; defer->n_partials = n_wg; defer->partial = gpart;
         return NAQS_OK;
     }
-    hipLaunchKernelGGL(amp_reduce_kernel, dim3((unsigned)((n_block_params + 255) / 256)), dim3(256), 0, s, n_block_params, n_wg,
+    NAQS_KLAUNCH(amp_reduce_kernel, dim3((unsigned)((n_block_params + 255) / 256)), dim3(256), 0, s, n_block_params, n_wg,
                        stride, gpart, grad_dev);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -297,7 +297,7 @@ int naqs::net_blocks_backward2(naqs_net *net, int64_t M, const uint64_t *keys_de
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&amp_backward2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         net->grad2_attr_set = true;
     }
-    hipLaunchKernelGGL(amp_backward2_kernel, dim3((unsigned)jobs[0].n_partials, (unsigned)d0.P, 2), dim3((unsigned)((d0.Ha >> 4) * WAVE)), lds, s,
+    NAQS_KLAUNCH(amp_backward2_kernel, dim3((unsigned)jobs[0].n_partials, (unsigned)d0.P, 2), dim3((unsigned)((d0.Ha >> 4) * WAVE)), lds, s,
                        d0, net->d_w, const_cast<float *>(jobs[0].partial), src0, d1, net->d_wph, const_cast<float *>(jobs[1].partial), src1, M,
                        keys_dev, g_amp, g_ph, jobs[0].stride, g_stride);
     HIP_TRY(hipGetLastError());

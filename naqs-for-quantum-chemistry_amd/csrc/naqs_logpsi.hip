@@ -1883,6 +1883,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     DeviceGuard guard;
     (void)guard.init(net->device);
     (void)net->prof.enable(0);
+    (void)net->prof_samp.enable(0);
     if (net->d_w) (void)hipFree(net->d_w);
     if (net->d_wph) (void)hipFree(net->d_wph);
     if (net->d_wh) (void)hipFree(net->d_wh);
@@ -1930,7 +1931,7 @@ static int pack_blocks(const NetDims &d, const int64_t *src_off, float *dst, con
     AmpSrcOff so;
     for (int n = 0; n < MAXP; ++n) so.off[n] = src_off[n];
     const int total_max = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;
-    hipLaunchKernelGGL(pack_amp_kernel, dim3((total_max + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, dst);
+    NAQS_KLAUNCH(pack_amp_kernel, dim3((total_max + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, dst);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -1947,7 +1948,7 @@ static int pack_amp_both(naqs_net_t *net, const float *flat_dev, hipStream_t s) 
     const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
     const int total_max = std::max(d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8, frag);
     net->wamp_fresh = false;
-    hipLaunchKernelGGL(pack_amp_both_kernel, dim3((total_max + 255) / 256, d.P, 2), dim3(256), 0, s, flat_dev, d, so, net->d_w, net->d_wamp);
+    NAQS_KLAUNCH(pack_amp_both_kernel, dim3((total_max + 255) / 256, d.P, 2), dim3(256), 0, s, flat_dev, d, so, net->d_w, net->d_wamp);
     HIP_TRY(hipGetLastError());
     net->wamp_fresh = true;
     return NAQS_OK;
@@ -1959,7 +1960,7 @@ static int pack_amp_fragments(naqs_net_t *net, const float *flat_dev, hipStream_
     AmpSrcOff so;
     for (int n = 0; n < MAXP; ++n) so.off[n] = net->amp_src_off[n];
     const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;          // elements of one plane
-    hipLaunchKernelGGL(pack_amp_mfma_kernel, dim3((frag + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_wamp);
+    NAQS_KLAUNCH(pack_amp_mfma_kernel, dim3((frag + 255) / 256, d.P), dim3(256), 0, s, flat_dev, d, so, net->d_wamp);
     HIP_TRY(hipGetLastError());
     net->wamp_fresh = true;
     return NAQS_OK;
@@ -2023,22 +2024,22 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
     if (!split) {
         if (fmt == 2) {
             // weight maxima -> scales (device side; no host round trip)
-            hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
+            NAQS_KLAUNCH(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy_amp + gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
+        NAQS_KLAUNCH(pack_net_kernel, dim3(gx, gy_amp + gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp,
                            with_f32, fmt, raw, net->d_scales, 0, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = nullptr;
     } else if (mode == PACK_AMP) {
-        hipLaunchKernelGGL(pack_net_kernel, dim3(std::min(256, (amp_biggest + 255) / 256), gy_amp), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w,
+        NAQS_KLAUNCH(pack_net_kernel, dim3(std::min(256, (amp_biggest + 255) / 256), gy_amp), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w,
                            net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = flat_dev;
     } else if (mode == PACK_PHASE) {
-        hipLaunchKernelGGL(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
+        NAQS_KLAUNCH(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(pack_net_kernel, dim3(gx, gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp, with_f32,
+        NAQS_KLAUNCH(pack_net_kernel, dim3(gx, gy_phase), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w, net->d_wh, net->d_wamp, with_f32,
                            fmt, raw, net->d_scales, gy_amp, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = nullptr;
@@ -2081,7 +2082,7 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
             const int frag = ((d.Ha >> 4) + (d.Ha >> 5)) * 512;
             const int total_max = std::max(std::max(d.Ha, net->dph.Ha) * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8, net->d_wamp ? frag : 0);
             net->wamp_fresh = false;
-            hipLaunchKernelGGL(pack_amp2_kernel, dim3((total_max + 255) / 256, d.P, net->d_wamp ? 3 : 2), dim3(256), 0, s, flat_dev, d, so0, net->d_w,
+            NAQS_KLAUNCH(pack_amp2_kernel, dim3((total_max + 255) / 256, d.P, net->d_wamp ? 3 : 2), dim3(256), 0, s, flat_dev, d, so0, net->d_w,
                                net->dph, so1, net->d_wph, net->d_wamp);
             HIP_TRY(hipGetLastError());
             net->wamp_fresh = net->d_wamp != nullptr;
@@ -2108,7 +2109,7 @@ static int launch_amp_kernel(const NetDims &d, const float *w, int64_t M, const 
                              const ElocFeed &feed, int raw, hipStream_t s) {
     const size_t amp_lds = ((size_t)d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
     if (amp_lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, w, M,
+    NAQS_KLAUNCH(amp_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d.P), dim3(AMP_TILES * AMP_SPLIT * WAVE), amp_lds, s, d, w, M,
                        keys_dev, scratch, feed, raw);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -2132,9 +2133,9 @@ int naqs::net_amp_forward(naqs_net *net, int64_t M, const uint64_t *keys_dev, hi
         const int64_t waves = (M + AMPK_TG * 16 - 1) / (AMPK_TG * 16) * d.P;
         const unsigned grid = (unsigned)((waves + AMPK_WAVES - 1) / AMPK_WAVES);
         const size_t lds = 0;
-        if (d.Ha == 128) hipLaunchKernelGGL(amp_mfma_kernel<8>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
-        else if (d.Ha == 64) hipLaunchKernelGGL(amp_mfma_kernel<4>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
-        else hipLaunchKernelGGL(amp_mfma_kernel<2>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        if (d.Ha == 128) NAQS_KLAUNCH(amp_mfma_kernel<8>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        else if (d.Ha == 64) NAQS_KLAUNCH(amp_mfma_kernel<4>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
+        else NAQS_KLAUNCH(amp_mfma_kernel<2>, dim3(grid), dim3(AMPK_WAVES * 64), lds, s, d, net->d_wamp, M, keys_dev, net->d_scratch, feed ? *feed : none);
         HIP_TRY(hipGetLastError());
         return NAQS_OK;
     }
@@ -2155,7 +2156,7 @@ static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float 
         const NetDims &d0 = net->dims, &d1 = net->dph;
         const size_t lds = ((size_t)std::max(d0.Ha, d1.Ha) * ((2 * (d0.P - 1) + 1 + 5 + 3) & ~3) + 8) * sizeof(float);
         if (lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(amp2_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d0.P, 2),
+        NAQS_KLAUNCH(amp2_kernel, dim3((unsigned)((M + AMP_TILES * WAVE - 1) / (AMP_TILES * WAVE)), (unsigned)d0.P, 2),
                            dim3(AMP_TILES * AMP_SPLIT * WAVE), lds, s, d0, net->d_w, net->d_scratch, feed, d1, net->d_wph, s_ph, M, keys_dev);
         HIP_TRY(hipGetLastError());
     } else {
@@ -2172,7 +2173,7 @@ static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float 
         if (st != NAQS_OK) return st;
         if (prof) { st = net->prof.end(s); if (st != NAQS_OK) return st; }
     }
-    hipLaunchKernelGGL(agg_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch, s_ph,
+    NAQS_KLAUNCH(agg_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch, s_ph,
                        reinterpret_cast<float2 *>(logpsi_dev), feed);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -2271,13 +2272,13 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         const int flags = naqs::env_int("NAQS_WS_FLAGS", 0);
 #define NAQS_WS_LAUNCH(RB)                                                                                                              \
         do {                                                                                                                            \
-            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_ws<RB, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
-            else hipLaunchKernelGGL((phase_kernel_ws<RB, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_ws<RB, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            else NAQS_KLAUNCH((phase_kernel_ws<RB, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
         } while (0)
 #define NAQS_WS_LAUNCH_SPLIT(RB)                                                                                                        \
         do {                                                                                                                            \
-            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_ws<RB, true, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
-            else hipLaunchKernelGGL((phase_kernel_ws<RB, false, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_ws<RB, true, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            else NAQS_KLAUNCH((phase_kernel_ws<RB, false, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
         } while (0)
         if (ws_split) {
             switch (rb) {
@@ -2298,8 +2299,8 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
 #define NAQS_PH_LAUNCH(RB, FMT)                                                                                                         \
         do {                                                                                                                            \
-            if (save.x != nullptr) hipLaunchKernelGGL((phase_kernel_h<RB, true, FMT>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales); \
-            else hipLaunchKernelGGL((phase_kernel_h<RB, false, FMT>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales); \
+            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_h<RB, true, FMT>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales); \
+            else NAQS_KLAUNCH((phase_kernel_h<RB, false, FMT>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales); \
         } while (0)
         if (fmt == 2) {
             switch (rb) {
@@ -2319,10 +2320,10 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     } else {
         const size_t lds = (size_t)bm * d.ld * sizeof(float);
         switch (rb) {
-            case 1: hipLaunchKernelGGL(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
-            case 2: hipLaunchKernelGGL(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
-            case 3: hipLaunchKernelGGL(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
-            default: hipLaunchKernelGGL(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 1: NAQS_KLAUNCH(phase_kernel<1>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 2: NAQS_KLAUNCH(phase_kernel<2>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            case 3: NAQS_KLAUNCH(phase_kernel<3>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
+            default: NAQS_KLAUNCH(phase_kernel<4>, dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, M, keys_dev, net->d_scratch, out, feed); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -2372,7 +2373,18 @@ NAQS_API int naqs_net_prof_enable(naqs_net_t *net, int max_records) {
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
-    return net->prof.enable(max_records);
+    return (net->prof_which == 1 ? net->prof_samp : net->prof).enable(max_records);
+}
+
+NAQS_API int naqs_net_prof_select(naqs_net_t *net, int which) {
+    if (!net || which < 0 || which > 1) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    (void)net->prof.enable(0);
+    (void)net->prof_samp.enable(0);
+    net->prof_which = which;
+    return NAQS_OK;
 }
 
 NAQS_API int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *launches) {
@@ -2380,7 +2392,7 @@ NAQS_API int naqs_net_prof_read(naqs_net_t *net, double *total_ms, int64_t *laun
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
-    return net->prof.read(total_ms, launches);
+    return (net->prof_which == 1 ? net->prof_samp : net->prof).read(total_ms, launches);
 }
 
 NAQS_API int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len) {
@@ -2391,7 +2403,8 @@ NAQS_API int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len)
 
 NAQS_API int naqs_net_prof_stride(naqs_net_t *net, int stride) {
     if (!net || stride < 1) return NAQS_ERR_INVALID;
-    net->prof.stride = stride;
-    net->prof.tick = 0;
+    naqs::EventRing &ring = net->prof_which == 1 ? net->prof_samp : net->prof;
+    ring.stride = stride;
+    ring.tick = 0;
     return NAQS_OK;
 }

@@ -203,7 +203,9 @@ struct naqs_net {
     float *d_wb = nullptr;                  // phase weights row-major [N_pad64][K_pad64] per layer (backward GEMMs)
     bool have_wb = false;
     bool grad_attr_set = false, grad2_attr_set = false;
-    naqs::EventRing prof;
+    naqs::EventRing prof;                   // HIP-event brackets around the log-psi kernel (naqs_net_prof_*)
+    naqs::EventRing prof_samp;              // ... around the sampler's launches of a training step (naqs_net_prof_select(net, 1))
+    int prof_which = 0;
     char last_kernel[96] = {0};             // naqs_net_last_kernel
     int64_t *h_info = nullptr;              // mapped host words the sampler publishes (M, overflow, call sequence number) to
     int64_t *d_info_alias = nullptr;        // their device address

@@ -736,10 +736,13 @@ static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     int st0 = naqs::net_info_alloc(net);
     if (st0 != NAQS_OK) return st0;
     const int64_t seq = ++net->info_seq;
+    const bool prof = net->prof_samp.armed();              // (bench.py's train_step.sampler_us: every stride-th step)
+    if (prof) { int stp = net->prof_samp.begin(s); if (stp != NAQS_OK) return stp; }
     int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev,
                                     info_dev ? info_dev : net->d_info2, s,
                                     net->d_info_alias, seq);
     if (st != NAQS_OK) return st;
+    if (prof) { int stp = net->prof_samp.end(s); if (stp != NAQS_OK) return stp; }
     volatile int64_t *h = net->h_info;
     if (spin) {
         // bounded: after ~2 s of polling (a sampler call is < 1 ms) the wait falls back to the stream's own completion signal
@@ -792,7 +795,7 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
 struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; bool form_sums = false; };   // form_sums: `sums` is an OUTPUT of the seed kernel
 static int launch_grad_finish(const GradFinish &F, const GradWJobs &J, const float *cpart, const float *bpart, float *grad_dev,
                               const naqs::AdamArgs *adam, hipStream_t s) {
-    hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)((F.total + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
+    NAQS_KLAUNCH(grad_finish_kernel, dim3((unsigned)((F.total + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
                        adam ? *adam : naqs::AdamArgs{});
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
@@ -828,7 +831,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
             if (st != NAQS_OK) return st;
         } else {
             float *g_amp = net->d_scratch, *g_ph = net->d_scratch + M;
-            hipLaunchKernelGGL(split_g2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, reinterpret_cast<const float2 *>(g_dev),
+            NAQS_KLAUNCH(split_g2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, reinterpret_cast<const float2 *>(g_dev),
                                g_amp, g_ph);
             HIP_TRY(hipGetLastError());
             st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, s,
@@ -878,13 +881,13 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
                 HIP_TRY(hipMemsetAsync(net->d_sum_words, 0, 8 * sizeof(unsigned long long), s));
                 net->sums_seq = 1u;
             }
-            hipLaunchKernelGGL(vmc_seed_delta_kernel<true>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+            NAQS_KLAUNCH(vmc_seed_delta_kernel<true>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
                                reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, nullptr, reinterpret_cast<float2 *>(seeds->g_out),
                                g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
                                reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]),
                                const_cast<double *>(seeds->sums), net->d_sum_words, net->sums_seq, net->ctl);
         } else {
-            hipLaunchKernelGGL(vmc_seed_delta_kernel<false>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+            NAQS_KLAUNCH(vmc_seed_delta_kernel<false>, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
                                reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
                                g_amp, top, L.top_ld, seeds->ev, net->d_wb + wb_offset(net, H),
                                reinterpret_cast<const float *>(base + L.act[H - 1]), Kp, reinterpret_cast<float *>(base + L.delta[H - 1]),
@@ -894,13 +897,13 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         if (side) { HIP_TRY(hipEventRecord(net->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0)); }
     } else if (seeds != nullptr) {
         // (on the caller's stream, before the fork: both halves of the backward pass read what it writes)
-        hipLaunchKernelGGL(vmc_seed_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
+        NAQS_KLAUNCH(vmc_seed_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev,
                            reinterpret_cast<const double2 *>(seeds->eloc), seeds->w, seeds->sums, reinterpret_cast<float2 *>(seeds->g_out),
                            g_amp, top, L.top_ld, seeds->ev);
         HIP_TRY(hipGetLastError());
         if (side) { HIP_TRY(hipEventRecord(net->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0)); }
     } else {
-        hipLaunchKernelGGL(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
+        NAQS_KLAUNCH(split_g_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, sa, M, g2, g_amp);
         HIP_TRY(hipGetLastError());
     }
     // NAQS_TRAIN_MEGA=0: every piece its own launch
@@ -916,7 +919,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
 
     // phase block.  First the chain of deltas, output layer down (the critical path: each needs the one above) ...
     if (seeds == nullptr) {
-        hipLaunchKernelGGL(top_delta_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, g2, top, L.top_ld);
+        NAQS_KLAUNCH(top_delta_kernel, dim3((unsigned)((M * L.top_ld + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, g2, top, L.top_ld);
         HIP_TRY(hipGetLastError());
     }
     const float *dl[MAXL];                            // delta of linear layer l's output
@@ -937,7 +940,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         if (l == H && seed_delta) { dl[l - 1] = dnext; continue; }
         if (l == H) {                                     // below the output layer: one term per element, no GEMM
             const float2 *gsrc = seeds != nullptr ? reinterpret_cast<const float2 *>(seeds->g_out) : g2;
-            hipLaunchKernelGGL(delta_below_top_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, gsrc,
+            NAQS_KLAUNCH(delta_below_top_kernel, dim3((unsigned)((M * (Kp >> 2) + 255) / 256)), dim3(256), 0, s, d, M, keys_dev, gsrc,
                                net->d_wb + wb_offset(net, l), in, Kp, dnext);
             HIP_TRY(hipGetLastError());
             dl[l - 1] = dnext;
@@ -951,7 +954,7 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
             dl[l - 1] = dnext;
             continue;
         }
-        hipLaunchKernelGGL(grad_in_kernel, dim3((unsigned)((M + TB - 1) / TB), Kp / TB), dim3(256), 0, s, dl[l],
+        NAQS_KLAUNCH(grad_in_kernel, dim3((unsigned)((M + TB - 1) / TB), Kp / TB), dim3(256), 0, s, dl[l],
                            net->d_wb + wb_offset(net, l), in, M, Np, Kp, dnext);
         HIP_TRY(hipGetLastError());
         dl[l - 1] = dnext;
@@ -990,15 +993,15 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         if (lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
         A.fuse_w0 = w0_tiles && naqs::env_int("NAQS_FUSE_W0", 1) != 0 ? 1 : 0;
         A.w0 = W0Fuse{x, L.x_ld, cpart + J.cpart_off[0], bpart + J.bpart_off[0], J.Kp[0]};
-        hipLaunchKernelGGL(backward_mega_kernel, dim3((unsigned)(A.n_gin + A.n_amp + blocks_total - J.block_end[0])), dim3(256), lds, s,
+        NAQS_KLAUNCH(backward_mega_kernel, dim3((unsigned)(A.n_gin + A.n_amp + blocks_total - J.block_end[0])), dim3(256), lds, s,
                            A, d, J, amp_src);
         HIP_TRY(hipGetLastError());
         if (!A.fuse_w0) {
-            hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, s, J, M, cpart, bpart, 0);
+            NAQS_KLAUNCH(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, s, J, M, cpart, bpart, 0);
             HIP_TRY(hipGetLastError());
         }
     } else {
-        hipLaunchKernelGGL(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart, 0);
+        NAQS_KLAUNCH(grad_w_kernel, dim3((unsigned)blocks_total), dim3(256), 0, s, J, M, cpart, bpart, 0);
         HIP_TRY(hipGetLastError());
     }
     if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the amplitude blocks' partial sums are complete
@@ -1052,6 +1055,77 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
         if (st != NAQS_OK) return st;
     }
     info_host[2] = 1;
+    return NAQS_OK;
+}
+
+// The loop of PartialSamplingOptimizer.run (energy.py:975-1008) with get_samples' adaptive sample count (energy.py:936-971)
+// around naqs_vmc_step — the rules are naqs_amd.optimizer._onecall_step's, statement for statement, so that a run through this
+// call and a run through the per-step calls are the same sequence of launches with the same seeds.
+static inline uint64_t sample_seed(const uint64_t base, const int64_t call) {        // naqs_amd.wavefunction._next_sample_seed
+    uint64_t x = base + 0x9E3779B97F4A7C15ull * (uint64_t)call;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+NAQS_API int naqs_vmc_run(naqs_net_t *net, naqs_ham_t *ham, int64_t n_steps, naqs_vmc_run_args_t *a, void *stream) {
+    if (!net || !ham || !a || n_steps < 0) return NAQS_ERR_INVALID;
+    if (!a->param_dev || !a->exp_avg_dev || !a->exp_avg_sq_dev || !a->grad_dev || !a->keys_dev || !a->counts_dev || !a->probs_dev ||
+        !a->weights_dev || !a->logpsi_dev || !a->eloc_dev || !a->g_dev || !a->ev_log_dev || !a->sums_log_dev || !a->m_log_host ||
+        !a->ns_log_host || !a->t_log_host || (a->events_cap > 0 && !a->events))
+        return NAQS_ERR_INVALID;
+    if (a->n_unq_samples_max <= 0 || a->n_samples <= 0 || a->adam_step < 0 || a->ring_elems < 0 || a->ring_off < 0) return NAQS_ERR_INVALID;
+    if (a->ring_elems > 0 && a->ring_elems < a->n_unq_samples_max) return NAQS_ERR_INVALID;
+    a->n_events = a->steps_done = 0;
+    a->stop_reason = 0;
+    a->last_keys_off = a->ring_elems > 0 ? a->ring_off : 0;
+    const int64_t cap = a->n_unq_samples_max;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t i = 0; i < n_steps; ++i) {
+        if (a->ring_elems > 0 && a->ring_off + cap > a->ring_elems) { a->stop_reason = 1; break; }
+        uint64_t *keys = a->keys_dev + (a->ring_elems > 0 ? a->ring_off : 0);
+        int last_action = 0;
+        int64_t info[3] = {0, 0, 0};
+        for (;;) {
+            const bool free_ = a->n_samples != a->n_unq_samples_min && a->n_samples != a->n_samples_max;
+            const int64_t m_lo = (free_ && last_action >= 0) ? a->n_unq_samples_min : 0;
+            if (a->n_events >= a->events_cap) { a->stop_reason = 2; break; }       // (room for the event this draw may cause)
+            const uint64_t seed = sample_seed(a->seed_base, ++a->sample_calls);
+            const int st = naqs_vmc_step(net, ham, a->n_samples, seed, cap, m_lo, cap, keys, a->counts_dev, a->probs_dev, a->weights_dev,
+                                         a->logpsi_dev, a->eloc_dev, a->sums_log_dev + 4 * i, a->g_dev, a->ev_log_dev + 2 * i, a->grad_dev,
+                                         a->param_dev, a->exp_avg_dev, a->exp_avg_sq_dev, a->lr, a->beta1, a->beta2, a->eps,
+                                         a->weight_decay, a->adam_step + 1, info, stream);
+            if (st != NAQS_OK) return st;
+            if (info[2]) break;                            // taken
+            int64_t n_unq = info[0];
+            int action = 0;
+            const bool overflow = info[1] != 0;
+            if (overflow) { n_unq = cap + 1; action = -1; }
+            if (free_ || overflow) {
+                if (n_unq < a->n_unq_samples_min && last_action >= 0) {
+                    action = 1;
+                    a->n_samples = std::min<int64_t>(a->n_samples > a->n_samples_max / 10 ? a->n_samples_max : a->n_samples * 10, a->n_samples_max);
+                } else if (n_unq > cap && last_action <= 0) {
+                    action = -1;
+                    a->n_samples = std::max<int64_t>(a->n_samples / 10, a->n_unq_samples_min);
+                }
+            }
+            naqs_vmc_event_t &e = a->events[a->n_events++];
+            e.step = i; e.n_unique = n_unq; e.overflow = overflow ? 1 : 0; e.n_samples = a->n_samples;
+            // (overflow right after an increase: get_samples' rules leave n_samples alone and draw again)
+            e.action = (overflow && !(n_unq > cap && last_action <= 0)) ? 0 : action;
+            if (action == 0) { a->stop_reason = 3; break; }
+            last_action = action;
+        }
+        if (a->stop_reason != 0) break;
+        a->adam_step += 1;
+        a->m_log_host[i] = info[0];
+        a->ns_log_host[i] = a->n_samples;
+        a->t_log_host[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        a->last_keys_off = a->ring_elems > 0 ? a->ring_off : 0;
+        if (a->ring_elems > 0) a->ring_off += info[0];
+        a->steps_done = i + 1;
+    }
     return NAQS_OK;
 }
 

@@ -929,19 +929,19 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         if (big) {
             if (lds > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sample_head_kernel<1024, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, naqs::PackPhaseArgs{});
+            NAQS_KLAUNCH((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, naqs::PackPhaseArgs{});
         } else {
             // the phase share of the last update's re-pack, if a training step left it pending, rides in this launch
             naqs::PackPhaseArgs pk;
             st = naqs::net_take_pending_pack(net, s, &pk);
             if (st != NAQS_OK) return st;
-            hipLaunchKernelGGL((sample_head_kernel<256, 4>), dim3(1 + (unsigned)pk.n_wgs), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, pk);
+            NAQS_KLAUNCH((sample_head_kernel<256, 4>), dim3(1 + (unsigned)pk.n_wgs), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, pk);
         }
         HIP_TRY(hipGetLastError());
         n_first = hl;
         for (int n = 0; n < hl; ++n) bound *= 4;
     } else {
-        hipLaunchKernelGGL(sample_init_kernel, dim3(1), dim3(64), 0, s, b, n_samples);
+        NAQS_KLAUNCH(sample_init_kernel, dim3(1), dim3(64), 0, s, b, n_samples);
         HIP_TRY(hipGetLastError());
     }
     // one launch per level (expand + compaction with a look-back scan across workgroups) unless NAQS_SAMPLE_FUSED=0 or
@@ -990,13 +990,13 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
             const unsigned grid_m = (unsigned)((std::min(bound, cap) + E - 1) / E);
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
             if (nl == 4)
-                hipLaunchKernelGGL((sample_multi_kernel<4>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
+                NAQS_KLAUNCH((sample_multi_kernel<4>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                    keys_dev, counts_dev, probs_dev, wamp, early, seq);
             else if (nl == 3)
-                hipLaunchKernelGGL((sample_multi_kernel<3>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
+                NAQS_KLAUNCH((sample_multi_kernel<3>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                    keys_dev, counts_dev, probs_dev, wamp, early, seq);
             else
-                hipLaunchKernelGGL((sample_multi_kernel<2>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
+                NAQS_KLAUNCH((sample_multi_kernel<2>), dim3(grid_m), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                    keys_dev, counts_dev, probs_dev, wamp, early, seq);
             HIP_TRY(hipGetLastError());
             for (int i = 0; i < nl; ++i) bound = bound > cap ? bound : bound * 4;
@@ -1008,13 +1008,13 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         const unsigned grid_e = (unsigned)((std::min(bound, cap) + EXP_PARENTS - 1) / EXP_PARENTS);
         if (fused_levels && (int64_t)grid_e <= resident_wg) {
             const uint32_t tag = (net->samp_seq << 8) | (uint32_t)(n + 1);
-            hipLaunchKernelGGL(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
+            NAQS_KLAUNCH(sample_level_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, tag, cap, last,
                                keys_dev, counts_dev, probs_dev, clk_dev, wamp, early, seq);
             HIP_TRY(hipGetLastError());
         } else {
-            hipLaunchKernelGGL(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, wamp);
+            NAQS_KLAUNCH(sample_expand_kernel, dim3(grid_e), dim3(SB), lds, s, d, net->d_w, n, b, half, k0, k1, wamp);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, half, cap, last, keys_dev, counts_dev,
+            NAQS_KLAUNCH(sample_scatter_kernel, dim3(grid), dim3(SB), 0, s, d, n, b, half, cap, last, keys_dev, counts_dev,
                                probs_dev);
             HIP_TRY(hipGetLastError());
         }
@@ -1022,7 +1022,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         ++n;
         half ^= 1;
     }
-    hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
+    NAQS_KLAUNCH(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
                        weights_dev, early, seq, net->d_info_alias + 4);
     HIP_TRY(hipGetLastError());
     if (clk_dev) {

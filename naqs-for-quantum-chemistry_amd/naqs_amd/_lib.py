@@ -63,6 +63,9 @@ SIGNATURES = {
     "naqs_net_train_backward_vmc": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_step": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_i64] + [c_vp] * 13 +
                       [ctypes.c_double] * 5 + [c_i64, ctypes.POINTER(c_i64), c_vp]),
+    "naqs_vmc_run": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "naqs_net_prof_select": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "naqs_launch_count": (c_i64, []),
     "naqs_shard_proof": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_shard_sample_forward": (ctypes.c_int, [c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
@@ -89,6 +92,27 @@ class NetConfig(ctypes.Structure):
                 ("masking", ctypes.c_int32), ("use_amp_spin_sym", ctypes.c_int32), ("amp_hidden", ctypes.c_int32),
                 ("n_phase_hidden", ctypes.c_int32), ("phase_hidden", ctypes.c_int32 * NET_MAX_PHASE_LAYERS),
                 ("qubit2model", ctypes.c_int32 * (2 * NET_MAX_PAIRS)), ("aggregate_phase", ctypes.c_int32)]
+
+
+class VmcEvent(ctypes.Structure):
+    """naqs_vmc_event_t"""
+    _fields_ = [("step", c_i64), ("n_unique", c_i64), ("overflow", ctypes.c_int32), ("action", ctypes.c_int32), ("n_samples", c_i64)]
+
+
+class VmcRunArgs(ctypes.Structure):
+    """naqs_vmc_run_args_t"""
+    _fields_ = [("n_samples", c_i64), ("n_samples_max", c_i64), ("n_unq_samples_min", c_i64), ("n_unq_samples_max", c_i64),
+                ("seed_base", ctypes.c_uint64), ("sample_calls", c_i64),
+                ("param_dev", c_vp), ("exp_avg_dev", c_vp), ("exp_avg_sq_dev", c_vp), ("grad_dev", c_vp),
+                ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double), ("adam_step", c_i64),
+                ("keys_dev", c_vp), ("ring_elems", c_i64), ("ring_off", c_i64), ("counts_dev", c_vp), ("probs_dev", c_vp),
+                ("weights_dev", c_vp), ("logpsi_dev", c_vp), ("eloc_dev", c_vp), ("g_dev", c_vp),
+                ("ev_log_dev", c_vp), ("sums_log_dev", c_vp), ("m_log_host", ctypes.POINTER(c_i64)),
+                ("ns_log_host", ctypes.POINTER(c_i64)), ("t_log_host", ctypes.POINTER(ctypes.c_double)),
+                ("events", ctypes.POINTER(VmcEvent)), ("events_cap", c_i64),
+                ("n_events", c_i64), ("steps_done", c_i64), ("last_keys_off", c_i64), ("stop_reason", ctypes.c_int32),
+                ("pad", ctypes.c_int32)]
 
 
 class NaqsError(RuntimeError):

@@ -452,6 +452,77 @@ class FusedLogPsi:
             self._flat = adam._flat
         return True, m, False, (keys[:m], counts[:m], probs[:m], weights[:m], log_psi[:m], eloc[:m], sums, g[:m], ev)
 
+    @torch.no_grad()
+    def vmc_run(self, ham, n_steps, adam, n_samples, n_samples_max, n_unq_min, n_unq_max, seed_base, sample_calls, ring=None, ring_off=0):
+        """``n_steps`` training steps in ONE library call (``naqs_vmc_run``): the loop of ``PartialSamplingOptimizer.run``
+        with get_samples' adaptive sample count in C.  ``ring``: the optimiser's tracking buffer (int64; the keys of step i go to
+        ``ring[off:off + M]``) or None.  -> dict(steps, stop_reason, events [(step, n_unique, overflow, action, n_samples)],
+        n_samples, sample_calls, ring_off, M [steps], ns [steps], t [steps], ev [steps, 2], sums [steps, 4], and the last step's
+        table views keys / counts / probs / weights / log_psi / eloc / g)."""
+        dev, cap = self.device, int(n_unq_max)
+        ob = getattr(self, "_onecall_bufs", None)
+        if ob is None or ob[0] != cap:
+            ob = self._onecall_bufs = (cap, torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.float32, device=dev),
+                                       torch.empty(cap, dtype=torch.float64, device=dev), torch.empty((cap, 2), dtype=torch.float32, device=dev),
+                                       torch.empty((cap, 2), dtype=torch.float64, device=dev), torch.empty((cap, 2), dtype=torch.float32, device=dev))
+        _, counts, probs, weights, log_psi, eloc, g = ob
+        if ring is None:
+            kb = getattr(self, "_run_keys", None)
+            if kb is None or kb.numel() < cap:
+                kb = self._run_keys = torch.empty(cap, dtype=torch.int64, device=dev)
+            keys_buf, ring_elems = kb, 0
+        else:
+            if ring.dtype != torch.int64 or not ring.is_contiguous() or ring.numel() < cap:
+                raise ValueError("vmc_run: the tracking buffer must be a contiguous int64 tensor of at least max_unique elements")
+            keys_buf, ring_elems = ring, ring.numel()
+        if self._grad_flat is None:
+            self._grad_flat = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+            self._grad_views, off = [], 0
+            for p in self.wf.param_list():
+                n = p.numel()
+                self._grad_views.append(self._grad_flat[off:off + n].view(p.shape))
+                off += n
+        n = int(n_steps)
+        ev = torch.empty((max(n, 1), 2), dtype=torch.float64, device=dev)
+        sums = torch.empty((max(n, 1), 4), dtype=torch.float64, device=dev)
+        m_log, ns_log, t_log = (ctypes.c_int64 * max(n, 1))(), (ctypes.c_int64 * max(n, 1))(), (ctypes.c_double * max(n, 1))()
+        ev_cap = 64 + 4 * n
+        events = (_lib.VmcEvent * ev_cap)()
+        grp = next(g_ for g_ in adam.param_groups if g_['params'])
+        if adam._flat.numel() != self.n_params:
+            raise ValueError("vmc_run: the optimiser's flat vector is not this network's")
+        a = _lib.VmcRunArgs()
+        a.n_samples, a.n_samples_max = int(n_samples), int(n_samples_max)
+        a.n_unq_samples_min, a.n_unq_samples_max = int(n_unq_min), cap
+        a.seed_base, a.sample_calls = int(seed_base) & (2 ** 64 - 1), int(sample_calls)
+        a.param_dev, a.exp_avg_dev, a.exp_avg_sq_dev = adam._flat.data_ptr(), adam._m.data_ptr(), adam._v.data_ptr()
+        a.grad_dev = self._grad_flat.data_ptr()
+        a.lr, a.beta1, a.beta2 = float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1])
+        a.eps, a.weight_decay, a.adam_step = float(grp['eps']), float(grp['weight_decay']), int(adam._t)
+        a.keys_dev, a.ring_elems, a.ring_off = keys_buf.data_ptr(), int(ring_elems), int(ring_off)
+        a.counts_dev, a.probs_dev, a.weights_dev = counts.data_ptr(), probs.data_ptr(), weights.data_ptr()
+        a.logpsi_dev, a.eloc_dev, a.g_dev = log_psi.data_ptr(), eloc.data_ptr(), g.data_ptr()
+        a.ev_log_dev, a.sums_log_dev = ev.data_ptr(), sums.data_ptr()
+        a.m_log_host, a.ns_log_host, a.t_log_host = m_log, ns_log, t_log
+        a.events, a.events_cap = events, ev_cap
+        st = self._lib.naqs_vmc_run(self._h, ham._h, n, ctypes.byref(a), _stream_ptr(dev))
+        _lib.check(st, "naqs_vmc_run")
+        done = int(a.steps_done)
+        if done:
+            if not adam.state:
+                adam._bind_state()
+            adam._t = int(a.adam_step)
+            adam._opt_called = True
+            self._flat = adam._flat
+        m_last = int(m_log[done - 1]) if done else 0
+        k0 = int(a.last_keys_off)
+        return dict(steps=done, stop_reason=int(a.stop_reason),
+                    events=[(int(e.step), int(e.n_unique), bool(e.overflow), int(e.action), int(e.n_samples)) for e in events[:int(a.n_events)]],
+                    n_samples=int(a.n_samples), sample_calls=int(a.sample_calls), ring_off=int(a.ring_off),
+                    M=[int(x) for x in m_log[:done]], ns=[int(x) for x in ns_log[:done]], t=[float(x) for x in t_log[:done]],
+                    ev=ev, sums=sums, keys=keys_buf[k0:k0 + m_last], counts=counts[:m_last], probs=probs[:m_last],
+                    weights=weights[:m_last], log_psi=log_psi[:m_last], eloc=eloc[:m_last], g=g[:m_last])
+
     # ---- the row-sharded step (world > 1): four library calls, the three collectives between them (include/naqs_hip.h) ----
     def _step_buffers(self, cap, world, keys_out=None):
         """Per-handle buffers of the sharded step, allocated once per (cap, world): the step's outputs are views of them and

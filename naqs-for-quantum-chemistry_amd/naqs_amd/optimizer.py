@@ -963,31 +963,94 @@ class PartialSamplingOptimizer(OptimizerBase):
         if save_final:
             self.save(quiet=False)
 
+    def _can_run_in_library(self):
+        """The loop itself in C (``naqs_vmc_run``): the one-call step without an LR scheduler stepping in between
+        (NAQS_TRAIN_RUN=0: one library call per step, as before)."""
+        return self.scheduler is None and os.environ.get("NAQS_TRAIN_RUN", "1") == "1"
+
+    def _library_run(self, n_steps):
+        """Up to ``n_steps`` steps of `run` through ``FusedLogPsi.vmc_run`` — sampling with the adaptive sample count
+        (energy.py:936-971), E_loc, backward, Adam, re-pack per step, nothing returning to the interpreter in between.  Books
+        the steps (log entries, counters, tracking buffer) exactly as the per-step loop does and prints the reference's
+        adaptation messages.  -> (counts, weights, steps taken) of the LAST step; fewer steps than asked when the tracking
+        buffer has to be folded first."""
+        wf = self.wavefunction
+        fused = wf.fused(need_phase=True)
+        cap = int(self.n_unq_samples_max)
+        ring, off = None, 0
+        if self.track_sampled_idxs:
+            self._sampled_ring_slot(cap)                   # (creates the buffer / folds it when the next slot would not fit)
+            ring, off = self._sampled_ring, self._sampled_ring_off
+        base = int(self.generator.initial_seed()) if self.generator is not None else int(torch.initial_seed())
+        t0, run_time0, epoch0 = time.time(), self.run_time, self.n_epochs
+        res = fused.vmc_run(self.pauli_hamiltonian, n_steps, self.optimizer, self.n_samples, int(self.n_samples_max),
+                            int(self.n_unq_samples_min), cap, base, wf._sample_calls, ring=ring, ring_off=off)
+        for step, n_unq, overflow, action, n_samples in res["events"]:
+            if overflow:
+                print("MaxBatchSizeExceededError")
+            if action > 0:
+                print(f"\t...{n_unq} unique samples generated --> increasing batch size to "
+                      f"{n_samples / 1e6:.1f}M at epoch {epoch0 + step}.")
+            elif action < 0:
+                print(f"\t...{n_unq} unique samples generated --> decreasing batch size to "
+                      f"{n_samples / 1e6:.1f}M at epoch {epoch0 + step}.")
+        self.n_samples = res["n_samples"]
+        wf._sample_calls = res["sample_calls"]
+        if self.track_sampled_idxs:
+            self._sampled_ring_off = res["ring_off"]
+        if res["stop_reason"] == 3:
+            raise RuntimeError(f"VMC step abandoned without a reason to re-sample (M={res['events'][-1][1] if res['events'] else '?'})")
+        done = res["steps"]
+        for i in range(done):
+            self.n_steps += 1
+            self.n_epochs += 1
+            self._pending_log.append((self.n_steps, res["ev"][i], res["M"][i], run_time0 + res["t"][i]))
+        self.run_time = run_time0 + (time.time() - t0)
+        if done:
+            wf.fused_repacked()
+            self._last_M = res["M"][-1]
+            self._sample_keys, self._sample_weights, self._prefused = res["keys"], res["weights"], None
+            self._loss_terms, self._last_loss = (res["g"], res["log_psi"]), None
+        return res["counts"], res["weights"], done
+
     def _run_epochs(self, n_epochs, save_freq, output_freq, run_time_at_last_log, steps_at_last_log):
-        for _ in range(n_epochs):
+        remaining = n_epochs
+        while remaining > 0:
             t0 = time.time()
             self._choose_dist_mode()                 # multi-GPU: replicate or shard this step (resets the cache on a switch)
             onecall = getattr(self, "_onecall_cached", None)
             if onecall is None:
                 onecall = self._onecall_cached = (2 if self._can_shard_onecall() else (1 if self._can_onecall() else 0))
-            if onecall == 2:
-                counts, weights, ev = self._sharded_onecall_step()
-            elif onecall:
-                counts, weights, ev = self._onecall_step()
+            if onecall == 1 and self._can_run_in_library():
+                # as many steps as fit before the loop has something to do itself: the first epoch's line, an output line,
+                # a checkpoint
+                chunk = min(remaining, 1 if self.n_epochs == 0 else output_freq - self.n_epochs % output_freq)
+                if save_freq is not None and save_freq > 0:
+                    chunk = min(chunk, save_freq - self.n_epochs % save_freq)
+                counts, weights, done = self._library_run(chunk)
+                remaining -= done
+                if done == 0:
+                    continue                         # (the tracking buffer was full: folded on the way back in)
             else:
-                states, counts, probs = self.get_samples(lazy=True)
-                weights = self._sample_weights                                            # counts / sum(counts), energy.py:993
-                keys = self._sample_keys                                                  # = hilbert.state2idx(states)
-                # <E>, Var stay on the device until they are printed or saved: reading them here would drain the queue
-                # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU
-                ev = self._SGD_step(states, keys, None, sample_weights=weights, lazy=True)
-            self.n_steps += 1
-            self._last_M = len(weights)
-            if self._dist_mode == "replicated":
-                self._replica_proof(self._sample_keys)
-            self.run_time += time.time() - t0
-            self._pending_log.append((self.n_steps, ev, len(weights), self.run_time))
-            self.n_epochs += 1
+                if onecall == 2:
+                    counts, weights, ev = self._sharded_onecall_step()
+                elif onecall:
+                    counts, weights, ev = self._onecall_step()
+                else:
+                    states, counts, probs = self.get_samples(lazy=True)
+                    weights = self._sample_weights                                            # counts / sum(counts), energy.py:993
+                    keys = self._sample_keys                                                  # = hilbert.state2idx(states)
+                    # <E>, Var stay on the device until they are printed or saved: reading them here would drain the queue
+                    # every step, and the ~25 launches of the next sampling call would be issued to an idle GPU
+                    ev = self._SGD_step(states, keys, None, sample_weights=weights, lazy=True)
+                self.n_steps += 1
+                self._last_M = len(weights)
+                if self._dist_mode == "replicated":
+                    self._replica_proof(self._sample_keys)
+                self.run_time += time.time() - t0
+                self._pending_log.append((self.n_steps, ev, len(weights), self.run_time))
+                self.n_epochs += 1
+                remaining -= 1
             if (self.n_epochs % output_freq == 0) or (self.n_epochs == 1):
                 self._flush_log()
                 var = self.log[LogKey.E_LOC_VAR][-1][1]

@@ -298,6 +298,42 @@ def test_one_call_training_step_equals_the_step_by_step_loop(mol, kw, tmp_path, 
         assert a["msgs"], "the adaptive sample count was meant to act in this case"
 
 
+@pytest.mark.parametrize("mol,kw", [("N2", {}), ("LiH", dict(n_samples=100, n_unq_samples_min=20)),
+                                     ("H2O", dict(n_samples=1000000, n_unq_samples_max=120, n_unq_samples_min=5))])
+def test_training_loop_in_the_library_equals_the_step_by_step_loop(mol, kw, tmp_path, monkeypatch, capsys):
+    """``naqs_vmc_run`` — the loop of PartialSamplingOptimizer.run (energy.py:975-1008) with get_samples' adaptive sample
+    count (energy.py:936-971) in C, chunks of steps between the loop's own events (first line, output lines, checkpoints,
+    folds of the tracking buffer) — against one ``naqs_vmc_step`` per step: same seeds, same launches, so energies, sample
+    counts, messages, sampled-state counts and parameters agree bit for bit."""
+    from naqs_amd.optimizer import LogKey
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NAQS_TRAIN_RUN", mode)
+        z, hil, wf, opt = make_opt_gpu(mol, tmp_path / mode, **kw)
+        assert opt._can_onecall() and opt._can_run_in_library() == (mode == "1")
+        opt.sampled_ring_elems = 1          # (the smallest tracking buffer: the library run stops to let it be folded)
+        opt.run(n_epochs=25, save_freq=7, save_final=False, output_freq=10)
+        opt.run(n_epochs=6, save_freq=None, save_final=False, output_freq=4)
+        out = capsys.readouterr().out
+        runs[mode] = dict(e=np.array(opt.log[LogKey.E_LOC]), v=np.array(opt.log[LogKey.E_LOC_VAR]),
+                          n=np.array(opt.log[LogKey.N_UNIQUE_SAMP]), p=wf.flatten_parameters().clone(), ns=opt.n_samples,
+                          t=opt.optimizer._t, idx=dict(opt.sampled_idxs), calls=wf._sample_calls,
+                          msgs=[l for l in out.splitlines() if "unique samples generated" in l or "MaxBatch" in l],
+                          lines=[l.split(": <E>")[0] for l in out.splitlines() if l.startswith("Epoch ")],
+                          sd=opt.optimizer.state_dict()['state'][0]['exp_avg'].clone(), loss=float(opt.last_loss),
+                          saved=sorted(f for f in os.listdir(tmp_path / mode) if f.startswith("opt_")),
+                          keys=opt._sample_keys.clone(), w=opt._sample_weights.clone())
+    a, b = runs["1"], runs["0"]
+    assert np.array_equal(a["e"], b["e"]) and np.array_equal(a["v"], b["v"]) and np.array_equal(a["n"], b["n"])
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["sd"], b["sd"])
+    assert torch.equal(a["keys"], b["keys"]) and torch.equal(a["w"], b["w"])
+    for k in ("ns", "t", "idx", "calls", "msgs", "lines", "loss", "saved"):
+        assert a[k] == b[k], k
+    assert a["t"] == 31 and np.isfinite(a["e"]).all() and len(a["lines"]) == 4      # epochs 1, 10, 20 and 28 (= 25 + 3: every 4th of the second run)
+    if kw:
+        assert a["msgs"], "the adaptive sample count was meant to act in this case"
+
+
 def test_training_run_is_reproducible_at_large_tables(tmp_path, monkeypatch):
     """Two identically seeded Li2O runs (tables of 10^3 .. 3 x 10^4 unique samples in the first steps: sampler launches with
     more workgroups than are resident at once) give the same energies and sample counts bit for bit.  A two-level sampler

@@ -5,7 +5,7 @@ Collect on the GPU box (separate passes, as MI355X_MICROARCH.md prescribes — F
 one pass; never combined with sys/hip traces; the program itself directly after `--`):
 
     cd /tmp && export TMPDIR=/tmp        # R = the repo
-    B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --pipeline 1"
+    B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --no-train-step --pipeline 1"
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o bench -- $B
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o bench -- $B
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES \

@@ -17,11 +17,11 @@ timeout 600 python tools/scaling_model.py tests/golden/ham_N2.npz 300 $G/train_s
 NAQS_SCALING_PUBLISHED=1 NAQS_SCALING_TRAIN_FIRST=30 timeout 600 python tools/scaling_model.py tests/golden/ham_Li2O.npz 60 $G/train_scaling_li2o_pub.json > $G/train_scaling_li2o_pub.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # (--no-serial-segment: the 2000 one-batch-at-a-time steps that precede the timed region would otherwise dominate the averages)
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_pipeline2 -o bench -- python3 $R/bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-config4 --no-serial-segment > $G/rocprof_pipeline2.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_serial -o bench -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-config4 --pipeline 1 > $G/rocprof_serial.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_li2o -o bench -- python3 $R/bench.py --shard rows --molecule Li2O --samples 50000 --steps 50 --warmup 5 --no-cpu-baseline --pipeline 1 > $G/rocprof_li2o.log 2>&1
-B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --pipeline 1"
-L="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --shard rows --molecule Li2O --samples 50000 --pipeline 1"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_pipeline2 -o bench -- python3 $R/bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-config4 --no-train-step --no-serial-segment > $G/rocprof_pipeline2.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_serial -o bench -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-config4 --no-train-step --pipeline 1 > $G/rocprof_serial.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_li2o -o bench -- python3 $R/bench.py --shard rows --molecule Li2O --samples 50000 --steps 50 --warmup 5 --no-cpu-baseline --no-train-step --pipeline 1 > $G/rocprof_li2o.log 2>&1
+B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --no-train-step --pipeline 1"
+L="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-step --shard rows --molecule Li2O --samples 50000 --pipeline 1"
 ISSUE="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
 pmc() { d=$G/$1; shift; timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $d -o bench -- "$@" > $d.log 2>&1; echo $HASH > $d/source_hash.txt; }
 PMC="FETCH_SIZE" pmc pmc_fetch $B

@@ -2,7 +2,7 @@
 # vector-memory-path counters of the log-psi kernel on the headline workload, one batch at a time (separate passes per block)
 R=$PWD; G=$R/gpurun_out/pmc_phase; rm -rf $G; mkdir -p $G
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --pipeline 1 --no-serial-segment"
+B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4 --no-train-step --pipeline 1 --no-serial-segment"
 pass() { n=$1; shift; timeout 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $G/$n -o bench -- $B > $G/$n.log 2>&1 || echo "pass $n failed"; }
 pass ta1 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE
 pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
