@@ -227,6 +227,15 @@ __device__ __forceinline__ int64_t group_bcast(int64_t v, int jj) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+#if defined(NAQS_SAMPLE_STATS)
+// developer build (tools/sample_regime_stats.py): per binomial_group call of a wave, which regimes its lanes were in (0 none,
+// 1 inversion only, 2 BTRS only, 3 both — the two loops then run one after the other), how many BTRS rounds and exact
+// acceptance tests it went through and how many steps its longest inversion search took.  Counts only: cycle stamps around
+// these regions measure the counters' own atomics (whichever region first waits for outstanding memory operations pays for
+// them) — cycles per regime come from tools/binomial_probe.cpp.
+extern __device__ unsigned long long g_sample_stats[2][4][4];      // [G == 4 ? 0 : 1][class][calls, rounds, exact tests, steps of the longest inversion]
+#endif
+
 template <int G>
 __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, const double p, const uint32_t k0,
                                                   const uint32_t k1, const uint32_t c0, const uint32_t c1) {
@@ -238,15 +247,26 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
     const bool flip = p > 0.5;
     const double pp = flip ? 1.0 - p : p, nd = (double)n;
     const bool inv = need && nd * pp < 10.0, bt = need && !inv;
+#if defined(NAQS_SAMPLE_STATS)
+    const int stat_cls = (__ballot(inv) != 0ull ? 1 : 0) | (__ballot(bt) != 0ull ? 2 : 0);
+    unsigned long long stat_rounds = 0, stat_exact = 0;
+#endif
     double k = 0.0;
     if (inv) {                                                  // short sequential search: every lane of the group runs it
         RngStream g{k0, k1, c0, c1, 0u, 0u};
         k = binomial_inversion(nd, pp, g);
     }
+#if defined(NAQS_SAMPLE_STATS)
+    int stat_steps = inv ? (int)k : 0;
+    for (int o = 32; o > 0; o >>= 1) stat_steps = max(stat_steps, __shfl_xor(stat_steps, o, 64));
+#endif
     Btrs t;
     if (bt) btrs_setup(t, nd, pp);
     bool pending = bt;
     for (int round = 0; round < BTRS_MAX_ATTEMPTS / G && __ballot(pending) != 0ull; ++round) {
+#if defined(NAQS_SAMPLE_STATS)
+        ++stat_rounds;
+#endif
         // my attempt, classified: 0 accepted by the squeeze, 1 needs the exact test, 2 rejected (out of range) / nothing
         int cls = 2;
         double us = 0.5, v = 0.0, kk = 0.0;
@@ -264,6 +284,9 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
             int cls_j = group_bcast<G>(cls, jj);
             const bool exact = pending && cls_j == 1;           // uniform within a group
             if (__ballot(exact) != 0ull) {
+#if defined(NAQS_SAMPLE_STATS)
+                ++stat_exact;
+#endif
                 if (exact) {
                     const double us_j = group_bcast<G>(us, jj), v_j = group_bcast<G>(v, jj), k_j = group_bcast<G>(kk, jj);
                     const double alpha = (2.83 + 5.1 * t.rb) * t.spq;
@@ -298,6 +321,15 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
         }
     }
     if (pending) k = t.m;                                       // unreachable in practice
+#if defined(NAQS_SAMPLE_STATS)
+    if (lane == 0) {
+        unsigned long long *st = g_sample_stats[G == 4 ? 0 : 1][stat_cls];
+        atomicAdd(&st[0], 1ull);
+        atomicAdd(&st[1], stat_rounds);
+        atomicAdd(&st[2], stat_exact);
+        atomicAdd(&st[3], (unsigned long long)stat_steps);
+    }
+#endif
     if (!need) return fixed;
     int64_t ki = (int64_t)k;
     ki = ki < 0 ? 0 : (ki > n ? n : ki);

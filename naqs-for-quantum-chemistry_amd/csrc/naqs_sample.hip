@@ -32,6 +32,16 @@
 #include "naqs_rng.hpp"
 #include "naqs_pack.hpp"
 
+#if defined(NAQS_SAMPLE_STATS)
+namespace naqs { __device__ unsigned long long g_sample_stats[2][4][4]; }
+// (developer build only) -> out[32]: [G == 4 ? 0 : 1][class][calls, BTRS rounds, exact tests, steps of the longest inversion], and reset
+extern "C" __attribute__((visibility("default"))) int naqs_debug_sample_stats(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(naqs::g_sample_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[32] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(naqs::g_sample_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 using naqs::MAXP;
@@ -165,10 +175,10 @@ __device__ __forceinline__ void cand_jobs(const NetDims &d, const naqs::ushort_t
 // first-level binomial of the multinomial split together and its two halves the two independent second-level ones.  Weights of pair n are in s_w (staged and
 // synchronised by the caller).  On return lane q == 0 holds the children counts (un-physical ones zeroed, nade.py:695)
 // and the float32 conditional probabilities p[c] = exp(log-amp)^2 (nade.py:673).
-__device__ __forceinline__ void expand_quad(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
-                                            const int64_t cnt, const uint32_t k0, const uint32_t k1, int64_t (&out)[4],
-                                            float (&p)[4], long long *clk = nullptr,
-                                            const naqs::ushort_t *__restrict__ wamp = nullptr) {
+// (expand_probs: the first half — block MLP, conditional, probabilities and physical mask; expand_quad: both halves)
+__device__ __forceinline__ void expand_probs(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
+                                             float (&p)[4], bool (&phys)[4], long long *clk = nullptr,
+                                             const naqs::ushort_t *__restrict__ wamp = nullptr) {
     const int q = threadIdx.x & 3;
     const int nin = n == 0 ? 1 : 2 * n;
     const int S = (nin + 1 + 5 + 3) & ~3;
@@ -221,11 +231,18 @@ __device__ __forceinline__ void expand_quad(const NetDims &d, const float *__res
 #pragma unroll
         for (int c = 0; c < 5; ++c) t[c] = (c < d.n_out_amp ? b2[c] : 0.0f) + quad_sum(o[c]);
     }
-    bool phys[4];
     probs_from_outputs(d, n, t, abits, bbits, p, phys);
     if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) clk[1] = clock64();     // conditional + probabilities done
+}
+__device__ __forceinline__ void expand_quad(const NetDims &d, const float *__restrict__ s_w, const int n, const uint32_t ab,
+                                            const int64_t cnt, const uint32_t k0, const uint32_t k1, int64_t (&out)[4],
+                                            float (&p)[4], long long *clk = nullptr,
+                                            const naqs::ushort_t *__restrict__ wamp = nullptr) {
+    bool phys[4];
+    expand_probs(d, s_w, n, ab, p, phys, clk, wamp);
     split_quad(n, ab, cnt, k0, k1, p, phys, out, clk);
 }
+
 
 // the second half of expand_quad: the count's multinomial split given the conditional probabilities and the physical mask
 __device__ __forceinline__ void split_quad(const int n, const uint32_t ab, const int64_t cnt, const uint32_t k0, const uint32_t k1,
@@ -463,6 +480,10 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
     const int entries = (int)min((int64_t)E, U - (int64_t)blockIdx.x * E);
     int U_loc = entries;
     uint32_t mid_a = 0u, mid_b = 0u, mid_c = 0u;           // this workgroup's prefixes at the launch's 2nd (3rd, 4th) level
+    // (not unrolled, and ONE call site of the binomial draws per level: the level body with its float64 generator inlined is
+    // ~5 k instructions; NL unrolled copies with two call sites each were 190 KB of straight-line code for NL = 4, and no
+    // instruction cache holds that — every level of every workgroup streamed its code from L2.  N2 step -6 us, same samples)
+#pragma unroll 1
     for (int li = 0; li < NL; ++li) {
         const int lev = n + li;
         const bool active = u < U_loc;
@@ -485,21 +506,23 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         __syncthreads();
         int64_t out[4] = {0, 0, 0, 0};
         float p[4] = {0.f, 0.f, 0.f, 0.f};
+        bool phys[4] = {false, false, false, false};
+        bool draws = true;                                 // (wave-uniform)
         if (ahead && wave > 0 && (E << (2 * li)) <= 16) {
             // this level's prefixes fill at most wave 0: the other waves evaluate the later levels' candidates meanwhile
             cand_jobs(d, wamp, n, NL, E, entries, s_entry, s_w + (size_t)wave * 128, s_cp, s_cphys, wave, SB / WAVE, li);
+            draws = false;
         } else if (ahead && li > 0) {
-            bool phys[4] = {false, false, false, false};
             if (active) {
                 const f32x4 pv = s_cp[(li - 1) * 64 + cand];
                 const uint32_t pm = s_cphys[(li - 1) * 64 + cand];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { p[c] = pv[c]; phys[c] = ((pm >> c) & 1u) != 0u; }
             }
-            split_quad(lev, ab, cnt, k0, k1, p, phys, out, nullptr);
         } else {
-            expand_quad(d, s_w, lev, ab, cnt, k0, k1, out, p, nullptr, wamp);
+            expand_probs(d, s_w, lev, ab, p, phys, nullptr, wamp);
         }
+        if (draws) split_quad(lev, ab, cnt, k0, k1, p, phys, out, nullptr);
         const bool owner = active && (tid & 3) == 0;
         uint32_t mine = 0;
         if (owner)
@@ -665,7 +688,8 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         if (AHEAD_OK) s_cand[0][0] = 0;
     }
     int U = 1;
-    for (int n = 0; n < HL; ++n) {
+#pragma unroll 1
+    for (int n = 0; n < HL; ++n) {                         // (not unrolled, one call site of the draws: see sample_multi_kernel)
         const int cur = n & 1, nxt = cur ^ 1;
         __syncthreads();                                   // previous level's LDS writes / everyone done with s_w
         if (wamp == nullptr) stage_pair_weights(d, w, n, s_w, HT);
@@ -677,20 +701,22 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         __syncthreads();
         int64_t out[4] = {0, 0, 0, 0};
         float p[4] = {0.f, 0.f, 0.f, 0.f};
+        bool phys[4] = {false, false, false, false};
+        bool draws = true;                                 // (wave-uniform)
         if (ahead && wave > 0 && n < 3) {                  // (levels 0-2 have at most 16 prefixes: wave 0)
             cand_jobs(d, wamp, 0, HL, 1, 1, s_entry, s_w + (size_t)wave * 128, s_cp, s_cphys, wave, HT / WAVE, n);
+            draws = false;
         } else if (ahead && n > 0) {
-            bool phys[4] = {false, false, false, false};
             if (active) {
                 const f32x4 pv = s_cp[(n - 1) * 64 + cand];
                 const uint32_t pm = s_cphys[(n - 1) * 64 + cand];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { p[c] = pv[c]; phys[c] = ((pm >> c) & 1u) != 0u; }
             }
-            split_quad(n, ab, cnt, k0, k1, p, phys, out, nullptr);
         } else {
-            expand_quad(d, s_w, n, ab, cnt, k0, k1, out, p, nullptr, wamp);
+            expand_probs(d, s_w, n, ab, p, phys, nullptr, wamp);
         }
+        if (draws) split_quad(n, ab, cnt, k0, k1, p, phys, out, nullptr);
         uint32_t mine = 0;                                 // survivors of this quad's prefix, held by its first lane
         if (active && q == 0)
 #pragma unroll

@@ -41,6 +41,27 @@ int main() {
     run<4>("BTRS, n = 1e12, p = 0.37", big, half);
     run<4>("BTRS, n = 5000, p = 0.37", mid, half);
     run<4>("inversion, n = 40, p = 0.05", small, tiny);
+    std::vector<int64_t> near10(16, 190), mixed10(16);
+    for (int i = 0; i < 16; ++i) mixed10[i] = (i & 1) ? 1000000000ll : 190;
+    run<4>("inversion, n = 190, p = 0.05 (np 9.5)", near10, tiny);
+    run<4>("mixed BTRS / inversion np 9.5", mixed10, tiny);
+    run<2>("inversion, n = 190, p = 0.05 (np 9.5)", near10, tiny);
+    std::vector<int64_t> above10(16, 240), above30(16, 600);
+    run<4>("BTRS, n = 240, p = 0.05 (np 12)", above10, tiny);
+    run<4>("BTRS, n = 600, p = 0.05 (np 30)", above30, tiny);
+    run<2>("BTRS, n = 240, p = 0.05 (np 12)", above10, tiny);
+    {   // every quad its own (n, p): inversion draws with n p = 0.6 .. 9.6 beside BTRS draws with n p = 10.5 .. 300
+        std::vector<int64_t> nn(16); std::vector<double> pp(16);
+        for (int i = 0; i < 16; ++i) {
+            if (i & 1) { nn[i] = 350ll * (1ll << (i / 3)); pp[i] = 0.03 + 0.02 * (i % 5); }
+            else { nn[i] = 20 * (i + 1); pp[i] = 0.03; }
+        }
+        run<4>("diverse mixed (np 0.6..9.6 | 10..300)", nn, pp);
+        run<2>("diverse mixed (np 0.6..9.6 | 10..300)", nn, pp);
+        for (int i = 0; i < 16; i += 2) { nn[i] = nn[i + 1]; pp[i] = pp[i + 1]; }
+        run<4>("diverse BTRS only (np 10..300)", nn, pp);
+        run<2>("diverse BTRS only (np 10..300)", nn, pp);
+    }
     run<4>("mixed BTRS / inversion", mixed, tiny);
     run<2>("BTRS, n = 1e12, p = 0.37", big, half);
     run<2>("inversion, n = 40, p = 0.05", small, tiny);
