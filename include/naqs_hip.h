@@ -366,7 +366,8 @@ int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t 
  * not fit, so that the caller can fold the buffer.  stop_reason: 0 all n_steps taken, 1 tracking buffer full, 2 event buffer
  * full, 3 a draw was abandoned without a rule to adapt by (an error in the reference too).  steps_done steps were taken in any
  * case; Adam's step count, the sampling-call counter, n_samples and ring_off are updated in place.
- * Results are bit-identical to calling naqs_vmc_step step by step with the same seeds (tests/test_optimizer_gpu.py). */
+ * Results are bit-identical to calling naqs_vmc_step step by step with the same seeds (tests/test_optimizer_gpu.py).
+ * (continued below the type definitions) */
 typedef struct naqs_vmc_event {
     int64_t step;            /* 0-based index (within this call) of the step whose draw was being adapted */
     int64_t n_unique;        /* unique samples of the abandoned draw (n_unq_samples_max + 1 for an overflow) */
@@ -402,7 +403,18 @@ typedef struct naqs_vmc_run_args {
     int64_t n_events, steps_done, last_keys_off;
     int32_t stop_reason, pad;
 } naqs_vmc_run_args_t;
+/* NAQS_DEFER_PHASE=1 (off by default: measured slower on this pool, the cross-stream hand-overs cost more than the overlap
+ * wins): inside the run the phase MLP's half of a step — its share of the backward pass, its reductions + Adam update, its
+ * re-pack — is issued on a second stream of the handle behind the amplitude blocks' half, so that it runs beside the NEXT
+ * step's sampler (launches that read the amplitude blocks only and leave the chip almost empty) instead of in front of it;
+ * the next forward pass waits for it, and so does this call before it returns: the caller never sees a half-updated
+ * parameter vector.  Same kernels on the same operands either way. */
 int naqs_vmc_run(naqs_net_t *net, naqs_ham_t *ham, int64_t n_steps, naqs_vmc_run_args_t *args, void *stream);
+/* Order `stream` behind whatever work of this handle is still in flight on its own streams (the deferred phase chain of a
+ * naqs_vmc_run that ended early with an error; a re-pack of the phase layers that no launch has hosted yet is started on
+ * `stream`).  Every entry point that reads the phase layers does this itself; callers that read the flat parameter or
+ * gradient buffers directly after such an error call it first.  No counterpart in the reference. */
+int naqs_net_finish_pending(naqs_net_t *net, void *stream);
 /* One Adam step on a flat float32 parameter vector (device pointers): torch.optim.Adam's rule without amsgrad —
  * the reference's optimiser, experiments/_base.py:228 (betas (0.9, 0.99), eps 1e-15).  `step` is the 1-based count
  * after this update (bias corrections 1 - beta^step are formed on the host in float64). */

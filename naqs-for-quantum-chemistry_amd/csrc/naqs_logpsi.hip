@@ -2036,6 +2036,7 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
                            net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = flat_dev;
+        net->pack_stream = s;
     } else if (mode == PACK_PHASE) {
         NAQS_KLAUNCH(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
@@ -2056,14 +2057,40 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
     return NAQS_OK;
 }
 
+// a pending re-pack reads the parameters the update wrote on `pack_stream`: a different stream is ordered behind it first
+static int pack_follow_update(naqs_net *net, hipStream_t s) {
+    if (net->pack_stream != nullptr && net->pack_stream != s) {
+        if (!net->ev_fork) HIP_TRY(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(net->ev_fork, net->pack_stream));
+        HIP_TRY(hipStreamWaitEvent(s, net->ev_fork, 0));
+    }
+    return NAQS_OK;
+}
 int naqs::net_take_pending_pack(naqs_net *net, hipStream_t s, naqs::PackPhaseArgs *out) {
     *out = naqs::PackPhaseArgs{};
     if (net->pack_pending == nullptr) return NAQS_OK;
+    const int st = pack_follow_update(net, s);
+    if (st != NAQS_OK) return st;
     return pack_single_phase(net, net->pack_pending, s, PACK_TAKE, out);
 }
 int naqs::net_flush_pack(naqs_net *net, hipStream_t s) {
+    if (net->phase_pending) {                              // naqs_vmc_run's deferred phase chain: `s` goes behind it
+        HIP_TRY(hipStreamWaitEvent(s, net->ev_phase_done, 0));
+        net->phase_pending = false;
+    }
     if (net->pack_pending == nullptr) return NAQS_OK;
+    const int st = pack_follow_update(net, s);
+    if (st != NAQS_OK) return st;
     return pack_single_phase(net, net->pack_pending, s, PACK_PHASE, nullptr);
+}
+int naqs::net_finish_pending(naqs_net *net, hipStream_t s) { return naqs::net_flush_pack(net, s); }
+
+NAQS_API int naqs_net_finish_pending(naqs_net_t *net, void *stream) {
+    if (!net) return NAQS_ERR_INVALID;
+    DeviceGuard guard;
+    int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    return naqs::net_flush_pack(net, reinterpret_cast<hipStream_t>(stream));
 }
 
 NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_t count, void *stream) {
@@ -2073,6 +2100,10 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const NetDims &d = net->dims;
+    if (net->phase_pending) {                             // (a deferred phase chain still writes what this re-pack reads and overwrites)
+        HIP_TRY(hipStreamWaitEvent(s, net->ev_phase_done, 0));
+        net->phase_pending = false;
+    }
     net->have_weights = net->have_amp_weights = net->have_wb = false;
     net->pack_pending = nullptr;                          // (whatever was pending is superseded by this re-pack)
     if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack

@@ -212,8 +212,18 @@ struct naqs_net {
     int64_t *d_info2 = nullptr;             // device words for the sampler's plain (M, overflow) output of those calls
     int64_t info_seq = 0;                   // sampling calls that published there
     const naqs::PollCtl *ctl = nullptr;     // the device's bounded-wait control block (naqs_poll.hpp); every kernel that polls gets it
-    hipStream_t side_stream = nullptr;      // the amplitude blocks' backward runs here, beside the phase MLP's (naqs_phase_grad.hip)
+    hipStream_t side_stream = nullptr;      // NAQS_TRAIN_SIDE_STREAM=1: the amplitude blocks' backward beside the phase MLP's; naqs_vmc_run: the
+                                            // phase MLP's share of a step's backward pass, update and re-pack, beside the NEXT step's sampler
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // naqs_vmc_run (round 5): the next sampler call reads the amplitude blocks only, and its three launches leave the chip
+    // almost empty for ~90 us — so the phase MLP's half of the backward pass, its reductions + Adam update and its re-pack
+    // run on side_stream behind the amplitude blocks' backward, and the caller's stream goes straight on to the sampler.
+    // Whoever needs the phase layers, the gradient or the parameters next waits for ev_phase_done first (net_flush_pack /
+    // naqs_net_finish_pending); naqs_vmc_run itself does before it returns, so its callers never see the pending state.
+    bool defer_phase = false;               // set by naqs_vmc_run around its steps (NAQS_DEFER_PHASE=0: never)
+    bool phase_pending = false;             // side_stream work the caller's stream has not been ordered behind yet
+    hipEvent_t ev_phase_done = nullptr;
+    hipStream_t pack_stream = nullptr;      // the stream whose work (the update) a pending re-pack must follow
 };
 
 namespace naqs {
@@ -238,6 +248,9 @@ struct WbPackJobs {
     float *dst[MAXL] = {};
 };
 int net_backward_pack_jobs(naqs_net *net, WbPackJobs *jobs);
+// naqs_logpsi.hip: order `s` behind whatever this handle still has in flight elsewhere (the deferred phase chain of
+// naqs_vmc_run), and start a pending re-pack of the phase layers on it
+int net_finish_pending(naqs_net *net, hipStream_t s);
 // naqs_grad.hip: d/d theta sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks, or the phase blocks of an
 // aggregate-phase network with raw = 1); grad_dev receives n_block_params floats in state_dict order
 // With `defer` the fixed-order reduction of the workgroups' partial sums is not launched but described there, for the

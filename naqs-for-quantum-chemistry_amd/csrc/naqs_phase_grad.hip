@@ -325,11 +325,12 @@ struct GradFinish {
     int64_t set_out[2] = {0, 0};       // where each set starts in the flat gradient
     int64_t total = 0;                 // sets + MLP elements
 };
+// (e0, e1: the elements this launch covers — all of them, or the block sets' and the MLP's as two launches on two streams)
 __global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, const GradWJobs J, const float *__restrict__ cpart_base,
                                                           const float *__restrict__ bpart_base, float *__restrict__ grad,
-                                                          const naqs::AdamArgs A) {
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= F.total) return;
+                                                          const naqs::AdamArgs A, const int64_t e0, const int64_t e1) {
+    int64_t e = e0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= e1) return;
     const int64_t sets_total = F.n_sets > 0 ? F.set_end[F.n_sets - 1] : 0;
     float s = 0.0f;
     int64_t o;
@@ -794,9 +795,11 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
 // (E_loc, w, sums) together with its amplitude column and the output delta (naqs_net_train_backward_vmc, single-phase only)
 struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; bool form_sums = false; };   // form_sums: `sums` is an OUTPUT of the seed kernel
 static int launch_grad_finish(const GradFinish &F, const GradWJobs &J, const float *cpart, const float *bpart, float *grad_dev,
-                              const naqs::AdamArgs *adam, hipStream_t s) {
-    NAQS_KLAUNCH(grad_finish_kernel, dim3((unsigned)((F.total + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
-                       adam ? *adam : naqs::AdamArgs{});
+                              const naqs::AdamArgs *adam, hipStream_t s, int64_t e0 = 0, int64_t e1 = -1) {
+    if (e1 < 0) e1 = F.total;
+    if (e1 <= e0) return NAQS_OK;
+    NAQS_KLAUNCH(grad_finish_kernel, dim3((unsigned)((e1 - e0 + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
+                       adam ? *adam : naqs::AdamArgs{}, e0, e1);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -863,11 +866,9 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     const bool side = naqs::env_int("NAQS_TRAIN_SIDE_STREAM", 0) == 1;
     hipStream_t sa = s;
     if (side) {
-        if (!net->side_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&net->side_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
-        }
+        if (!net->side_stream) HIP_TRY(hipStreamCreateWithFlags(&net->side_stream, hipStreamNonBlocking));
+        if (!net->ev_fork) HIP_TRY(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+        if (!net->ev_join) HIP_TRY(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
         sa = net->side_stream;
         HIP_TRY(hipEventRecord(net->ev_fork, s));                 // g (and the keys) are ready on the caller's stream
         HIP_TRY(hipStreamWaitEvent(sa, net->ev_fork, 0));
@@ -908,6 +909,15 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     }
     // NAQS_TRAIN_MEGA=0: every piece its own launch
     const bool mega = H == 2 && d.Ha == 64 && !side && naqs::env_int("NAQS_TRAIN_MEGA", 1) == 1;
+    // naqs_vmc_run's steps: the phase MLP's half of what follows goes to the side stream (see the launch below)
+    const bool defer = net->defer_phase && mega && adam != nullptr && seed_delta;
+    hipStream_t sp = s;
+    if (defer) {
+        if (!net->side_stream) HIP_TRY(hipStreamCreateWithFlags(&net->side_stream, hipStreamNonBlocking));
+        if (!net->ev_fork) HIP_TRY(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+        if (!net->ev_phase_done) HIP_TRY(hipEventCreateWithFlags(&net->ev_phase_done, hipEventDisableTiming));
+        sp = net->side_stream;
+    }
     naqs::ampbw::AmpSrc amp_src{};
     if (mega) st = naqs::net_blocks_backward_plan(net, net->dims, net->amp_src_off, net->amp_params, M, 0, &F.set[0], &amp_src);
     else st = naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_amp, grad_dev, 0, sa,
@@ -993,11 +1003,28 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         if (lds > 64 * 1024) return NAQS_ERR_UNSUPPORTED;
         A.fuse_w0 = w0_tiles && naqs::env_int("NAQS_FUSE_W0", 1) != 0 ? 1 : 0;
         A.w0 = W0Fuse{x, L.x_ld, cpart + J.cpart_off[0], bpart + J.bpart_off[0], J.Kp[0]};
-        NAQS_KLAUNCH(backward_mega_kernel, dim3((unsigned)(A.n_gin + A.n_amp + blocks_total - J.block_end[0])), dim3(256), lds, s,
-                           A, d, J, amp_src);
-        HIP_TRY(hipGetLastError());
+        if (defer) {
+            // naqs_vmc_run: the amplitude blocks' pieces alone on the caller's stream — the next sampler call needs nothing
+            // else — and the phase MLP's pieces (first hidden layer's delta, every layer's weight gradient) on the side
+            // stream BEHIND them, where they run beside that sampler call's almost empty launches instead of in front of them.
+            // Same device functions on the same operands: the same numbers as the one launch.
+            MegaArgs Aa = A;
+            Aa.n_gin = 0;
+            NAQS_KLAUNCH(backward_mega_kernel, dim3((unsigned)A.n_amp), dim3(256), lds, s, Aa, d, J, amp_src);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(net->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(sp, net->ev_fork, 0));
+            MegaArgs Ap = A;
+            Ap.n_amp = 0;
+            NAQS_KLAUNCH(backward_mega_kernel, dim3((unsigned)(A.n_gin + blocks_total - J.block_end[0])), dim3(256), lds, sp, Ap, d, J, amp_src);
+            HIP_TRY(hipGetLastError());
+        } else {
+            NAQS_KLAUNCH(backward_mega_kernel, dim3((unsigned)(A.n_gin + A.n_amp + blocks_total - J.block_end[0])), dim3(256), lds, s,
+                               A, d, J, amp_src);
+            HIP_TRY(hipGetLastError());
+        }
         if (!A.fuse_w0) {
-            NAQS_KLAUNCH(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, s, J, M, cpart, bpart, 0);
+            NAQS_KLAUNCH(grad_w_kernel, dim3((unsigned)J.block_end[0]), dim3(256), 0, sp, J, M, cpart, bpart, 0);
             HIP_TRY(hipGetLastError());
         }
     } else {
@@ -1006,6 +1033,14 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
     }
     if (side) HIP_TRY(hipStreamWaitEvent(s, net->ev_join, 0));   // the amplitude blocks' partial sums are complete
     F.total = F.set_end[0] + elems;
+    if (defer) {                                             // each half's reductions + Adam update behind its own pieces
+        st = launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, s, 0, F.set_end[0]);
+        if (st != NAQS_OK) return st;
+        st = launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, sp, F.set_end[0], F.total);
+        if (st != NAQS_OK) return st;
+        net->phase_pending = true;                           // (the re-pack and ev_phase_done follow: naqs_vmc_step)
+        return NAQS_OK;
+    }
     return launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, s);
 }
 
@@ -1049,10 +1084,21 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
     if (adam_step >= 1) {
         // the next sampling call reads the amplitude blocks; the phase layers' share of the re-pack rides in that call's
         // first launch (naqs_pack.hpp; NAQS_PACK_OVERLAP=0: everything here, in order)
-        net->overlap_next_pack = naqs::env_int("NAQS_PACK_OVERLAP", 1) != 0;
+        const bool deferred = net->phase_pending;            // (train_backward_impl put the phase MLP's half on the side stream)
+        net->phase_pending = false;                          // (naqs_net_set_weights must not wait for what it is part of)
+        net->overlap_next_pack = deferred || naqs::env_int("NAQS_PACK_OVERLAP", 1) != 0;
         st = naqs_net_set_weights(net, param_dev, net->n_params, stream);
         net->overlap_next_pack = false;
         if (st != NAQS_OK) return st;
+        if (deferred) {
+            // the phase layers' re-pack behind their update, on the side stream; whoever reads them, the gradient or the
+            // parameters next waits for ev_phase_done (net_flush_pack) — the next step's forward pass, ~100 us from here
+            net->pack_stream = net->side_stream;             // (nothing to order: the update ran on this very stream)
+            st = naqs::net_flush_pack(net, net->side_stream);
+            if (st != NAQS_OK) return st;
+            HIP_TRY(hipEventRecord(net->ev_phase_done, net->side_stream));
+            net->phase_pending = true;
+        }
     }
     info_host[2] = 1;
     return NAQS_OK;
@@ -1081,6 +1127,19 @@ NAQS_API int naqs_vmc_run(naqs_net_t *net, naqs_ham_t *ham, int64_t n_steps, naq
     a->last_keys_off = a->ring_elems > 0 ? a->ring_off : 0;
     const int64_t cap = a->n_unq_samples_max;
     const auto t0 = std::chrono::steady_clock::now();
+    // NAQS_DEFER_PHASE=1: the phase MLP's half of every step's backward pass / update / re-pack beside the next step's sampler
+    // (naqs_net.hpp); joined below, before the caller sees anything.  OFF by default — measured slower: the two event
+    // hand-overs between the streams cost 7-30 us of queue time per step on this pool where the split saves 2 (H2O) to 12 us
+    // (N2) of kernel time on the caller's stream: N2 0.188-0.190 ms per step against 0.185-0.187, H2O 0.142 against 0.130
+    // (profiles/r05_defer_phase_timeline.txt).  Same numbers either way (tests/test_optimizer_gpu.py).
+    struct DeferScope {
+        naqs_net_t *net; hipStream_t s;
+        ~DeferScope() {
+            net->defer_phase = false;
+            (void)naqs::net_finish_pending(net, s);
+        }
+    } scope{net, reinterpret_cast<hipStream_t>(stream)};
+    net->defer_phase = naqs::env_int("NAQS_DEFER_PHASE", 0) != 0;
     for (int64_t i = 0; i < n_steps; ++i) {
         if (a->ring_elems > 0 && a->ring_off + cap > a->ring_elems) { a->stop_reason = 1; break; }
         uint64_t *keys = a->keys_dev + (a->ring_elems > 0 ? a->ring_off : 0);

@@ -341,6 +341,9 @@ def _farm_launch(args, argv):
     for g in range(n_gpus):
         mine = ",".join(str(j) for j in range(g, len(jobs), n_gpus))
         env = dict(os.environ, WORLD_SIZE=str(n_gpus), RANK=str(g), LOCAL_RANK=str(g), NAQS_FARM_DEVICE=str(g), NAQS_FARM_JOBS=mine)
+        if args.per_gpu > 1:
+            # (NAQS_DEFER_PHASE=1 would give every replica a second stream of its own: a hardware queue too many — see below)
+            env["NAQS_DEFER_PHASE"] = "0"
         if args.per_gpu > 2:
             # more than two ACTIVE hardware queues are time-sliced in multi-millisecond quanta on this pool (k = 4 threads on
             # four queues: 3 000-step runs take 40-130 s instead of 9): let the runtime map the threads' streams onto two

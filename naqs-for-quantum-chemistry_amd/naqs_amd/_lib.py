@@ -64,6 +64,7 @@ SIGNATURES = {
     "naqs_vmc_step": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_i64] + [c_vp] * 13 +
                       [ctypes.c_double] * 5 + [c_i64, ctypes.POINTER(c_i64), c_vp]),
     "naqs_vmc_run": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "naqs_net_finish_pending": (ctypes.c_int, [c_vp, c_vp]),
     "naqs_net_prof_select": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_launch_count": (c_i64, []),
     "naqs_shard_proof": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp]),

@@ -299,7 +299,8 @@ def test_one_call_training_step_equals_the_step_by_step_loop(mol, kw, tmp_path, 
 
 
 @pytest.mark.parametrize("mol,kw", [("N2", {}), ("LiH", dict(n_samples=100, n_unq_samples_min=20)),
-                                     ("H2O", dict(n_samples=1000000, n_unq_samples_max=120, n_unq_samples_min=5))])
+                                     ("H2O", dict(n_samples=1000000, n_unq_samples_max=120, n_unq_samples_min=5)),
+                                     ("N2", dict(defer=True))])
 def test_training_loop_in_the_library_equals_the_step_by_step_loop(mol, kw, tmp_path, monkeypatch, capsys):
     """``naqs_vmc_run`` — the loop of PartialSamplingOptimizer.run (energy.py:975-1008) with get_samples' adaptive sample
     count (energy.py:936-971) in C, chunks of steps between the loop's own events (first line, output lines, checkpoints,
@@ -307,6 +308,11 @@ def test_training_loop_in_the_library_equals_the_step_by_step_loop(mol, kw, tmp_
     counts, messages, sampled-state counts and parameters agree bit for bit."""
     from naqs_amd.optimizer import LogKey
     runs = {}
+    kw = dict(kw)
+    if kw.pop("defer", False):
+        # the phase MLP's half of each step on a second stream beside the next step's sampler (off by default: slower on this
+        # pool) — the same kernels on the same operands, joined before naqs_vmc_run returns
+        monkeypatch.setenv("NAQS_DEFER_PHASE", "1")
     for mode in ("1", "0"):
         monkeypatch.setenv("NAQS_TRAIN_RUN", mode)
         z, hil, wf, opt = make_opt_gpu(mol, tmp_path / mode, **kw)
@@ -332,6 +338,8 @@ def test_training_loop_in_the_library_equals_the_step_by_step_loop(mol, kw, tmp_
     assert a["t"] == 31 and np.isfinite(a["e"]).all() and len(a["lines"]) == 4      # epochs 1, 10, 20 and 28 (= 25 + 3: every 4th of the second run)
     if kw:
         assert a["msgs"], "the adaptive sample count was meant to act in this case"
+    # whatever was deferred inside the run has been joined: parameters read right after it are the updated ones
+    assert torch.equal(a["p"][-4:], b["p"][-4:])
 
 
 def test_training_run_is_reproducible_at_large_tables(tmp_path, monkeypatch):
