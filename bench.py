@@ -612,15 +612,23 @@ def worker(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("NAQS_BENCH_FORCE_DIST") == "1"      # (forced at world 1: exercises the path)
+    rank_info = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        # what the communicator saw, per rank: (rank, HIP device the rank is bound to, communicator world size) — gathered
+        # THROUGH the communicator, so that a recorded line shows that N ranks on N devices took part
+        mine = torch.tensor([rank, torch.cuda.current_device(), dist.get_world_size()], dtype=torch.int64,
+                            device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_info = [{"rank": int(t[0]), "device": int(t[1]), "communicator_world_size": int(t[2])} for t in allr]
 
     if args.emulate_world:
         return emulate_main(args, dev)
     if args.shard == "rows":
-        return sharded_main(args, dev, world, rank, use_dist)
+        return sharded_main(args, dev, world, rank, use_dist, rank_info)
 
     ham_p = packing.load_packed(os.path.join(ROOT, "tests", "golden", f"ham_{args.molecule}.npz"))
     ham = hamiltonian.DevicePauliHamiltonian(ham_p, device=dev)
@@ -820,6 +828,7 @@ def worker(args):
                        "input": "unique sampled bit-strings (keys) resident in HBM; random-init network",
                        "ranks": (f"{dist.get_world_size()} {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} rank(s)"
                                  if use_dist else "single process, no process group"),
+                       "ranks_detail": rank_info,
                        "energy": float(s[0] / s[3])},
             "roofline": roofline,
         }
@@ -843,7 +852,7 @@ def worker(args):
     return 0
 
 
-def sharded_main(args, dev, world, rank, use_dist):
+def sharded_main(args, dev, world, rank, use_dist, rank_info=None):
     """--shard rows: the sharded table is the measurement (BASELINE config 4 with --molecule Li2O --samples 50000)."""
     import torch.distributed as dist
     res, (ham_p, keys_np, log_psi_np, wf_args) = run_row_sharded(dev, world, rank, use_dist, args.molecule, args.samples,
@@ -870,7 +879,7 @@ def sharded_main(args, dev, world, rank, use_dist):
                "config": {"workload": res["workload"], "collectives_per_step": res["collectives_per_step"],
                           "ranks": (f"{dist.get_world_size()} {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} rank(s)"
                                     if use_dist else "single process, no process group"),
-                          "rows_per_rank": rows, "energy": res["energy"]},
+                          "ranks_detail": rank_info, "rows_per_rank": rows, "energy": res["energy"]},
                "roofline": roofline}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ham_p, keys_np, log_psi_np, wf_args)
@@ -878,9 +887,74 @@ def sharded_main(args, dev, world, rank, use_dist):
     return 0
 
 
-# what a collective of this size costs on the node is NOT measured here (one GPU): the model carries an explicit, labelled
-# assumption instead — a latency-bound RCCL collective over xGMI (the all-gather moves M x 8 B in all, the all-reduce 32 B)
-ASSUMED_COLLECTIVE_US = {"all_gather_table": 25.0, "all_reduce_accumulators": 20.0}
+# What a collective costs on the node cannot be measured here (one GPU).  The scaling models carry two things instead, both
+# printed in their JSON: (1) the MEASURED floor of each collective on this box — RCCL at world size 1 through
+# torch.distributed, i.e. the software path and the kernel launch with nothing on the wire; (2) a stated per-hop model on top:
+# a ring over W ranks takes W - 1 steps for an all-gather and 2 (W - 1) for an all-reduce, each step one xGMI hop of ASSUMED
+# latency HOP_US plus its nbytes / W at one link's rate (xGMI is point to point: 7 links x ~153 GB/s per GPU, a ring uses one
+# per direction).  Everything stays "unmeasured on hardware" for W > 1.
+XGMI_LINK_GBS = 153.0
+ASSUMED_HOP_US = 2.0
+ASSUMED_FLOOR_US = {"all_gather_table": 25.0, "all_reduce_accumulators": 20.0, "all_reduce_gradient": 35.0}     # when no RCCL group can be formed
+
+
+def measure_collective_floor(dev, table_bytes, grad_bytes, reps=200):
+    """us per collective at world size 1 (RCCL; a group of one is formed here when the process has none): the all-gather of a
+    (log|psi|, phase) table of `table_bytes`, the all-reduce of the 64-byte accumulator block and the all-reduce of a flat
+    gradient of `grad_bytes` — stream-synchronised means over `reps` calls.  -> (dict, how)"""
+    import torch
+    import torch.distributed as dist
+    made = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            made = True
+        if dist.get_world_size() != 1:
+            return dict(ASSUMED_FLOOR_US), "assumed (the process group has more than one rank: no world-1 measurement taken)"
+        out = {}
+        cases = {"all_gather_table": ("gather", max(8, table_bytes)), "all_reduce_accumulators": ("reduce", 64),
+                 "all_reduce_gradient": ("reduce", max(4, grad_bytes))}
+        for name, (kind, nbytes) in cases.items():
+            a = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+            b = torch.empty_like(a)
+            fn = (lambda: dist.all_gather_into_tensor(b, a)) if kind == "gather" else (lambda: dist.all_reduce(a))
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / reps * 1e6
+        return out, f"measured: {dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}) at world size 1 on this box, mean of {reps} back-to-back calls"
+    except Exception as ex:                                              # no RCCL here: fall back to the labelled assumptions
+        return dict(ASSUMED_FLOOR_US), f"assumed ({type(ex).__name__}: {ex})"
+    finally:
+        if made:
+            dist.destroy_process_group()
+
+
+def collective_model_us(kind, world, nbytes, floor_us):
+    """floor (measured at world 1) + ring steps x (assumed hop latency + that step's bytes at one xGMI link's rate)"""
+    if world <= 1:
+        return floor_us
+    steps = (world - 1) * (2 if kind == "reduce" else 1)
+    return floor_us + steps * (ASSUMED_HOP_US + (nbytes / world) / (XGMI_LINK_GBS * 1e3))
+
+
+def collective_table(worlds, table_bytes, grad_bytes, floor):
+    """per world size: the three collectives of a sharded step under the model above (us)"""
+    rows = {}
+    for W in worlds:
+        rows[str(W)] = {"all_gather_table": collective_model_us("gather", W, table_bytes, floor["all_gather_table"]),
+                        "all_reduce_accumulators": collective_model_us("reduce", W, 64, floor["all_reduce_accumulators"]),
+                        "all_reduce_gradient": collective_model_us("reduce", W, grad_bytes, floor["all_reduce_gradient"])}
+    return rows
 
 
 def emulate_main(args, dev):
@@ -902,10 +976,13 @@ def emulate_main(args, dev):
                          "rows_per_rank": res["rows_per_rank"], "logpsi_rows_per_rank": res["logpsi_rows_per_rank"],
                          "eloc_kernel_us": res["eloc_kernel_us"], "logpsi_kernel_us": res["logpsi_kernel_us"],
                          "eloc_kernel": res["eloc_kernel_name"], "logpsi_kernel": res["logpsi_kernel_name"]})
-    coll = sum(ASSUMED_COLLECTIVE_US.values()) * 1e-3
+    # the evaluation path has two collectives per step: the table's all-gather and the accumulators' all-reduce
+    floor, how = measure_collective_floor(dev, args.samples * 8, 4)
+    table = collective_table(worlds, args.samples * 8, 4, floor)
     for r in rows:
         base = next(x for x in rows if x["world"] == worlds[0] and x["pipeline"] == r["pipeline"])
         r["kernel_only_speedup"] = base["rank0_ms_per_step"] * (worlds[0] / 1.0) / r["rank0_ms_per_step"] if worlds[0] == 1 else None
+        coll = (table[str(r["world"])]["all_gather_table"] + table[str(r["world"])]["all_reduce_accumulators"]) * 1e-3
         # serial step: the collectives' latency adds to every step; pipelined: it overlaps the next evaluation's kernels
         # (bench.py issues the all-reduce one step late for exactly that), so the kernel-only time is the model
         t_model = r["rank0_ms_per_step"] + (coll if (r["world"] > 1 and r["pipeline"] == 1) else 0.0)
@@ -920,7 +997,10 @@ def emulate_main(args, dev):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rows[-1]["model_ms_per_step"], "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": dtype_label(), "data": "synthetic",
            "emulated_worlds": worlds, "unmeasured_on_hardware": True,
-           "assumed_collective_latency_us": ASSUMED_COLLECTIVE_US,
+           "collective_latency": {"world1_floor_us": floor, "world1_floor_source": how,
+                                  "model": f"floor + ring steps x ({ASSUMED_HOP_US} us ASSUMED per xGMI hop + (bytes / W) at {XGMI_LINK_GBS} GB/s per "
+                                           "link); steps = W - 1 (all-gather), 2 (W - 1) (all-reduce)",
+                                  "per_world_us": {w: {k: v for k, v in t.items() if k != "all_reduce_gradient"} for w, t in table.items()}},
            "config": {"workload": f"{args.molecule} STO-3G, ONE table of {args.samples} unique samples; rank 0 of W evaluates log psi for "
                                   f"ceil(M/W) rows and E_loc for its rows against the whole table (stand-in for the all-gather: the "
                                   f"table evaluated once up front), no collectives issued"},

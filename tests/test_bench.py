@@ -100,6 +100,7 @@ def test_row_sharded_table_through_rccl_on_one_gpu():
     d = json.loads(lines[-1])
     assert REQUIRED <= set(d) and d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 1e6
     assert "1 RCCL rank(s)" in d["config"]["ranks"] and d["config"]["rows_per_rank"] == 50000
+    assert d["config"]["ranks_detail"] == [{"rank": 0, "device": 0, "communicator_world_size": 1}]     # what the communicator saw
     assert np.isfinite(d["config"]["energy"]) and "all-gather" in d["config"]["collectives_per_step"]
 
 
@@ -114,6 +115,7 @@ def test_two_ranks_on_one_gpu_shard_one_table_to_the_same_energy():
     assert one.returncode == 0 and two.returncode == 0, one.stderr[-1500:] + two.stderr[-1500:]
     d1, d2 = json.loads(l1[-1]), json.loads(l2[-1])
     assert d2["n_gpus"] == 2 and "2 gloo rank(s)" in d2["config"]["ranks"] and d2["config"]["rows_per_rank"] == 10001
+    assert [(r["rank"], r["communicator_world_size"]) for r in d2["config"]["ranks_detail"]] == [(0, 2), (1, 2)]
     e1, e2 = d1["config"]["energy"], d2["config"]["energy"]
     assert np.isfinite(e1) and abs(e1 - e2) < 1e-9 * abs(e1), (e1, e2)
 

@@ -7,7 +7,8 @@ delivers the true table by evaluating log psi of all rows with the inference ker
 timed separately and subtracted.
 
 usage: python tools/scaling_model.py [molecule npz] [steps] [out.json]
-Everything is single-GPU evidence ("unmeasured on hardware" for W > 1); collective latencies are labelled assumptions."""
+Everything is single-GPU evidence ("unmeasured on hardware" for W > 1).  The collectives enter as bench.py's model: each
+one's MEASURED floor at world size 1 (RCCL on this box) plus ring steps at an assumed per-hop latency and one xGMI link's rate."""
 import contextlib
 import io
 import json
@@ -28,7 +29,7 @@ from naqs_amd.wavefunction import NAQSComplex_NADE_orbitals
 mol_f = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/ham_N2.npz")
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 out_f = sys.argv[3] if len(sys.argv) > 3 else None
-ASSUMED_US = {"all_gather_table": 25.0, "all_reduce_accumulators": 20.0, "all_reduce_gradient_1MB": 35.0}
+import bench                                      # measured world-1 collective floors + the stated per-hop model
 dev = torch.device("cuda", 0)
 
 
@@ -102,12 +103,21 @@ if len(WORLDS) > 1:
         rows += sub["per_world"]
         print(sub["per_world"][0], flush=True)
     base = rows[0]["rank0_ms_per_step"]
-    coll = sum(ASSUMED_US.values()) * 1e-3
+    n_params = sub["n_params"]
+    m_big = max(r["mean_unique_samples"] for r in rows)
+    floor, how = bench.measure_collective_floor(dev, int(m_big) * 8, n_params * 4)
+    table = bench.collective_table(WORLDS, int(m_big) * 8, n_params * 4, floor)
     for r in rows:
+        coll = sum(table[str(r["world"])].values()) * 1e-3
         r["kernel_only_speedup"] = base / r["rank0_ms_per_step"]
         r["model_ms_per_step"] = r["rank0_ms_per_step"] + (coll if (r["world"] > 1 and r["mode"] == "sharded") else 0.0)
         r["model_speedup"] = base / r["model_ms_per_step"]
     res = dict(sub, per_world=rows)
+    res["collective_latency"] = {"world1_floor_us": floor, "world1_floor_source": how,
+                                 "model": f"floor + ring steps x ({bench.ASSUMED_HOP_US} us ASSUMED per xGMI hop + (bytes / W) at {bench.XGMI_LINK_GBS} "
+                                          "GB/s per link); steps = W - 1 (all-gather), 2 (W - 1) (all-reduce)",
+                                 "bytes": {"all_gather_table": int(m_big) * 8, "all_reduce_accumulators": 64, "all_reduce_gradient": n_params * 4},
+                                 "per_world_us": table}
     print(json.dumps(res))
     if out_f:
         with open(out_f, "w") as f:
@@ -171,16 +181,10 @@ for W in WORLDS:
                           "replicated": "every rank runs the single-GPU step (one library call; 32-byte proof every 64 steps)",
                           "sharded": "sharded step (forward of my rows, all-gather, E_loc of my rows, two all-reduces)"}[mode]})
     print(rows[-1], flush=True)
-base = rows[0]["rank0_ms_per_step"]
-coll = sum(ASSUMED_US.values()) * 1e-3
-for r in rows:
-    r["kernel_only_speedup"] = base / r["rank0_ms_per_step"]
-    r["model_ms_per_step"] = r["rank0_ms_per_step"] + (coll if (r["world"] > 1 and r["mode"] == "sharded") else 0.0)
-    r["model_speedup"] = base / r["model_ms_per_step"]
+n_params = int(sum(p.numel() for p in wf.model.parameters()))
 res = {"what": "training step (published network), rank 0's share per world size, measured on ONE GPU; collectives NOT issued",
-       "shard_min_rows": opt.shard_min_rows, "shard_min_table": opt.shard_min_table,
-       "molecule": os.path.basename(mol_f), "steps": steps, "unmeasured_on_hardware": True,
-       "assumed_collective_latency_us": ASSUMED_US, "per_world": rows}
+       "shard_min_rows": opt.shard_min_rows, "shard_min_table": opt.shard_min_table, "n_params": n_params,
+       "molecule": os.path.basename(mol_f), "steps": steps, "unmeasured_on_hardware": True, "per_world": rows}
 print(json.dumps(res))
 if out_f:
     with open(out_f, "w") as f:
