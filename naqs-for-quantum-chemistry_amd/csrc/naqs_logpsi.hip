@@ -1488,6 +1488,393 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     NAQS_MARK(7);
 }
 
+// ------------------------------------------------------------------------------------------------
+// phase_kernel_wt (round 5; NAQS_PHASE_WT=1 — NOT the default: measured no faster) — the big layer TRANSPOSED,
+// H1^T = W1 . H0^T, with layer 0 produced just in time.
+// phase_kernel_ws prices the big layer by the bytes of weight planes a CU streams (1 MB per 48-row workgroup whatever its rows:
+// 27.9 k of the tile's 40 k cycles, the matrix pipe at 35 %); the only way to stream less per CU is the column split
+// (two workgroups per tile, 0.5 MB each), and at 10^4 rows that needs tiles of 80 rows to stay within one round of 256
+// workgroups — whose 160 KB activation tile does not exist.  Here it does not have to: the weights are the A operand (the packed
+// fragments are symmetric in A / B: lane (index, k-group)), the activations the B operand, and a chunk of H0^T — 32 hidden
+// units x 16 samples — comes out of layer 0's accumulators already in B-operand order if W1's contraction index is packed in
+// the order those accumulators hold it (slot 8 g + 4 t + r of chunk c <- unit tile_col(2 c + t, 4 g + r): naqs_amp_mfma.hpp's
+// second stage does the same).  The amplitude waves produce those chunks between their items — 20 MFMAs + bias / ReLU / split
+// per chunk of 80 samples — into a ring of eight 10 KB chunks in LDS (flags in LDS, no fences: a wave's LDS operations execute
+// in order), the matrix waves read their B fragments from it: nothing of the 512-wide activations is ever written as a tile,
+// and a workgroup is 80 rows x 256 output units: 125 tiles x 2 halves = 250 workgroups for 10^4 rows.
+// The output layer, the hand-over between the two halves and the epilogue are phase_kernel_ws<SPLIT>'s.
+// Arithmetic: the same three-term f16x2 products in the same order of terms and chunks; the 32 products inside one MFMA meet in
+// a different slot order and the output layer adds its columns in a different order: the phase differs from phase_kernel_ws in
+// the last bits (4.5e-7 at most on the bench's table; <= 2e-5 of the PyTorch modules like every other form), log|psi| not at all.
+// MEASURED (N2, 10^4 rows, cycle stamps of workgroup 0, tools/wt_check.py; phase_kernel_ws on the same box: 23.1 us):
+//   * first form — every matrix wave recomputes layer 0 itself, fragments in registers: big layer 38.6 k cycles, 29.5 us;
+//   * this form — big layer 24.3 k cycles (27.9 k in phase_kernel_ws), but the amplitude waves, which share their SIMDs'
+//     issue with matrix waves that no longer stall on the weight stream, finish their items at 33-38 k instead of 27 k and end
+//     the workgroup at 41 k cycles: 24.5 us.  The stream was what the MATRIX waves waited for, not what the workgroup waits
+//     for: 1 128 MFMAs + the items' and the output stage's VALU work per SIMD are the same as before.
+//   Stop rule of the review (big layer <= 20 k cycles) not met: kept selectable, off.
+constexpr int WT_NT = 5;                          // sample tiles (16 rows each) of a workgroup
+__host__ __device__ __forceinline__ int wt_in_unit(int c, int s) {       // slot s of chunk c of W1's contraction index -> hidden unit of layer 0
+    const int g = s >> 3, t = (s >> 2) & 1, r = s & 3, cb = 2 * c + t, nn = 4 * g + r;
+    return ((cb >> 2) << 6) + 4 * nn + (cb & 3);                          // = tile_col(cb, nn, 512)
+}
+// W1 [512 out][512 in] f32 -> two scaled f16 planes [plane][out tile 32][chunk 16][64 lanes][8]: lane (m, kg), slot 8 kg + j
+__global__ __launch_bounds__(256) void pack_wt_kernel(const float *__restrict__ W1, const naqs::PhaseScales *__restrict__ scales,
+                                                      ushort_t *__restrict__ wt) {
+    constexpr int total = 512 * 512;
+    const float sw = scales->sw[1];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e & 7, lane = (e >> 3) & 63, c = (e >> 9) & 15, mt = e >> 13;
+        const int out = mt * 16 + (lane & 15), in = wt_in_unit(c, 8 * (lane >> 4) + j);
+        ushort_t h1, h2;
+        split2(W1[out * 512 + in] * sw, h1, h2);
+        wt[e] = h1; wt[total + e] = h2;
+    }
+}
+
+// the amplitude waves' share of a phase_kernel_wt tile: ws_amp_work's items, hand-over and conditionals, with the wave's chunks
+// of H0^T produced in between (`produce(k)`: the k-th of its WT_PROD chunks; the first before any item, then one every
+// `every` items, so that a chunk is in the ring before the matrix waves get to it)
+constexpr int WT_RING = 8;                        // chunks of H0^T the LDS ring holds (10 KB each at 80 rows)
+constexpr int WT_PROD = 16 / (PH_WAVES - WS_MW);  // chunks an amplitude wave produces
+template <int CT, int RB, typename Produce>
+__device__ __forceinline__ void wt_amp_work(const NetDims &d, const ushort_t *__restrict__ wamp, int64_t M, int64_t row0,
+                                            const uint64_t *__restrict__ keys, const ElocFeed &feed, const uint32_t *s_ab,
+                                            float (*s_lan)[RB * 16], float *__restrict__ s_o, AmpFrag<CT> &f0, int aw, int lane,
+                                            long long *clk, int wave, int qlo, int qhi, bool do_feed, Produce &&produce) {
+    constexpr int BM = RB * 16;
+    constexpr int AW = PH_WAVES - WS_MW;
+    const size_t pair_elems = amp_mfma_pair_elems(CT * 16);
+    const int q0 = qlo + (qhi - qlo) * aw / AW, q1 = qlo + (qhi - qlo) * (aw + 1) / AW;
+    AmpFrag<CT> f1;
+    int na = q0 < q1 ? q0 / RB : -1, nb = -1;
+    const int n_last = q0 < q1 ? (q1 - 1) / RB : -1;
+    // the ring holds eight chunks: a wave's first two go in at once, the others one item apart (each waits for the matrix
+    // waves to have read the chunk whose slot it takes)
+    int made = 0;
+    produce(made++);
+    produce(made++);
+    for (int q = q0; q < q1; ++q) {
+        if (made < WT_PROD && (q - q0) >= made - 1) produce(made++);
+        const int n = q / RB, t = q - n * RB;
+        const uint32_t ab = s_ab[t * 16 + (lane & 15)];
+        float *outs = s_o + ((size_t)n * BM + t * 16) * 8;
+        if (n == na) {
+            if (nb < n && n_last > n) { nb = n + 1; amp_mfma_load<CT>(wamp + (size_t)nb * pair_elems, lane, f1); }
+            __builtin_amdgcn_sched_barrier(0);
+            amp_mfma_item<CT>(d, f0, n, ab, lane, outs);
+        } else {
+            if (na < n && n_last > n) { na = n + 1; amp_mfma_load<CT>(wamp + (size_t)na * pair_elems, lane, f0); }
+            __builtin_amdgcn_sched_barrier(0);
+            amp_mfma_item<CT>(d, f1, n, ab, lane, outs);
+        }
+    }
+    while (made < WT_PROD) produce(made++);
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 8] = clock64();
+    {
+        const int r = aw * WAVE + lane;
+        if (do_feed && r < BM && feed.tab != nullptr && row0 + r < M) {
+            const uint64_t key = keys[row0 + r];
+            if (feed.key_bits == 32) naqs::feed_key<uint32_t>(feed, row0 + r, key);
+            else naqs::feed_key<uint64_t>(feed, row0 + r, key);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = q0 * 16 + lane; e < q1 * 16; e += WAVE) {
+        const int q = e >> 4, sidx = e & 15;
+        const int n = q / RB, r = (q - n * RB) * 16 + sidx;
+        float o[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o[c] = s_o[((size_t)n * BM + r) * 8 + c];
+        const uint32_t ab = s_ab[r], mask = (1u << n) - 1u;
+        const int occ = (int)((ab >> n) & 1u) + 2 * (int)((ab >> (16 + n)) & 1u);
+        s_lan[n][r] = naqs::amp_finish(d, n, o, ab & mask, (ab >> 16) & mask, occ);
+    }
+    if (clk != nullptr && blockIdx.x == 0 && lane == 0) clk[wave * 16 + 15] = clock64();
+}
+
+template <int DBG = 0>
+__global__ __launch_bounds__(PH_THREADS) void phase_kernel_wt(const NetDims d, const float *__restrict__ w, const ushort_t *__restrict__ wh,
+                                                              const ushort_t *__restrict__ wt, int64_t M, const uint64_t *__restrict__ keys,
+                                                              float2 *__restrict__ out, const ElocFeed feed, const ushort_t *__restrict__ wamp,
+                                                              const naqs::PhaseScales *__restrict__ scales, const WsSplit split,
+                                                              const naqs::PhaseSave save) {
+    constexpr int NT = WT_NT, BM = NT * 16;
+    constexpr int CHUNK_U4 = 2 * NT * 64;                                  // 16-byte fragments of one chunk of H0^T: [plane][sample tile][lane]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wt[];
+    uint4 *ring = reinterpret_cast<uint4 *>(smem_wt);                       // [WT_RING][2][NT][64]
+    float *s_o = reinterpret_cast<float *>(smem_wt + (size_t)WT_RING * CHUNK_U4 * sizeof(uint4));   // [P][BM][8] raw outputs of the items
+    __shared__ uint32_t s_ab[BM];
+    __shared__ float s_lan[MAXP][BM];
+    __shared__ __attribute__((aligned(16))) float s_part[WS_MW][4][BM][4];  // the output layer's partial rows: [matrix wave][lane group]
+    __shared__ float s_recv[BM][4];
+    __shared__ __attribute__((aligned(16))) float s_b0[16][4][8];          // layer 0's scaled bias in the big layer's slot order
+    __shared__ uint32_t s_ready[16], s_done[16];                           // chunk c of H0^T is in the ring / matrix waves that have read it
+    constexpr int AW = PH_WAVES - WS_MW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (int)(gridDim.x >> 1);
+    const bool producer = (int)blockIdx.x < n_tiles;                       // upper 256 output units; the consumer has the lower ones + the epilogue
+    const int tile = producer ? (int)blockIdx.x : (int)blockIdx.x - n_tiles;
+    const int64_t row0 = (int64_t)tile * BM;
+    const int P = d.P;
+    NAQS_MARK(0);
+    uint64_t key = 0ull;
+    if (tid < BM && row0 + tid < M) key = keys[row0 + tid];
+    const int aw = wave >= WS_MW ? wave - WS_MW : 0;
+    const int items = NT * P;
+    const int q_split = (P / 2) * NT;
+    const int qlo = producer ? q_split : 0, qhi = producer ? items : q_split;
+    const int first_pair = (qlo + (qhi - qlo) * aw / AW) / NT;
+    AmpFrag<4> f4;
+    AmpFrag<2> f2;
+    const bool ha64 = d.Ha == 64;
+    if (wave >= WS_MW) {
+        if (ha64) amp_mfma_load<4>(wamp + (size_t)first_pair * amp_mfma_pair_elems(64), lane, f4);
+        else amp_mfma_load<2>(wamp + (size_t)first_pair * amp_mfma_pair_elems(32), lane, f2);
+    }
+    const float sn0 = scales->sn[0], c0 = scales->c[0];
+    for (int e = tid; e < 512; e += PH_THREADS) s_b0[e >> 5][(e >> 3) & 3][e & 7] = (w + d.b_off[0])[wt_in_unit(e >> 5, e & 31)] * sn0;
+    if (tid < 16) { s_ready[tid] = 0u; s_done[tid] = 0u; }
+    if (tid < BM) {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            if (k < P) {
+                a |= (uint32_t)((key >> d.qa[k]) & 1ull) << k;
+                b |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
+            }
+        }
+        s_ab[tid] = a | (b << 16);
+    }
+    __syncthreads();
+    NAQS_MARK(1);
+
+    LayerScale sc;
+    sc.c = scales->c[1]; sc.sn = scales->sn[1]; sc.isn = scales->isn[1];
+    const int n = lane & 15, g = lane >> 4;
+    if (wave < WS_MW) {
+        // ---- matrix waves: H1^T tiles mt0 .. mt0 + 3 (64 output units) x 80 samples; A = W1 fragments from L2, B = H0^T chunks from the ring
+        const int mt0 = (producer ? 16 : 0) + wave * 4;
+        const size_t WTPL = (size_t)512 * 512;
+        const ushort_t *wtp = wt + ((size_t)mt0 * 16 * 64 + lane) * 8;     // tile mt0 + i, chunk c: + (i * 16 + c) * 512
+        bf16x8 wa[2][4], hb0[2][NT], hb1[2][NT];
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load_wa2 = [&](int c, int i0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) wa[p][i] = *reinterpret_cast<const bf16x8 *>(wtp + p * WTPL + (size_t)(i * 16 + c) * 512);
+        };
+        auto take = [&](int c, bf16x8 (&hb)[2][NT]) {                      // wait for chunk c, read this wave's copy of its fragments
+            // (LDS operations of a wave execute in order and every producer's fragments precede its flag in its own LDS
+            // stream: no fence — a workgroup-scope fence would also wait for the weight fragments in flight from L2 — only the
+            // compiler is kept from moving anything across)
+            while (__hip_atomic_load(&s_ready[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const uint4 *src = ring + (size_t)(c % WT_RING) * CHUNK_U4 + lane;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) hb[p][nt] = __builtin_bit_cast(bf16x8, src[(p * NT + nt) * 64]);
+        };
+        auto release = [&](int c) {                                        // (after the reads have returned: the slot may be overwritten)
+            asm volatile("" ::: "memory");                                 // (the add is behind the reads in this wave's LDS stream)
+            if (lane == 0) __hip_atomic_fetch_add(&s_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // term-major: consecutive MFMAs go to different accumulators (ten of them), so that none waits for the one before —
+        // written accumulator-major the three dependent products of an accumulator sat back to back (29 cycles per MFMA)
+        auto mma2 = [&](int i0, const bf16x8 (&hb)[2][NT]) {
+            if constexpr (DBG == 1) return;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) acc[i][nt] = mfma_h<2>(wa[0][i], hb[1][nt], acc[i][nt]);      // w hi x h lo: smallest terms first
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) acc[i][nt] = mfma_h<2>(wa[1][i], hb[0][nt], acc[i][nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) acc[i][nt] = mfma_h<2>(wa[0][i], hb[0][nt], acc[i][nt]);
+        };
+        load_wa2(0, 0);
+        load_wa2(0, 2);
+        take(0, hb0);
+        release(0);
+        NAQS_MARK(5);
+#pragma unroll 1
+        for (int c = 0; c < 16; c += 2) {
+            take(c + 1, hb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(0, hb0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wa2(c + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(2, hb0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wa2(c + 1, 2);
+            release(c + 1);
+            const int cn = min(c + 2, 15);
+            if (c + 2 < 16) take(c + 2, hb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(0, hb1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wa2(cn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(2, hb1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wa2(cn, 2);
+            if (c + 2 < 16) release(c + 2);
+        }
+        NAQS_MARK(9);
+        // the output layer (512 -> 4) from the accumulators: this lane holds, for sample n of every tile, units 16 (mt0 + i) + 4 g + r
+        const float *W2 = w + d.w_off[2], *bias1 = w + d.b_off[1];
+        const int K2 = d.K_pad[2];
+        float po[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) po[nt][o] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u0 = (mt0 + i) * 16 + 4 * g;
+            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias1 + u0) * sc.sn;
+            f32x4 w2[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) w2[o] = *reinterpret_cast<const f32x4 *>(W2 + (size_t)o * K2 + u0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float h = fmaxf(fmaf(acc[i][nt][r], sc.c, b1[r]), 0.0f);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) po[nt][o] = fmaf(h, w2[o][r], po[nt][o]);
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4 *>(&s_part[wave][g][nt * 16 + n][0]) = (f32x4){po[nt][0], po[nt][1], po[nt][2], po[nt][3]};
+    } else {
+        // ---- amplitude waves: chunks aw, aw + 4, ... of H0^T (layer 0 for all 80 samples of 32 hidden units, straight from its
+        // accumulators into B-operand fragments) between their (tile, pair) items
+        bf16x8 xb[NT];
+        {
+            const uint32_t pmask = (1u << (P - 1)) - 1u;
+            const int nv = min(max(2 * (P - 1) - 8 * g, 0), 8) >> 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint32_t ab = s_ab[nt * 16 + n];
+                const uint32_t tb = ((ab & pmask) | (((ab >> 16) & pmask) << (P - 1))) >> (8 * g);
+                const bool live = row0 + nt * 16 + n < M;
+                uint32_t aw4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t wv = 0xBC00BC00u ^ ((tb << (15 - 2 * j)) & 0x8000u) ^ ((tb << (30 - 2 * j)) & 0x80000000u);
+                    aw4[j] = (live && j < nv) ? wv : 0u;
+                }
+                __builtin_memcpy(&xb[nt], aw4, sizeof(bf16x8));
+            }
+        }
+        const size_t W0PL = (size_t)d.N_pad[0] * d.Kh_pad[0];
+        const ushort_t *w0p = wh + d.wh_off[0] + lane * 8;                 // layer 0's tile cb, its one K chunk: + cb * 512
+        bf16x8 w0[2][2];
+        auto load_w0 = [&](int c) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) w0[p][t] = *reinterpret_cast<const bf16x8 *>(w0p + p * W0PL + (size_t)(2 * c + t) * 512);
+        };
+        load_w0(aw);
+        auto produce = [&](int k) {
+            const int c = aw + AW * k;
+            if (c >= WT_RING)                                              // the slot's previous chunk has been read by all four matrix waves
+                while (__hip_atomic_load(&s_done[c - WT_RING], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)WS_MW) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            uint4 *dst = ring + (size_t)(c % WT_RING) * CHUNK_U4 + lane;
+            const f32x4 ba = *reinterpret_cast<const f32x4 *>(&s_b0[c][g][0]), bb = *reinterpret_cast<const f32x4 *>(&s_b0[c][g][4]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = d0;
+                d0 = mfma_h<2>(w0[1][0], xb[nt], d0);                      // smallest term first (the inputs are exact: two terms)
+                d1 = mfma_h<2>(w0[1][1], xb[nt], d1);
+                d0 = mfma_h<2>(w0[0][0], xb[nt], d0);
+                d1 = mfma_h<2>(w0[0][1], xb[nt], d1);
+                float h[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h[r] = fmaxf(fmaf(d0[r], c0, ba[r]), 0.0f);
+                    h[4 + r] = fmaxf(fmaf(d1[r], c0, bb[r]), 0.0f);
+                }
+                uint32_t hh[4], hl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split2_pair(h[2 * q], h[2 * q + 1], hh[q], hl[q]);
+                dst[nt * 64] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                dst[(NT + nt) * 64] = make_uint4(hl[0], hl[1], hl[2], hl[3]);
+            }
+            if (k + 1 < WT_PROD) load_w0(c + AW);
+            asm volatile("" ::: "memory");                                 // (the flag is behind the fragments in this wave's LDS stream)
+            if (lane == 0) __hip_atomic_store(&s_ready[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (ha64) wt_amp_work<4, NT>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f4, aw, lane, save.clk, wave, qlo, qhi, !producer, produce);
+        else wt_amp_work<2, NT>(d, wamp, M, row0, keys, feed, s_ab, s_lan, s_o, f2, aw, lane, save.clk, wave, qlo, qhi, !producer, produce);
+    }
+    NAQS_MARK(10);
+    __syncthreads();
+    NAQS_MARK(6);
+    auto part_sum = [&](int r, int o) {                    // fixed order: matrix waves, then their lane groups
+        float v = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < WS_MW; ++wv) v += (s_part[wv][0][r][o] + s_part[wv][1][r][o]) + (s_part[wv][2][r][o] + s_part[wv][3][r][o]);
+        return v;
+    };
+    {
+        constexpr int TILE_WORDS = BM * 4 + MAXP * BM;
+        unsigned long long *xw = split.xchg + (size_t)tile * TILE_WORDS;
+        const int n_split = q_split / NT, n_amp = (P - n_split) * BM;
+        const unsigned long long tagw = (unsigned long long)split.tag << 32;
+        if (producer) {
+            for (int x = tid; x < BM * 4 + n_amp; x += PH_THREADS) {
+                float v;
+                if (x < BM * 4) v = part_sum(x >> 2, x & 3);
+                else { const int e = x - BM * 4; v = s_lan[n_split + e / BM][e % BM]; }
+                if (!(naqs::poll_drop(split.ctl, naqs::POLL_LOGPSI_SPLIT) && tile == 0 && x == 0))
+                    __hip_atomic_store(&xw[x], tagw | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        bool ok = true;
+        for (int x = tid; x < BM * 4 + n_amp; x += PH_THREADS) {
+            unsigned long long word;
+            ok = naqs::poll_tagged<2>(&xw[x], split.tag, word, split.ctl, naqs::POLL_LOGPSI_SPLIT, (uint32_t)x) && ok;
+            const float v = __uint_as_float((uint32_t)word);
+            if (x < BM * 4) s_recv[x >> 2][x & 3] = v;
+            else { const int e = x - BM * 4; s_lan[n_split + e / BM][e % BM] = v; }
+        }
+        if (__syncthreads_or(!ok)) return;
+    }
+    if (tid < BM) {
+        const int64_t i = row0 + tid;
+        if (i < M) {
+            float la = 0.0f;
+            for (int nn = 0; nn < P; ++nn) la += s_lan[nn][tid];
+            const uint32_t ab = s_ab[tid];
+            const int occ = (int)((ab >> (P - 1)) & 1u) + 2 * (int)((ab >> (16 + P - 1)) & 1u);
+            const float psum = part_sum(tid, occ) + s_recv[tid][occ];
+            const float ph = fmaf(psum, sc.isn, (w + d.b_off[2])[occ]);
+            out[i] = make_float2(la, ph);
+            if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
+        }
+    }
+    NAQS_MARK(7);
+}
+
 // the weight maxima, their reduction and the scales derived from them: naqs_pack.hpp
 using naqs::PhasePackJobs;
 using naqs::phase_weight_scale;
@@ -1864,6 +2251,12 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_ws<RB, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_all);
             NAQS_WS_ATTR(1) NAQS_WS_ATTR(2) NAQS_WS_ATTR(3)
 #undef NAQS_WS_ATTR
+            {   // phase_kernel_wt: the ring of H0^T chunks + the items' raw outputs
+                const int lds_wt = (int)((size_t)WT_RING * 2 * WT_NT * 64 * 16 + (size_t)MAXP * 16 * WT_NT * 8 * sizeof(float));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_wt<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_wt);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_wt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_wt);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&phase_kernel_wt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_wt);
+            }
             (void)hipGetLastError();            // a refused attribute must not stay behind as the runtime's "last error"
         }
         if (st == NAQS_OK && hipMalloc((void **)&net->d_raw, sizeof(naqs::PhaseRaw)) != hipSuccess) st = NAQS_ERR_NOMEM;
@@ -1888,6 +2281,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_wph) (void)hipFree(net->d_wph);
     if (net->d_wh) (void)hipFree(net->d_wh);
     if (net->d_wamp) (void)hipFree(net->d_wamp);
+    if (net->d_wt) (void)hipFree(net->d_wt);
     if (net->d_scratch) (void)hipFree(net->d_scratch);
     if (net->d_samp) (void)hipFree(net->d_samp);
     if (net->d_gpart) (void)hipFree(net->d_gpart);
@@ -2014,6 +2408,7 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
         net->packed_fmt = fmt;
         net->wamp_fresh = false;
     }
+    if (mode != PACK_TAKE) net->have_wt = false;          // (a re-pack of any kind: phase_kernel_wt's copy is only refreshed by PACK_ALL, below)
     const bool split = mode != PACK_ALL && fmt == 2;      // (PACK_AMP on another format: everything now, nothing pending)
     if (fmt == 2 && (!split || mode >= PACK_PHASE)) {
         if (++net->pack_seq == 0u) {                       // the 32-bit tag is about to repeat: forget every old word
@@ -2031,6 +2426,14 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
                            with_f32, fmt, raw, net->d_scales, 0, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = nullptr;
+        // the big layer once more in phase_kernel_wt's order (inference on tables of a few thousand rows and up; the training
+        // step's re-packs leave it stale and its forward passes never read it)
+        if (fmt == 2 && d.n_lin == 3 && jobs.N[0] == 512 && jobs.K[1] == 512 && jobs.N[1] == 512 && naqs::env_int("NAQS_PHASE_WT", 0) != 0) {
+            if (!net->d_wt) HIP_TRY(hipMalloc((void **)&net->d_wt, (size_t)2 * 512 * 512 * sizeof(unsigned short)));
+            NAQS_KLAUNCH(pack_wt_kernel, dim3(256), dim3(256), 0, s, flat_dev + jobs.src_off[1], net->d_scales, net->d_wt);
+            HIP_TRY(hipGetLastError());
+            net->have_wt = true;
+        }
     } else if (mode == PACK_AMP) {
         NAQS_KLAUNCH(pack_net_kernel, dim3(std::min(256, (amp_biggest + 255) / 256), gy_amp), dim3(256), 0, s, flat_dev, d, so, jobs, wb, net->d_w,
                            net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u, net->ctl);
@@ -2272,20 +2675,35 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         const int64_t tiles = (M + 16 * rbs - 1) / (16 * rbs);
         if (2 * tiles <= net->cu_count && rbs * lds_h16 + (size_t)d.P * rbs * 16 * 8 * sizeof(float) <= 155 * 1024) { ws_split = true; rb = rbs; }
     }
+    // NAQS_PHASE_WT=1 (off by default: measured no faster — see the kernel's header): tables between the two take the transposed
+    // big layer (phase_kernel_wt: 80-row tiles, two workgroups per tile, layer 0 just in time) while one round of workgroups covers
+    // the table; 2: whatever the size.  The variable must be set when the weights are packed (naqs_net_set_weights).
+    const int wt_mode = naqs::env_int("NAQS_PHASE_WT", 0);
+    const int64_t wt_tiles = (M + 16 * WT_NT - 1) / (16 * WT_NT);
+    const bool wt = ws && !ws_split && wt_mode != 0 && save.x == nullptr && amp_in_phase && net->have_wt && net->d_wt != nullptr &&
+                    (wt_mode == 2 || 2 * wt_tiles <= net->cu_count);
     const int bm = rb * 16;
     const unsigned grid = (unsigned)((M + bm - 1) / bm);
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
     WsSplit split{nullptr, 0u, net->ctl};
-    if (ws_split) {
-        const size_t words = (size_t)(net->cu_count / 2) * (48 * 4 + MAXP * 48);      // per tile (of up to 48 rows): partial rows + the producer's conditionals
+    if (ws_split || wt) {
+        // per tile (of up to 80 rows): partial rows + the producer's conditionals
+        const size_t tiles_cap = std::max<size_t>((size_t)(net->cu_count / 2), wt ? (size_t)wt_tiles : 0);
+        const size_t words = tiles_cap * (16 * WT_NT * 4 + MAXP * 16 * WT_NT);
+        if (net->d_ws_xchg && net->ws_xchg_words < words) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(net->d_ws_xchg);
+            net->d_ws_xchg = nullptr;
+        }
+        net->ws_xchg_words = std::max(net->ws_xchg_words, words);
         if (!net->d_ws_xchg) {
-            HIP_TRY(hipMalloc((void **)&net->d_ws_xchg, words * sizeof(unsigned long long)));
-            HIP_TRY(hipMemset(net->d_ws_xchg, 0, words * sizeof(unsigned long long)));      // tag 0 = never written
+            HIP_TRY(hipMalloc((void **)&net->d_ws_xchg, net->ws_xchg_words * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(net->d_ws_xchg, 0, net->ws_xchg_words * sizeof(unsigned long long)));      // tag 0 = never written
             HIP_TRY(hipDeviceSynchronize());               // (a null-stream fill is not ordered against the callers' streams)
             net->ws_seq = 0;
         }
         if (++net->ws_seq == 0u) {                         // the 32-bit call tag is about to repeat: forget every old word
-            HIP_TRY(hipMemsetAsync(net->d_ws_xchg, 0, words * sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(net->d_ws_xchg, 0, net->ws_xchg_words * sizeof(unsigned long long), s));
             net->ws_seq = 1u;
         }
         split.xchg = net->d_ws_xchg;
@@ -2293,12 +2711,20 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     }
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
-    if (ws) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_ws<RB=%d, SAVE=%d%s> (f16x2%s)", rb,
+    if (wt) {
+        std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_wt<80 rows x 256 units> (f16x2, transposed big layer, amplitude waves beside)");
+        const size_t lds = (size_t)WT_RING * 2 * WT_NT * 64 * 16 + (size_t)d.P * 16 * WT_NT * 8 * sizeof(float);
+        const int dbg = naqs::env_int("NAQS_WT_DEBUG", 0);           // developer aid (timing only, wrong results): 1 = no big-layer MFMAs, 2 = no layer-0 MFMAs
+        if (dbg == 1) NAQS_KLAUNCH((phase_kernel_wt<1>), dim3((unsigned)(2 * wt_tiles)), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, net->d_wt, M, keys_dev, out, feed, wamp, net->d_scales, split, save_dbg);
+        else if (dbg == 2) NAQS_KLAUNCH((phase_kernel_wt<2>), dim3((unsigned)(2 * wt_tiles)), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, net->d_wt, M, keys_dev, out, feed, wamp, net->d_scales, split, save_dbg);
+        else NAQS_KLAUNCH((phase_kernel_wt<0>), dim3((unsigned)(2 * wt_tiles)), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, net->d_wt, M, keys_dev, out, feed, wamp, net->d_scales, split, save_dbg);
+    } else if (ws) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_ws<RB=%d, SAVE=%d%s> (f16x2%s)", rb,
                           save.x != nullptr ? 1 : 0, ws_split ? ", SPLIT=1" : "", amp_in_phase ? ", amplitude waves beside the matrix waves" : "");
     else if (use_h) std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel_h<RB=%d, SAVE=%d, FMT=%d (%s)>%s", rb, save.x != nullptr ? 1 : 0,
                              fmt, fmt == 2 ? "f16x2" : "bf16x3", amp_in_phase ? " incl. amplitude prologue" : "");
     else std::snprintf(net->last_kernel, sizeof(net->last_kernel), "phase_kernel<RB=%d> (f32 MFMA)", rb);
-    if (ws) {
+    if (wt) {
+    } else if (ws) {
         const size_t lds = rb * lds_h16 + (size_t)d.P * bm * 8 * sizeof(float);
         const int flags = naqs::env_int("NAQS_WS_FLAGS", 0);
 #define NAQS_WS_LAUNCH(RB)                                                                                                              \

@@ -189,7 +189,10 @@ struct naqs_net {
     int packed_fmt = 0;                     // split format of d_wh: 1 = three bf16 planes, 2 = two scaled f16 planes
     naqs::PhaseRaw *d_raw = nullptr;        // partial weight maxima of the phase layers (net_bounds_kernel -> pack_net_kernel)
     naqs::PhaseScales *d_scales = nullptr;  // the f16x2 scales of the current weights
-    unsigned long long *d_ws_xchg = nullptr;   // phase_kernel_ws<.., SPLIT>: the producers' partial rows (tag << 32 | float), [cu_count / 2][64]
+    unsigned short *d_wt = nullptr;            // the big layer's planes in phase_kernel_wt's order (W1's contraction index permuted per chunk)
+    bool have_wt = false;                      // ... packed from the current parameters (naqs_net_set_weights packs them; a training step's re-pack does not)
+    unsigned long long *d_ws_xchg = nullptr;
+    size_t ws_xchg_words = 0;   // phase_kernel_ws<.., SPLIT>: the producers' partial rows (tag << 32 | float), [cu_count / 2][64]
     uint32_t ws_seq = 0;                       // call tag of the last split launch (0 = no word written yet)
     unsigned long long *d_sum_words = nullptr; // vmc_seed_delta_kernel<true>: the four weighted sums as eight tagged words (tag << 32 | half a double)
     uint32_t sums_seq = 0;

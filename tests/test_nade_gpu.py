@@ -478,3 +478,38 @@ def test_big_layer_shared_by_two_workgroups_agrees_with_one(monkeypatch):
                 continue
             scale = float(b.abs().max()) + 1e-12
             assert float((a - b).abs().max()) < 1e-5 * scale + 1e-10, (M, pname)
+
+
+def test_transposed_big_layer_kernel_agrees(monkeypatch):
+    """phase_kernel_wt (NAQS_PHASE_WT=1, off by default: measured no faster): the big layer as H1^T = W1 . H0^T in 80-row tiles
+    shared by two workgroups, layer 0's chunks produced just in time by the amplitude waves into an LDS ring.  Same products,
+    another summation order inside an MFMA and in the output layer: log|psi| bit-identical to the default kernel, phase to the
+    last bits, both <= 2e-5 of the PyTorch modules — also on a table that is not a multiple of the tile, and chained into E_loc."""
+    import os
+    from test_nade import make_wf
+    from naqs_amd import hamiltonian, packing
+    from naqs_amd.fused import FusedLogPsi
+    z = golden("nade_N2.npz")
+    hil, wf = make_wf("N2", z, device="cuda")
+    rs = np.random.RandomState(3)
+    space = np.array(sorted(set(z["samp_keys"].astype(np.int64).tolist()) | set(z["eval_keys"].astype(np.int64).tolist())))
+    keys_np = np.sort(rs.choice(space, min(len(space), 4171), replace=False))
+    keys = hamiltonian.keys_to_device(keys_np, wf.device)
+    ref = FusedLogPsi(wf)
+    lp0 = ref.log_psi(keys).clone()
+    assert "phase_kernel_ws" in ref.last_kernel()
+    monkeypatch.setenv("NAQS_PHASE_WT", "1")
+    fused = FusedLogPsi(wf)                                   # (packs the transposed copy of the big layer)
+    lp1 = fused.log_psi(keys).clone()
+    assert "phase_kernel_wt" in fused.last_kernel(), fused.last_kernel()
+    with torch.no_grad():
+        lp_t = wf.log_psi(hil.idx2state(torch.as_tensor(keys_np, device="cuda")))
+    assert torch.equal(lp0[:, 0], lp1[:, 0])
+    assert torch.max(torch.abs(lp1 - lp_t)).item() < 2e-5 and torch.max(torch.abs(lp1[:, 1] - lp0[:, 1])).item() < 2e-6
+    ham = hamiltonian.DevicePauliHamiltonian(packing.load_packed(os.path.join(GOLDEN, "ham_N2.npz")))
+    lp2, e2 = fused.log_psi_and_local_energy(ham, keys)
+    e_ref = ham.local_energy(keys, lp1, kind="log_psi")
+    torch.cuda.synchronize()
+    assert torch.equal(lp2, lp1) and torch.equal(e2, e_ref)
+    for _ in range(3):                                        # the call tag of the hand-over words moves on
+        assert torch.equal(fused.log_psi(keys), lp1)
