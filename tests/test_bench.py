@@ -29,6 +29,13 @@ def test_bench_imports_and_workload_is_deterministic():
     assert len(np.unique(k1)) == 10000 and np.all(np.diff(k1.astype(np.int64)) > 0)
     # B_alg(M) = M (40 + 24 Kxy) + 16 K + 12 Kxy = 91.16 MB for N2 at M = 10 000
     assert bench.algorithmic_bytes(10000, 2239, 378) == 10000 * (40 + 24 * 378) + 16 * 2239 + 12 * 378 == 91160360
+    # the log-psi roofline carries both views of the same clock: executed 16-bit flops (`frac`) and the network's own
+    # f32 flops (`algorithmic_frac`), both against the dense f16 MFMA peak — the split's 3x separates them
+    roof = bench.logpsi_roofline("phase_kernel_ws<3, false, false> [f16x2 + amplitude]", 23.48e-6, 20, 10000, True, 23.48e-6)
+    assert roof["algorithmic_flops_per_launch"] == bench.logpsi_flops(20, 10000, True)
+    assert roof["algorithmic_frac"] == pytest.approx(roof["algorithmic_flops_per_launch"] / 23.48e-6 / 1e12 / bench.MFMA_BF16_PEAK_TF)
+    assert roof["algorithmic_frac"] < roof["frac"] < 3.0 * roof["algorithmic_frac"] * 1.01
+    assert roof["isolated"]["algorithmic_frac"] == pytest.approx(roof["algorithmic_frac"])
 
 
 def test_li2o_batch_and_row_shards():
