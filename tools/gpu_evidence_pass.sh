@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round evidence on ONE GPU box: full gpu suite, headline bench (default, driver-like, Li2O row-sharded, RCCL world 1), rocprof
 # kernel stats, PMC passes (each stamped with the library's source hash), scaling models, training-step profile, 10 000-step
-# training runs with the reference's flags.  usage: ROUND=r04 bash tools/gpu_evidence_pass.sh   -> gpurun_out/$ROUND/
-ROUND=${ROUND:-r04}
+# training runs with the reference's flags.  usage: ROUND=r05 bash tools/gpu_evidence_pass.sh   -> gpurun_out/$ROUND/
+ROUND=${ROUND:-r05}
 R=$PWD; G=$R/gpurun_out/$ROUND; mkdir -p $G
 HASH=$(python -c "import sys; sys.path.insert(0, 'naqs-for-quantum-chemistry_amd'); from naqs_amd import _lib; print(_lib.load_library().naqs_source_hash().decode())")
 echo "library source hash: $HASH" | tee $G/source_hash.txt
@@ -54,4 +54,6 @@ for mol in N2_1.95 N2_2.25; do
   cp /tmp/train_${mol}_full_mask_psi/summary.txt $G/train_${mol}_summary.txt
 done
 cd $R
-tail -c 400 $G/bench.log; echo; for m in H2O N2 N2_default Li2O N2_1.95 N2_2.25; do grep "training time\|final <E_loc>\|error to FCI" $G/train_${m}_summary.txt | tr '\n' ' '; echo; done; cat $G/train_step_timing.txt | grep steps
+# BASELINE config 5 through the farm: 33 runs of 10 000 steps on this one GPU
+ROUND=$ROUND bash tools/n2_sweep.sh > /dev/null 2>&1
+tail -c 400 $G/bench.log; echo; for m in H2O N2 N2_default Li2O N2_1.95 N2_2.25; do grep "training time\|final <E_loc>\|error to FCI" $G/train_${m}_summary.txt | tr '\n' ' '; echo; done; cat $G/train_step_timing.txt | grep steps; tail -1 $G/n2_sweep.txt
