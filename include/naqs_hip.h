@@ -249,6 +249,12 @@ int naqs_net_prof_select(naqs_net_t *net, int which);
 /* Kernel launches this library has issued in this process so far (all handles, all streams): bench.py's `launches per step`
  * is the difference over a timed region divided by its steps.  No counterpart in the reference. */
 int64_t naqs_launch_count(void);
+/* naqs_vmc_step / naqs_vmc_run launch the training forward behind the sampler's launches, BEFORE the host knows the number of
+ * unique samples M (the kernel reads M on the device; the launch covers the last accepted draw's M plus an eighth in the kernel
+ * form that M gets), and launch it again the ordinary way when the real M does not fit that launch or gets another form — the
+ * same kernel on the same rows either way.  counts[0] = forwards launched ahead, counts[1] = of those, the ones that stood.
+ * NAQS_SPEC_FORWARD=0: never ahead.  No counterpart in the reference (its loop is synchronous: energy.py:975-998). */
+int naqs_net_spec_counts(const naqs_net_t *net, int64_t counts[2]);
 /* Name of the log-psi kernel the most recent naqs_net_logpsi / naqs_logpsi_eloc / training forward launched. */
 int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len);
 

@@ -1225,7 +1225,13 @@ __device__ __forceinline__ void ws_amp_work(const NetDims &d, const ushort_t *__
 // sampler's look-back words, naqs_sample.hip); the consumer adds the partial rows last:
 // ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)), a fixed order, but not the unsplit kernel's (last-bit differences of the
 // phase between the two forms; every other value — log|psi|, saved activations — is the same).
-struct WsSplit { unsigned long long *xchg; uint32_t tag; const naqs::PollCtl *ctl; };
+struct WsSplit {
+    unsigned long long *xchg; uint32_t tag; const naqs::PollCtl *ctl;
+    // naqs::SpecRows (launched before the host knew the row count): M = U[MAXP + 1] ? 0 : U[P]; nullptr: M is the argument.
+    // fin.U != nullptr: workgroup 0 is the sampler's finish job and the tiles start at workgroup 1.
+    const int64_t *spec_U; int spec_P;
+    naqs::SampleFinishJob fin;
+};
 
 template <int RB, bool SAVE, bool SPLIT = false>
 __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, const float *__restrict__ w,
@@ -1247,10 +1253,21 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     constexpr int FMT = 2, NP = 2;
     constexpr int AW = PH_WAVES - WS_MW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
-    const int n_tiles = SPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
-    const bool producer = SPLIT && (int)blockIdx.x < n_tiles;                   // (workgroup-uniform)
-    const int tile = SPLIT && !producer ? (int)blockIdx.x - n_tiles : (int)blockIdx.x;
+    const int hosted = split.fin.U != nullptr ? 1 : 0;    // (launch-uniform)
+    if (hosted && blockIdx.x == 0) {                      // the sampler's finish job rides in this launch (naqs_net.hpp)
+        __shared__ int64_t s_fin[16];
+        naqs::sample_finish_body(split.fin, s_fin);
+        return;
+    }
+    const int bx = (int)blockIdx.x - hosted;
+    const int n_tiles = SPLIT ? (int)((gridDim.x - hosted) >> 1) : (int)gridDim.x - hosted;
+    const bool producer = SPLIT && bx < n_tiles;                                // (workgroup-uniform)
+    const int tile = SPLIT && !producer ? bx - n_tiles : bx;
     const int64_t row0 = (int64_t)tile * BM;
+    if (split.spec_U != nullptr) {                        // launched ahead of the host's look at the sampler's M (workgroup-uniform)
+        M = split.spec_U[MAXP + 1] != 0 ? 0 : split.spec_U[split.spec_P];
+        if (row0 >= M) return;                            // (both halves of a shared tile leave)
+    }
     const int P = d.P, ldh = d.ldh;
     float *s_o = reinterpret_cast<float *>(planes + (size_t)NP * BM * ldh);     // [P][BM][8] raw outputs of the items
     const bool ha64 = d.Ha == 64;
@@ -2613,8 +2630,55 @@ static int agg_logpsi(naqs_net *net, int64_t M, const uint64_t *keys_dev, float 
     return NAQS_OK;
 }
 
+// which form of the log-psi kernel M rows get (net_logpsi_impl; naqs::net_logpsi_form for callers that must know in advance)
+struct FormSel { bool ws = false, ws_split = false; int rb = 1; };
+static FormSel select_form(const naqs_net *net, const int64_t M, const int fmt, const size_t lds_h16, const int rb_max) {
+    const NetDims &d = net->dims;
+    FormSel f;
+    // wave-specialised form (phase_kernel_ws): the published shape in the f16x2 format, tiles of up to 48 rows
+    const bool ws_shape = fmt == 2 && d.n_lin == 3 && d.N_pad[0] == PH_WAVES * CBT * 16 && d.N_pad[1] == WS_MW * WS_NCT * 16 &&
+                          d.Kh_pad[0] == 32 && d.N_pad[2] == 16 && (d.Ha == 64 || d.Ha == 32) && CBT == 4 && PH_WAVES == 8;
+    const int ws_mode = naqs::env_int("NAQS_PHASE_WS", 1);
+    int rb = naqs::env_int("NAQS_PHASE_RB", 0);
+    if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
+    bool ws = ws_shape && ws_mode != 0;
+    if (ws) {
+        const int rb_ws = std::min(rb, 3);
+        if (rb_ws * lds_h16 + (size_t)d.P * rb_ws * 16 * 8 * sizeof(float) > 155 * 1024) ws = false;
+        else rb = rb_ws;
+    }
+    // small tables: two workgroups per tile share the big layer (phase_kernel_ws<RB, SAVE, true>) while both halves of every
+    // tile are resident together, one workgroup per CU; NAQS_WS_SPLIT=0: never; NAQS_WS_SPLIT_RB: the tile height of that form
+    bool ws_split = false;
+    if (ws && naqs::env_int("NAQS_WS_SPLIT", 1) != 0) {
+        int rbs = naqs::env_int("NAQS_WS_SPLIT_RB", 0);
+        if (rbs < 1 || rbs > 3) rbs = 1;
+        const int64_t tiles = (M + 16 * rbs - 1) / (16 * rbs);
+        if (2 * tiles <= net->cu_count && rbs * lds_h16 + (size_t)d.P * rbs * 16 * 8 * sizeof(float) <= 155 * 1024) { ws_split = true; rb = rbs; }
+    }
+    f.ws = ws; f.ws_split = ws_split; f.rb = rb;
+    return f;
+}
+
+naqs::PhaseForm naqs::net_logpsi_form(const naqs_net *net, const int64_t M, const bool training) {
+    PhaseForm f;
+    const NetDims &d = net->dims;
+    if (net->aggregate) return f;
+    const int fmt = phase_format(d);
+    if (fmt == 0) return f;
+    const size_t lds_h16 = phase_slab_bytes(d, fmt);
+    const int rb_max = phase_rb_max(d, fmt);
+    const size_t amp_scratch = (size_t)d.P * rb_max * 16 * 8 * sizeof(float);
+    const bool amp_in_phase = net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
+                              amp_scratch <= 150 * 1024 && d.Ha <= 64;
+    const FormSel sel = select_form(net, M, fmt, lds_h16, rb_max);
+    const bool wt = sel.ws && !sel.ws_split && !training && naqs::env_int("NAQS_PHASE_WT", 0) != 0;
+    f.kind = (sel.ws && amp_in_phase && !wt) ? 1 : 0; f.rb = sel.rb; f.split = sel.ws_split ? 1 : 0;
+    return f;
+}
+
 int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
-                          const ElocFeed &feed, const PhaseSave &save) {
+                          const ElocFeed &feed, const PhaseSave &save, const SpecRows *spec) {
     if (!net || M < 0 || (M > 0 && (!keys_dev || !logpsi_dev))) return NAQS_ERR_INVALID;
     if (!net->have_weights) return NAQS_ERR_INVALID;
     if (M == 0) return NAQS_OK;
@@ -2638,6 +2702,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const size_t amp_scratch = (size_t)d.P * rb_max * 16 * 8 * sizeof(float);          // [P][BM][8] raw outputs of the items
     const bool amp_in_phase = use_h && net->d_wamp != nullptr && net->wamp_fresh && naqs::env_int("NAQS_AMP_MODE", 1) == 1 &&
                               amp_scratch <= 150 * 1024 && d.Ha <= 64;      // (128-unit blocks: two fragment sets do not fit the prologue's registers)
+    if (spec && !(amp_in_phase && save.x != nullptr && select_form(net, spec->m_var, fmt, lds_h16, rb_max).ws)) return NAQS_ERR_UNSUPPORTED;
     if (!amp_in_phase) {
         st = naqs::net_amp_forward(net, M, keys_dev, s, &feed);
         if (st != NAQS_OK) return st;
@@ -2654,27 +2719,10 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     // rows per workgroup: fill the CUs once if possible (16-row granularity of the MFMA tile)
     if (save.x != nullptr && !use_h) return NAQS_ERR_UNSUPPORTED;             // activations are saved by the split kernels only
     if (!use_h && !net->packed_f32) return NAQS_ERR_INVALID;
-    // wave-specialised form (phase_kernel_ws): the published shape in the f16x2 format, tiles of up to 48 rows
-    const bool ws_shape = fmt == 2 && d.n_lin == 3 && d.N_pad[0] == PH_WAVES * CBT * 16 && d.N_pad[1] == WS_MW * WS_NCT * 16 &&
-                          d.Kh_pad[0] == 32 && d.N_pad[2] == 16 && (d.Ha == 64 || d.Ha == 32) && CBT == 4 && PH_WAVES == 8;
-    const int ws_mode = naqs::env_int("NAQS_PHASE_WS", 1);
-    int rb = naqs::env_int("NAQS_PHASE_RB", 0);
-    if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
-    bool ws = ws_shape && ws_mode != 0;
-    if (ws) {
-        const int rb_ws = std::min(rb, 3);
-        if (rb_ws * lds_h16 + (size_t)d.P * rb_ws * 16 * 8 * sizeof(float) > 155 * 1024) ws = false;
-        else rb = rb_ws;
-    }
-    // small tables: two workgroups per tile share the big layer (phase_kernel_ws<RB, SAVE, true>) while both halves of every
-    // tile are resident together, one workgroup per CU; NAQS_WS_SPLIT=0: never; NAQS_WS_SPLIT_RB: the tile height of that form
-    bool ws_split = false;
-    if (ws && naqs::env_int("NAQS_WS_SPLIT", 1) != 0) {
-        int rbs = naqs::env_int("NAQS_WS_SPLIT_RB", 0);
-        if (rbs < 1 || rbs > 3) rbs = 1;
-        const int64_t tiles = (M + 16 * rbs - 1) / (16 * rbs);
-        if (2 * tiles <= net->cu_count && rbs * lds_h16 + (size_t)d.P * rbs * 16 * 8 * sizeof(float) <= 155 * 1024) { ws_split = true; rb = rbs; }
-    }
+    // (a speculative launch, naqs::SpecRows: the form of m_var rows on a grid that covers M)
+    const FormSel sel = select_form(net, spec ? spec->m_var : M, fmt, lds_h16, rb_max);
+    const bool ws = sel.ws, ws_split = sel.ws_split;
+    const int rb = sel.rb;
     // NAQS_PHASE_WT=1 (off by default: measured no faster — see the kernel's header): tables between the two take the transposed
     // big layer (phase_kernel_wt: 80-row tiles, two workgroups per tile, layer 0 just in time) while one round of workgroups covers
     // the table; 2: whatever the size.  The variable must be set when the weights are packed (naqs_net_set_weights).
@@ -2685,10 +2733,14 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     const int bm = rb * 16;
     const unsigned grid = (unsigned)((M + bm - 1) / bm);
     float2 *out = reinterpret_cast<float2 *>(logpsi_dev);
-    WsSplit split{nullptr, 0u, net->ctl};
+    WsSplit split{nullptr, 0u, net->ctl, spec ? spec->U : nullptr, spec ? spec->P : 0, naqs::SampleFinishJob{}};
+    const bool host_fin = spec && spec->host_finish && net->fin_pending && !wt;
+    if (host_fin) split.fin = net->fin_job;
+    const unsigned hosted = host_fin ? 1u : 0u;
     if (ws_split || wt) {
-        // per tile (of up to 80 rows): partial rows + the producer's conditionals
-        const size_t tiles_cap = std::max<size_t>((size_t)(net->cu_count / 2), wt ? (size_t)wt_tiles : 0);
+        // per tile (of up to 80 rows): partial rows + the producer's conditionals  (a speculative launch of the split form may
+        // cover more tiles than the form is chosen for: its words exist all the same)
+        const size_t tiles_cap = std::max<size_t>(std::max<size_t>((size_t)(net->cu_count / 2), wt ? (size_t)wt_tiles : 0), ws_split ? (size_t)grid : 0);
         const size_t words = tiles_cap * (16 * WT_NT * 4 + MAXP * 16 * WT_NT);
         if (net->d_ws_xchg && net->ws_xchg_words < words) {
             HIP_TRY(hipDeviceSynchronize());
@@ -2709,6 +2761,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         split.xchg = net->d_ws_xchg;
         split.tag = net->ws_seq;
     }
+    net->last_form_kind = (ws && amp_in_phase && !wt) ? 1 : 0; net->last_form_rb = rb; net->last_form_split = ws_split ? 1 : 0;
     const bool prof = net->prof.armed();
     if (prof) { st = net->prof.begin(s); if (st != NAQS_OK) return st; }
     if (wt) {
@@ -2729,13 +2782,13 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         const int flags = naqs::env_int("NAQS_WS_FLAGS", 0);
 #define NAQS_WS_LAUNCH(RB)                                                                                                              \
         do {                                                                                                                            \
-            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_ws<RB, true>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
-            else NAQS_KLAUNCH((phase_kernel_ws<RB, false>), dim3(grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_ws<RB, true>), dim3(grid + hosted), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            else NAQS_KLAUNCH((phase_kernel_ws<RB, false>), dim3(grid + hosted), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
         } while (0)
 #define NAQS_WS_LAUNCH_SPLIT(RB)                                                                                                        \
         do {                                                                                                                            \
-            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_ws<RB, true, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
-            else NAQS_KLAUNCH((phase_kernel_ws<RB, false, true>), dim3(2 * grid), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            if (save.x != nullptr) NAQS_KLAUNCH((phase_kernel_ws<RB, true, true>), dim3(2 * grid + hosted), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
+            else NAQS_KLAUNCH((phase_kernel_ws<RB, false, true>), dim3(2 * grid + hosted), dim3(PH_THREADS), lds, s, d, net->d_w, net->d_wh, M, keys_dev, net->d_scratch, out, feed, save_dbg, wamp, net->d_scales, flags, split); \
         } while (0)
         if (ws_split) {
             switch (rb) {
@@ -2752,6 +2805,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
         }
 #undef NAQS_WS_LAUNCH_SPLIT
 #undef NAQS_WS_LAUNCH
+        if (hosted) net->fin_pending = false;             // (workgroup 0 of that launch is the sampler's finish job)
     } else if (use_h) {
         const size_t lds = std::max(rb * lds_h16, amp_in_phase ? amp_scratch : (size_t)0);
 #define NAQS_PH_LAUNCH(RB, FMT)                                                                                                         \

@@ -154,6 +154,55 @@ __device__ __forceinline__ float amp_finish(const NetDims &d, int NB, const floa
     return occ == 0 ? la[0] : (occ == 1 ? la[1] : (occ == 2 ? la[2] : la[3]));
 }
 
+// The sampler's last launch — (M, overflow) for the caller and the polling host, the level sizes as hints for the next call,
+// the weights counts / sum(counts) (energy.py:993) — described as a job: naqs_sample.hip launches it as sample_finish_kernel,
+// or leaves it pending for a launch of the caller's that can host it (the training forward launched ahead of M).
+struct SampleFinishJob {
+    const int64_t *U = nullptr;             // level sizes U[0..P], overflow flag U[MAXP + 1]
+    int P = 0;
+    int64_t *info = nullptr;                // (M, overflow) on the device
+    const int64_t *counts = nullptr;
+    double *weights = nullptr;              // nullptr: no weights
+    int64_t *early = nullptr;               // mapped host words (publish_info); nullptr: none
+    int64_t seq = 0;
+    int64_t *levels_out = nullptr;
+};
+#if defined(__HIPCC__)
+// (M, overflow) for a host that polls mapped memory (naqs_vmc_step): system-scope stores, the call's sequence number last —
+// the host waits for ITS number, so words left by an earlier call are never mistaken for this one's.
+__device__ __forceinline__ void publish_info(int64_t *early, const int64_t M, const int64_t overflow, const int64_t seq) {
+    __hip_atomic_store(&early[0], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&early[1], overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&early[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one workgroup of blockDim.x threads (a multiple of 64, <= 1024); s_part: 16 int64 of LDS.  The integer total is exact
+// whatever the summation order, so the weights do not depend on the workgroup's size.
+__device__ __forceinline__ void sample_finish_body(const SampleFinishJob &j, int64_t *s_part) {
+    const int nt = (int)blockDim.x;
+    const int64_t overflow = j.U[MAXP + 1];
+    const int64_t M = overflow ? 0 : j.U[j.P];
+    if (threadIdx.x == 0) {
+        j.info[0] = M;
+        j.info[1] = overflow;
+        if (j.early != nullptr) publish_info(j.early, M, overflow, j.seq);
+    }
+    // the level sizes of this draw, for the host's choice of launches in the NEXT call (a hint: mapped memory it reads
+    // without synchronising)
+    if (j.levels_out != nullptr && (int)threadIdx.x <= j.P) j.levels_out[threadIdx.x] = j.U[threadIdx.x];
+    if (j.weights == nullptr) return;
+    int64_t part = 0;
+    for (int64_t i = threadIdx.x; i < M; i += nt) part += j.counts[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    int64_t total = 0;
+    for (int i = 0; i < nt / WAVE; ++i) total += s_part[i];
+    const double tot = (double)total;
+    for (int64_t i = threadIdx.x; i < M; i += nt) j.weights[i] = (double)j.counts[i] / tot;
+}
+#endif
+
 }  // namespace naqs
 
 struct naqs_net {
@@ -227,6 +276,13 @@ struct naqs_net {
     bool phase_pending = false;             // side_stream work the caller's stream has not been ordered behind yet
     hipEvent_t ev_phase_done = nullptr;
     hipStream_t pack_stream = nullptr;      // the stream whose work (the update) a pending re-pack must follow
+    // naqs_vmc_step: the training forward launched ahead of the host's look at M (naqs::SpecRows)
+    int64_t spec_hint = 0;                  // unique samples of the last accepted draw (0: none yet)
+    int last_form_kind = 0, last_form_rb = 0, last_form_split = 0;      // what net_logpsi_impl launched last
+    int64_t spec_launched = 0, spec_hits = 0;                           // naqs_net_spec_counts
+    bool hold_finish = false;               // in: the sampler leaves its finish job pending (fin_job) instead of launching it
+    bool fin_pending = false;               // a finish job nobody has launched or hosted yet (naqs::net_sample_finish_flush)
+    naqs::SampleFinishJob fin_job{};
 };
 
 namespace naqs {
@@ -239,9 +295,20 @@ struct PhaseSave {
     int act_ld[MAXL] = {};
     long long *clk = nullptr;               // NAQS_DEBUG_CLOCKS=1: [8 waves][16 marks] cycle counter of workgroup 0
 };
+// A forward pass launched BEFORE the host knows the table's size (naqs_vmc_step: behind the sampler's launches, while the host
+// still polls for M): the kernel reads the row count from the sampler's level sizes `U` (U[P], or 0 when the overflow word
+// U[MAXP + 1] is set; with host_finish the launch's first workgroup is the sampler's finish job, net->fin_job), the launch covers M rows (the
+// caller's upper estimate) and the kernel form is the one `m_var` rows would get — the caller checks afterwards that the real M
+// gets the same form and fits the launch, and launches again the ordinary way if not.  Only the wave-specialised form takes it
+// (net_logpsi_impl returns NAQS_ERR_UNSUPPORTED otherwise, before launching anything).
+struct SpecRows { const int64_t *U = nullptr; int P = 0; int64_t m_var = 0; bool host_finish = false; };
+// the log-psi kernel form net_logpsi_impl chose last / would choose for M rows (kind: 0 other, 1 phase_kernel_ws)
+struct PhaseForm { int kind = 0, rb = 0, split = 0; };
+inline bool operator==(const PhaseForm &a, const PhaseForm &b) { return a.kind == b.kind && a.rb == b.rb && a.split == b.split; }
 // naqs_logpsi.hip: amp_kernel + phase kernel -> (log|psi|, phase)
 int net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, float *logpsi_dev, void *stream,
-                    const ElocFeed &feed, const PhaseSave &save);
+                    const ElocFeed &feed, const PhaseSave &save, const SpecRows *spec = nullptr);
+PhaseForm net_logpsi_form(const naqs_net *net, int64_t M, bool training);
 // naqs_phase_grad.hip: row-major padded copies of the phase weights for the backward GEMMs — described as jobs for the
 // one packing launch of naqs_net_set_weights (allocates the destination on first use)
 struct WbPackJobs {
@@ -300,6 +367,7 @@ __device__ __forceinline__ void adam_update(const AdamArgs &a, const int64_t i, 
 }
 #endif
 // naqs_sample.hip
+int net_sample_finish_flush(naqs_net *net, hipStream_t s);      // launch a pending finish job as a kernel of its own (no-op if none)
 int net_info_alloc(naqs_net *net);
 int net_sample_early(naqs_net *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev, int64_t *counts_dev,
                      float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream, int64_t *early, int64_t seq);

@@ -729,9 +729,13 @@ static inline void cpu_relax() {
     std::this_thread::yield();
 #endif
 }
+struct AfterSampler {          // what the caller queues behind the sampler's launches before the host starts waiting for M
+    virtual int operator()() = 0;  // (the sampler's finish job is still pending — net->fin_job — and may ride in what is queued here)
+    virtual ~AfterSampler() = default;
+};
 static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
                            int64_t *counts_dev, float *probs_dev, double *weights_dev, hipStream_t s, int64_t out[2],
-                           int64_t *info_dev = nullptr) {
+                           int64_t *info_dev = nullptr, AfterSampler *after = nullptr) {
     // info_dev: where the sampler leaves its plain (M, overflow) words on the device (default: the handle's own two words)
     static const bool spin = [] { const char *e = getenv("NAQS_SPIN_WAIT"); return !e || atoi(e) != 0; }();
     int st0 = naqs::net_info_alloc(net);
@@ -739,11 +743,19 @@ static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const int64_t seq = ++net->info_seq;
     const bool prof = net->prof_samp.armed();              // (bench.py's train_step.sampler_us: every stride-th step)
     if (prof) { int stp = net->prof_samp.begin(s); if (stp != NAQS_OK) return stp; }
+    net->hold_finish = after != nullptr;
     int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev,
                                     info_dev ? info_dev : net->d_info2, s,
                                     net->d_info_alias, seq);
+    net->hold_finish = false;
     if (st != NAQS_OK) return st;
     if (prof) { int stp = net->prof_samp.end(s); if (stp != NAQS_OK) return stp; }
+    if (after) {
+        st = (*after)();
+        const int st2 = naqs::net_sample_finish_flush(net, s);     // (nobody hosted the finish job: a launch of its own)
+        if (st != NAQS_OK) return st;
+        if (st2 != NAQS_OK) return st2;
+    }
     volatile int64_t *h = net->h_info;
     if (spin) {
         // bounded: after ~2 s of polling (a sampler call is < 1 ms) the wait falls back to the stream's own completion signal
@@ -1064,17 +1076,67 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!net->have_weights) return NAQS_ERR_INVALID;
-    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info2);
+    // The training forward goes out BEHIND THE SAMPLER'S LAUNCHES, before the host knows M (NAQS_SPEC_FORWARD=0: after): between
+    // the sampler's last launch and a forward pass launched once M is known the GPU idled ~7 us per step (the store reaching
+    // the host, the launch reaching the GPU).  The kernel reads M on the device; the launch covers the last accepted draw's M
+    // plus an eighth (at least 64 rows) in the kernel form that M gets.  Once the host has M it checks that the real M gets
+    // the same form and fits the launch — otherwise (and after an abandoned draw, whose forward pass was for nothing) the
+    // ordinary launch follows and overwrites everything: the same kernel on the same rows either way, bit for bit.
+    struct SpecForward : AfterSampler {
+        naqs_net_t *net; naqs_ham_t *ham; hipStream_t s; const uint64_t *keys; float *logpsi; int64_t max_unique;
+        bool launched = false; int64_t rows = 0; naqs::ElocFeed feed{}; naqs::PhaseForm form;
+        int operator()() override {
+            const int64_t hint = net->spec_hint;
+            if (hint <= 0 || net->aggregate || !ham || !logpsi || naqs::env_int("NAQS_SPEC_FORWARD", 1) == 0) return NAQS_OK;
+            if (naqs::ham_device(ham) != net->device) return NAQS_OK;
+            int64_t cover = std::min<int64_t>(max_unique, hint + std::max<int64_t>(64, hint / 8));
+            if (naqs::env_int("NAQS_DEBUG_SPEC_SHRINK", 0) != 0) cover = std::max<int64_t>(16, hint / 2);      // (tests: a launch that does not fit)
+            form = naqs::net_logpsi_form(net, hint, /*training=*/true);
+            if (form.kind != 1) return NAQS_OK;
+            int st = ensure_train_scratch(net, cover);
+            if (st != NAQS_OK) return st;
+            const TrainLayout L = train_layout(net, net->train_cap);
+            char *base = static_cast<char *>(net->d_train);
+            naqs::PhaseSave save;
+            save.x = reinterpret_cast<float *>(base + L.x);
+            save.x_ld = L.x_ld;
+            for (int l = 0; l + 1 < net->dims.n_lin; ++l) {
+                save.act[l] = reinterpret_cast<float *>(base + L.act[l]);
+                save.act_ld[l] = L.act_ld[l];
+            }
+            st = naqs::eloc_begin(ham, cover, s, &feed);
+            if (st != NAQS_OK) return st;
+            naqs::SpecRows spec;
+            spec.U = net->fin_job.U; spec.P = net->fin_job.P; spec.m_var = hint;
+            spec.host_finish = naqs::env_int("NAQS_SPEC_HOST_FINISH", 1) != 0;
+            st = naqs::net_logpsi_impl(net, cover, keys, logpsi, s, feed, save, &spec);
+            if (st == NAQS_ERR_UNSUPPORTED) return NAQS_OK;            // (nothing was launched: the ordinary forward follows)
+            if (st != NAQS_OK) return st;
+            launched = true; rows = cover;
+            ++net->spec_launched;
+            return NAQS_OK;
+        }
+    } specf;
+    specf.net = net; specf.ham = ham; specf.s = s; specf.keys = keys_dev; specf.logpsi = logpsi_dev; specf.max_unique = max_unique;
+    st = sample_and_wait(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, s, info2, nullptr, &specf);
     if (st != NAQS_OK) return st;
     info_host[0] = info2[0]; info_host[1] = info2[1];
     const int64_t M = info2[0];
     if (info2[1] != 0 || M <= 0 || M < m_lo || M > m_hi) return NAQS_OK;        // abandoned: the caller adapts n_samples
+    net->spec_hint = M;
+    const bool spec_hit = specf.launched && M <= specf.rows && naqs::net_logpsi_form(net, M, true) == specf.form;
+    if (spec_hit) ++net->spec_hits;
     // small tables: the weighted sums of E_loc are formed by the first workgroup of the backward pass's seed kernel (same
     // arithmetic, same order: naqs_reduce.hpp) instead of by a launch between E_loc and the seeds (NAQS_FUSE_SUMS=0: the launch)
     const bool form_sums = !net->aggregate && net->dims.n_lin >= 2 && M <= SUMS_FUSE_MAX_ROWS && sums_dev != nullptr &&
                            net->d_sum_words != nullptr && naqs::env_int("NAQS_FUSE_SUMS", 1) != 0;
-    st = naqs_net_train_forward_eloc(net, ham, M, keys_dev, form_sums ? nullptr : weights_dev, logpsi_dev, eloc_dev,
-                                     form_sums ? nullptr : sums_dev, stream);
+    if (spec_hit) {
+        if (!eloc_dev || (!form_sums && (!weights_dev || !sums_dev))) return NAQS_ERR_INVALID;
+        st = naqs::eloc_main(ham, M, specf.feed, eloc_dev, form_sums ? nullptr : weights_dev, form_sums ? nullptr : sums_dev, s);
+    } else {
+        st = naqs_net_train_forward_eloc(net, ham, M, keys_dev, form_sums ? nullptr : weights_dev, logpsi_dev, eloc_dev,
+                                         form_sums ? nullptr : sums_dev, stream);
+    }
     if (st != NAQS_OK) return st;
     naqs::AdamArgs adam;
     if (adam_step >= 1) adam = naqs::adam_args(param_dev, exp_avg_dev, exp_avg_sq_dev, lr, beta1, beta2, eps, weight_decay, adam_step);
@@ -1112,6 +1174,12 @@ static inline uint64_t sample_seed(const uint64_t base, const int64_t call) {   
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
+}
+
+NAQS_API int naqs_net_spec_counts(const naqs_net_t *net, int64_t counts[2]) {
+    if (!net || !counts) return NAQS_ERR_INVALID;
+    counts[0] = net->spec_launched; counts[1] = net->spec_hits;
+    return NAQS_OK;
 }
 
 NAQS_API int naqs_vmc_run(naqs_net_t *net, naqs_ham_t *ham, int64_t n_steps, naqs_vmc_run_args_t *a, void *stream) {

@@ -76,15 +76,10 @@ __global__ void sample_init_kernel(SampleBufs b, int64_t n_samples) {
     }
 }
 
-// (M, overflow) for a host that polls mapped memory (naqs_vmc_step): system-scope stores, the call's sequence number last —
-// the host waits for ITS number, so words left by an earlier call are never mistaken for this one's.  Written as soon as the
-// size of the last level is known (the workgroup that closes the look-back chain), i.e. while the rest of that launch and the
-// weights launch are still running, and again by sample_finish_kernel (the paths that do not end in the fused level kernel).
-__device__ __forceinline__ void publish_info(int64_t *early, const int64_t M, const int64_t overflow, const int64_t seq) {
-    __hip_atomic_store(&early[0], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&early[1], overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&early[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// (publish_info — (M, overflow) for a host that polls mapped memory — is naqs_net.hpp's: written as soon as the size of the last
+// level is known (the workgroup that closes the look-back chain), i.e. while the rest of that launch and the weights launch are
+// still running, and again by the finish job (the paths that do not end in the fused level kernel).)
+using naqs::publish_info;
 
 // quad (4 consecutive lanes) sum: every lane of the quad gets the total
 __device__ __forceinline__ float quad_sum(float v) {
@@ -829,34 +824,11 @@ __global__ __launch_bounds__(SB) void sample_scatter_kernel(const NetDims d, con
 }
 
 // M and the overflow flag for the host; optionally the samples' weights counts / sum(counts) (energy.py:993) — the
-// integer total is exact whatever the summation order, so the weights are deterministic
+// integer total is exact whatever the summation order, so the weights are deterministic (naqs_net.hpp: sample_finish_body)
 constexpr int FIN_THREADS = 1024;
-__global__ __launch_bounds__(FIN_THREADS) void sample_finish_kernel(SampleBufs b, int P, int64_t *__restrict__ info,
-                                                                     const int64_t *__restrict__ counts,
-                                                                     double *__restrict__ weights, int64_t *__restrict__ early,
-                                                                     const int64_t seq, int64_t *__restrict__ levels_out) {
+__global__ __launch_bounds__(FIN_THREADS) void sample_finish_kernel(const naqs::SampleFinishJob j) {
     __shared__ int64_t s_part[FIN_THREADS / WAVE];
-    const int64_t overflow = b.U[MAXP + 1];
-    const int64_t M = overflow ? 0 : b.U[P];
-    if (threadIdx.x == 0) {
-        info[0] = M;
-        info[1] = overflow;
-        if (early != nullptr) publish_info(early, M, overflow, seq);
-    }
-    // the level sizes of this draw, for the host's choice of launches in the NEXT call (a hint: mapped memory it reads
-    // without synchronising)
-    if (levels_out != nullptr && (int)threadIdx.x <= P) levels_out[threadIdx.x] = b.U[threadIdx.x];
-    if (weights == nullptr) return;
-    int64_t part = 0;
-    for (int64_t i = threadIdx.x; i < M; i += FIN_THREADS) part += counts[i];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
-    __syncthreads();
-    int64_t total = 0;
-    for (int i = 0; i < FIN_THREADS / WAVE; ++i) total += s_part[i];
-    const double tot = (double)total;
-    for (int64_t i = threadIdx.x; i < M; i += FIN_THREADS) weights[i] = (double)counts[i] / tot;
+    naqs::sample_finish_body(j, s_part);
 }
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1048,9 +1020,15 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
         ++n;
         half ^= 1;
     }
-    NAQS_KLAUNCH(sample_finish_kernel, dim3(1), dim3(weights_dev ? FIN_THREADS : 64), 0, s, b, d.P, info_dev, counts_dev,
-                       weights_dev, early, seq, net->d_info_alias + 4);
-    HIP_TRY(hipGetLastError());
+    naqs::SampleFinishJob fin;
+    fin.U = b.U; fin.P = d.P; fin.info = info_dev; fin.counts = counts_dev; fin.weights = weights_dev; fin.early = early; fin.seq = seq;
+    fin.levels_out = net->d_info_alias + 4;
+    net->fin_job = fin;
+    net->fin_pending = true;
+    if (!net->hold_finish || clk_dev) {                    // (hold_finish: the caller's next launch hosts it, or the caller flushes)
+        st = naqs::net_sample_finish_flush(net, s);
+        if (st != NAQS_OK) return st;
+    }
     if (clk_dev) {
         long long h[MAXP * 12];
         HIP_TRY(hipMemcpy(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost));
@@ -1067,6 +1045,14 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
             std::fprintf(stderr, "\n");
         }
     }
+    return NAQS_OK;
+}
+
+int naqs::net_sample_finish_flush(naqs_net *net, hipStream_t s) {
+    if (!net->fin_pending) return NAQS_OK;
+    net->fin_pending = false;
+    NAQS_KLAUNCH(sample_finish_kernel, dim3(1), dim3(net->fin_job.weights ? FIN_THREADS : 64), 0, s, net->fin_job);
+    HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
 

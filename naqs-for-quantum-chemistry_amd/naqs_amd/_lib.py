@@ -67,6 +67,7 @@ SIGNATURES = {
     "naqs_net_finish_pending": (ctypes.c_int, [c_vp, c_vp]),
     "naqs_net_prof_select": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_launch_count": (c_i64, []),
+    "naqs_net_spec_counts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "naqs_shard_proof": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_shard_sample_forward": (ctypes.c_int, [c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),

@@ -61,3 +61,12 @@ from naqs_amd.optimizer import LogKey
 n_unq = opt.log[LogKey.N_UNIQUE_SAMP][-1][1]
 print(f"{os.path.basename(mol_f)}: {steps} steps, {dt / steps * 1e3:.3f} ms/step, {n_unq} unique samples in the last step, "
       f"<E_loc> = {opt.log[LogKey.E_LOC][-1][1]:.6f}")
+try:      # forwards launched ahead of the host's look at M, and how many of them stood (naqs_net_spec_counts)
+    import ctypes
+    from naqs_amd import _lib
+    fz = wf._fused
+    c = (ctypes.c_int64 * 2)()
+    _lib.check(_lib.load_library().naqs_net_spec_counts(fz._h, c), "naqs_net_spec_counts")
+    print(f"  forward launched ahead of M: {c[0]} times, {c[1]} stood")
+except Exception as e:      # (an older library)
+    print("  (no spec counts:", e, ")")
