@@ -78,6 +78,51 @@ NAQS_HD double rcp_fast(double x) {
 #endif
 }
 
+// log and exp for the generator (round 5).  The library functions are ~510 (log), ~900 (log1p) and ~800 (exp) cycles of one wave —
+// full-range, correctly rounded to an ulp, with their special cases — and they sit on the chain that a tree level waits for
+// (tools/binomial_parts_probe.cpp: the exact acceptance test was 1.9 k of a 4.0 k-cycle BTRS call, exp(n log1p(-p)) 1.75 k of a
+// 3.5 k-cycle inversion call).  The arguments here are finite, normal and positive (log) / in [-745, 0] (exp), which leaves
+// one range reduction and one polynomial each; errors are a few ulp, i.e. ~1e-15 relative in an acceptance bound that the
+// float64 generator meets with a margin of 2^-9 at the largest supported n (2^44).  Host and device run the same arithmetic
+// except for the reciprocal (rcp_fast).
+// log(x), x > 0 finite and normal: x = 2^e m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716
+NAQS_HD double log_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double m = __builtin_amdgcn_frexp_mant(x);                  // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+#else
+    int e;
+    double m = std::frexp(x, &e);
+#endif
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    const double f = m - 1.0;                                   // exact
+    const double s = f * rcp_fast(2.0 + f);
+    const double z = s * s;                                     // <= 0.02944: z^11 / 23 < 1e-18
+    double q = 1.0 / 23.0;
+    q = fma(q, z, 1.0 / 21.0); q = fma(q, z, 1.0 / 19.0); q = fma(q, z, 1.0 / 17.0); q = fma(q, z, 1.0 / 15.0);
+    q = fma(q, z, 1.0 / 13.0); q = fma(q, z, 1.0 / 11.0); q = fma(q, z, 1.0 / 9.0); q = fma(q, z, 1.0 / 7.0);
+    q = fma(q, z, 1.0 / 5.0); q = fma(q, z, 1.0 / 3.0);
+    const double s2 = 2.0 * s;
+    const double l = fma(s2 * z, q, s2);                        // 2 s (1 + z / 3 + z^2 / 5 + ...)
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, l));      // e ln2 (hi: 32 trailing zero bits, lo)
+}
+// log(1 - p), 0 < p <= 1/2, from p itself (1 - p alone has lost p's low bits): Kahan's log(w) (-p) / (w - 1), w = fl(1 - p)
+NAQS_HD double log1m_fast(double p) {
+    const double w = 1.0 - p;
+    return w == 1.0 ? -p : log_fast(w) * (-p) * rcp_fast(w - 1.0);
+}
+// exp(x), -745 < x <= 0: x = k ln2 + r, |r| <= 0.3466, Taylor to r^13 (remainder < 5e-18)
+NAQS_HD double exp_fast(double x) {
+    const double kd = rint(x * 1.44269504088896338700);
+    const double r = fma(-kd, 1.90821492927058770002e-10, fma(-kd, 6.93147180369123816490e-01, x));
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, r, 1.0 / 479001600.0); q = fma(q, r, 1.0 / 39916800.0); q = fma(q, r, 1.0 / 3628800.0); q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0); q = fma(q, r, 1.0 / 5040.0); q = fma(q, r, 1.0 / 720.0); q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0); q = fma(q, r, 1.0 / 6.0); q = fma(q, r, 0.5); q = fma(q, r, 1.0); q = fma(q, r, 1.0);
+    return ldexp(q, (int)kd);
+}
+
 // log(k!) - [ (k + 1/2) log(k + 1) - (k + 1) + log(2 pi)/2 ]  (Stirling series remainder)
 NAQS_HD double stirling_tail(double k) {
     if (k < 10.0) {
@@ -103,7 +148,7 @@ NAQS_HD double binomial_inversion(double n, double p, RngStream &g) {
     const double s = p * rcp_fast(1.0 - p);
     double u, v;
     g.pair(u, v);
-    double f = exp(n * log1p(-p));          // P(0) = q^n >= e^-15 here
+    double f = exp_fast(n * log1m_fast(p)); // P(0) = q^n >= e^-15 here
     double k = 0.0;
     for (int it = 0; it < 400 && u > f && k < n; ++it) {
         u -= f;
@@ -149,11 +194,14 @@ NAQS_HD bool btrs_attempt(Btrs &t, double u, double v, double &k) {
         t.have_slow = true;
         t.alpha = (2.83 + 5.1 * t.rb) * t.spq;
         t.r = t.p * rcp_fast(1.0 - t.p);
-        t.h_m = (t.m + 0.5) * log((t.m + 1.0) * rcp_fast(t.r * (t.n - t.m + 1.0))) + stirling_tail(t.m) + stirling_tail(t.n - t.m);
+        t.h_m = (t.m + 0.5) * log_fast((t.m + 1.0) * rcp_fast(t.r * (t.n - t.m + 1.0))) + stirling_tail(t.m) + stirling_tail(t.n - t.m);
     }
-    const double lv = log(v * t.alpha * rcp_fast(t.a * rcp_fast(us * us) + t.b));
-    const double ub = t.h_m + (t.n + 1.0) * log1p((k - t.m) * rcp_fast(t.n - k + 1.0)) +
-                      (k + 0.5) * log(t.r * (t.n - k + 1.0) * rcp_fast(k + 1.0)) - stirling_tail(k) - stirling_tail(t.n - k);
+    // (log1p as log(1 + x) x / ((1 + x) - 1), the form the group draw below evaluates)
+    const double x1 = (k - t.m) * rcp_fast(t.n - k + 1.0), a1 = 1.0 + x1;
+    const double l1p = a1 == 1.0 ? x1 : log_fast(a1) * x1 * rcp_fast(a1 - 1.0);
+    const double lv = log_fast(v * t.alpha * rcp_fast(t.a * rcp_fast(us * us) + t.b));
+    const double ub = t.h_m + (t.n + 1.0) * l1p +
+                      (k + 0.5) * log_fast(t.r * (t.n - k + 1.0) * rcp_fast(k + 1.0)) - stirling_tail(k) - stirling_tail(t.n - k);
     return lv <= ub;
 }
 
@@ -297,20 +345,25 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
                     const double a1 = 1.0 + x1;
                     const double a2 = r * (t.n - k_j + 1.0) * rcp_fast(k_j + 1.0);
                     const double a3 = (t.m + 1.0) * rcp_fast(r * (t.n - t.m + 1.0));
-                    double T[4];
+                    // ... and of the four Stirling remainders (round 5: one after the other they were 0.8 k cycles of the test)
+                    const double b0 = k_j, b1 = t.n - k_j, b2 = t.m, b3 = t.n - t.m;
+                    double T[4], S[4];
                     if (G == 4) {
-                        const double mine = log(j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)));
+                        const double mine = log_fast(j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)));
+                        const double tail = stirling_tail(j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3)));
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) T[q] = group_bcast<4>(mine, q);
+                        for (int q = 0; q < 4; ++q) { T[q] = group_bcast<4>(mine, q); S[q] = group_bcast<4>(tail, q); }
                     } else {
-                        const double m0 = log(j == 0 ? a0 : a1), m1 = log(j == 0 ? a2 : a3);
+                        const double m0 = log_fast(j == 0 ? a0 : a1), m1 = log_fast(j == 0 ? a2 : a3);
+                        const double t0 = stirling_tail(j == 0 ? b0 : b1), t1 = stirling_tail(j == 0 ? b2 : b3);
                         T[0] = group_bcast<2>(m0, 0); T[1] = group_bcast<2>(m0, 1);
                         T[2] = group_bcast<2>(m1, 0); T[3] = group_bcast<2>(m1, 1);
+                        S[0] = group_bcast<2>(t0, 0); S[1] = group_bcast<2>(t0, 1);
+                        S[2] = group_bcast<2>(t1, 0); S[3] = group_bcast<2>(t1, 1);
                     }
                     const double l1p = a1 == 1.0 ? x1 : T[1] * x1 * rcp_fast(a1 - 1.0);      // log1p(x1)
-                    const double h_m = (t.m + 0.5) * T[3] + stirling_tail(t.m) + stirling_tail(t.n - t.m);
-                    const double ub = h_m + (t.n + 1.0) * l1p + (k_j + 0.5) * T[2] - stirling_tail(k_j) -
-                                      stirling_tail(t.n - k_j);
+                    const double h_m = (t.m + 0.5) * T[3] + S[2] + S[3];
+                    const double ub = h_m + (t.n + 1.0) * l1p + (k_j + 0.5) * T[2] - S[0] - S[1];
                     cls_j = T[0] <= ub ? 0 : 2;
                 }
             }
