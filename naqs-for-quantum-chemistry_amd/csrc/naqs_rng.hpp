@@ -337,33 +337,42 @@ __device__ __forceinline__ int64_t binomial_group(bool need, const int64_t n, co
 #endif
                 if (exact) {
                     const double us_j = group_bcast<G>(us, jj), v_j = group_bcast<G>(v, jj), k_j = group_bcast<G>(kk, jj);
-                    const double alpha = (2.83 + 5.1 * t.rb) * t.spq;
-                    const double r = t.p * rcp_fast(1.0 - t.p);
-                    // arguments of the four logarithms; term 1 (log1p) goes through log(1 + x) with Kahan's correction
-                    const double x1 = (k_j - t.m) * rcp_fast(t.n - k_j + 1.0);
-                    const double a0 = v_j * alpha * rcp_fast(t.a * rcp_fast(us_j * us_j) + t.b);
-                    const double a1 = 1.0 + x1;
-                    const double a2 = r * (t.n - k_j + 1.0) * rcp_fast(k_j + 1.0);
-                    const double a3 = (t.m + 1.0) * rcp_fast(r * (t.n - t.m + 1.0));
-                    // ... and of the four Stirling remainders (round 5: one after the other they were 0.8 k cycles of the test)
-                    const double b0 = k_j, b1 = t.n - k_j, b2 = t.m, b3 = t.n - t.m;
+                    // The test's four logarithms and four Stirling remainders, shared out over the group's lanes.  Every lane
+                    // forms ITS term as one quotient — one reciprocal, where forming all four arguments on every lane took six:
+                    //   0: log( v alpha us^2 / (a + b us^2) )            (= log(v alpha / (a / us^2 + b)))
+                    //   1: log1p(x), x = (k - m) / (n - k + 1), as log(1 + x) x / ((1 + x) - 1)
+                    //   2: log( p (n - k + 1) / ((1 - p)(k + 1)) )       (= log(r (n - k + 1) / (k + 1)), r = p / (1 - p))
+                    //   3: log( (m + 1)(1 - p) / (p (n - m + 1)) )       (= log((m + 1) / (r (n - m + 1))))
+                    const double q1 = 1.0 - t.p, us2 = us_j * us_j;
+                    const double num[4] = {v_j * ((2.83 + 5.1 * t.rb) * t.spq) * us2, k_j - t.m, t.p * (t.n - k_j + 1.0), (t.m + 1.0) * q1};
+                    const double den[4] = {fma(t.b, us2, t.a), t.n - k_j + 1.0, q1 * (k_j + 1.0), t.p * (t.n - t.m + 1.0)};
+                    const double b[4] = {k_j, t.n - k_j, t.m, t.n - t.m};                  // arguments of the Stirling remainders
                     double T[4], S[4];
-                    if (G == 4) {
-                        const double mine = log_fast(j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)));
-                        const double tail = stirling_tail(j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3)));
+                    constexpr int R = 4 / G;                                                // terms per lane
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { T[q] = group_bcast<4>(mine, q); S[q] = group_bcast<4>(tail, q); }
-                    } else {
-                        const double m0 = log_fast(j == 0 ? a0 : a1), m1 = log_fast(j == 0 ? a2 : a3);
-                        const double t0 = stirling_tail(j == 0 ? b0 : b1), t1 = stirling_tail(j == 0 ? b2 : b3);
-                        T[0] = group_bcast<2>(m0, 0); T[1] = group_bcast<2>(m0, 1);
-                        T[2] = group_bcast<2>(m1, 0); T[3] = group_bcast<2>(m1, 1);
-                        S[0] = group_bcast<2>(t0, 0); S[1] = group_bcast<2>(t0, 1);
-                        S[2] = group_bcast<2>(t1, 0); S[3] = group_bcast<2>(t1, 1);
+                    for (int r = 0; r < R; ++r) {
+                        const int term = G == 4 ? j : 2 * r + j;                            // (a pair: lane j takes terms j and 2 + j)
+                        const double nu = term == 0 ? num[0] : (term == 1 ? num[1] : (term == 2 ? num[2] : num[3]));
+                        const double de = term == 0 ? den[0] : (term == 1 ? den[1] : (term == 2 ? den[2] : den[3]));
+                        const double bb = term == 0 ? b[0] : (term == 1 ? b[1] : (term == 2 ? b[2] : b[3]));
+                        const double qt = nu * rcp_fast(de);
+                        const bool is_l1p = term == 1;
+                        const double arg = is_l1p ? 1.0 + qt : qt;
+                        const double lg = log_fast(arg);
+                        const double am1 = arg - 1.0;                                       // (exact near 1; only used by term 1)
+                        const double kahan = lg * qt * rcp_fast(is_l1p && am1 != 0.0 ? am1 : 1.0);
+                        const double mine = is_l1p ? (am1 == 0.0 ? qt : kahan) : lg;
+                        const double tail = stirling_tail(bb);
+                        if (G == 4) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { T[q] = group_bcast<4>(mine, q); S[q] = group_bcast<4>(tail, q); }
+                        } else {
+                            T[2 * r] = group_bcast<2>(mine, 0); T[2 * r + 1] = group_bcast<2>(mine, 1);
+                            S[2 * r] = group_bcast<2>(tail, 0); S[2 * r + 1] = group_bcast<2>(tail, 1);
+                        }
                     }
-                    const double l1p = a1 == 1.0 ? x1 : T[1] * x1 * rcp_fast(a1 - 1.0);      // log1p(x1)
                     const double h_m = (t.m + 0.5) * T[3] + S[2] + S[3];
-                    const double ub = h_m + (t.n + 1.0) * l1p + (k_j + 0.5) * T[2] - S[0] - S[1];
+                    const double ub = h_m + (t.n + 1.0) * T[1] + (k_j + 0.5) * T[2] - S[0] - S[1];
                     cls_j = T[0] <= ub ? 0 : 2;
                 }
             }
