@@ -216,6 +216,11 @@ typedef struct naqs_net_config {
                                        * 1: one phase block per orbital pair, phases summed — the reference's default
                                        *    (experiments/run.py:31, nade.py:556-569): every block is
                                        *    Linear(max(1, 2n), phase_hidden[0]) + ReLU + Linear(phase_hidden[0], 4); n_phase_hidden must be 1 */
+    int32_t use_phase_spin_sym;       /* 1 (-phase_sym, nade.py:281, 507-533, 590-610; ABI 7): the phase block reads spin-ordered inputs
+                                       *    (alpha and beta strings of the first P-1 pairs exchanged when idx(alpha) > idx(beta)), has
+                                       *    3 outputs for |00>, |01> = |10>, |11>, and the phase gets + pi (N_01 mod 2) where
+                                       *    idx(alpha) < idx(beta).  With aggregate_phase every per-pair block orders ITS prefix and
+                                       *    the last block's phase carries the shift (nade.py:758-759). */
 } naqs_net_config_t;
 
 int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_t **out);

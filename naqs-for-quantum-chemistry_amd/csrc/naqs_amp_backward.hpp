@@ -78,7 +78,7 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
             bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
         }
         const int occ = (int)((key >> d.qa[NB]) & 1ull) + 2 * (int)((key >> d.qb[NB]) & 1ull);
-        const bool swap = d.sym && abits > bbits;
+        const bool swap = (raw ? d.phase_sym != 0 : d.sym != 0) && abits > bbits;      // (raw: the phase blocks' spin-ordered inputs)
         const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
         float x[NIN];
         if (NB == 0) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
         float da4[4];
         if (raw) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) da4[c] = valid && c == occ ? gi : 0.0f;
+            for (int c = 0; c < 4; ++c) da4[c] = valid && c == naqs::phase_out_row(d, occ) ? gi : 0.0f;
         } else {
             float la[4];
             bool ok[4];

@@ -93,9 +93,16 @@ __global__ __launch_bounds__(256) void phase_inputs_kernel(const NetDims d, cons
     const int64_t i = e / W;
     const int c = (int)(e - i * W);
     const uint64_t key = keys[i];
-    const int bit = c < d.P - 1 ? d.qa[c] : d.qb[c - (d.P - 1)];
-    x[e] = ((key >> bit) & 1ull) ? 1.0f : -1.0f;
-    if (c == 0) occ[i] = (int64_t)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int64_t)((key >> d.qb[d.P - 1]) & 1ull);
+    if (d.phase_sym) {                                  // spin-ordered inputs; occ = the row of the 3-output layer (naqs_net.hpp)
+        uint32_t a_, b_;
+        naqs::key_strings(d, key, a_, b_);
+        naqs::phase_order_inputs(d, d.P - 1, a_, b_);
+        x[e] = (c < d.P - 1 ? ((a_ >> c) & 1u) : ((b_ >> (c - (d.P - 1))) & 1u)) ? 1.0f : -1.0f;
+    } else {
+        const int bit = c < d.P - 1 ? d.qa[c] : d.qb[c - (d.P - 1)];
+        x[e] = ((key >> bit) & 1ull) ? 1.0f : -1.0f;
+    }
+    if (c == 0) occ[i] = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
 }
 
 // d loss / d (log|psi|, phase) of the VMC loss 2 Re sum_i w_i log psi_i (E_loc_i - <E>)^* in the reference's float32

@@ -96,8 +96,9 @@ __device__ __forceinline__ void amp_body(const NetDims &d, const float *__restri
         bbits |= (uint32_t)((key >> d.qb[k]) & 1ull) << k;
     }
     const int occ = (int)((key >> d.qa[n]) & 1ull) + 2 * (int)((key >> d.qb[n]) & 1ull);
-    // spin ordering: the string with the smaller index goes first (nade.py:399-405, :519-530)
-    const bool swap = d.sym && abits > bbits;
+    // spin ordering: the string with the smaller index goes first (nade.py:399-405, :519-530); the phase blocks (raw) order
+    // their inputs under use_phase_spin_sym
+    const bool swap = (raw ? d.phase_sym != 0 : d.sym != 0) && abits > bbits;
     const uint32_t first = swap ? bbits : abits, second = swap ? abits : bbits;
     const int per = (d.Ha + AMP_SPLIT - 1) / AMP_SPLIT;
     const int j0 = min(d.Ha, q * per), j1 = min(d.Ha, j0 + per);
@@ -123,8 +124,15 @@ __device__ __forceinline__ void amp_body(const NetDims &d, const float *__restri
             for (int u = 0; u < AMP_SPLIT; ++u) v += s_part[tile][u][c][lane];      // fixed order
             t[c] = v;
         }
-        scratch[(int64_t)n * M + i] = raw ? (occ == 0 ? t[0] : (occ == 1 ? t[1] : (occ == 2 ? t[2] : t[3])))
-                                          : amp_finish(d, n, t, abits, bbits, occ);
+        if (raw) {
+            const int row = naqs::phase_out_row(d, occ);       // (-phase_sym: |01> and |10> share the middle output, nade.py:593-595)
+            float ph = row == 0 ? t[0] : (row == 1 ? t[1] : (row == 2 ? t[2] : t[3]));
+            // ... and the last block's phase carries the sign of the spin-exchanged partner (nade.py:597-610, :758-759)
+            if (n == d.P - 1) ph += naqs::phase_sym_shift(d, abits | ((uint32_t)(occ & 1) << n), bbits | ((uint32_t)(occ >> 1) << n));
+            scratch[(int64_t)n * M + i] = ph;
+        } else {
+            scratch[(int64_t)n * M + i] = amp_finish(d, n, t, abits, bbits, occ);
+        }
     }
 }
 
@@ -338,8 +346,15 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
         float v = 0.0f;
         if (i < M && k < 2 * (P - 1)) {
             const uint64_t key = keys[i];
-            const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
-            v = ((key >> q) & 1ull) ? 1.0f : -1.0f;
+            if (d.phase_sym) {                          // spin-ordered inputs (nade.py:519-530)
+                uint32_t a_, b_;
+                naqs::key_strings(d, key, a_, b_);
+                naqs::phase_order_inputs(d, P - 1, a_, b_);
+                v = (k < P - 1 ? ((a_ >> k) & 1u) : ((b_ >> (k - (P - 1))) & 1u)) ? 1.0f : -1.0f;
+            } else {
+                const int q = k < P - 1 ? d.qa[k] : d.qb[k - (P - 1)];
+                v = ((key >> q) & 1ull) ? 1.0f : -1.0f;
+            }
         }
         buf[r * ld + k] = v;
     }
@@ -354,7 +369,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel(const NetDims d, cons
         if (i < M) {
             const uint64_t key = keys[i];
             const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
-            const float ph = buf[tid * ld + occ];
+            float ph = buf[tid * ld + naqs::phase_out_row(d, occ)];
+            if (d.phase_sym) { uint32_t a_, b_; naqs::key_strings(d, key, a_, b_); ph += naqs::phase_sym_shift(d, a_, b_); }
             out[i] = make_float2(la, ph);
             if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
         }
@@ -993,6 +1009,11 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_h(const NetDims d, co
                 for (int k = 0; k < P; ++k) { a_ |= (uint32_t)((key >> d.qa[k]) & 1ull) << k; b_ |= (uint32_t)((key >> d.qb[k]) & 1ull) << k; }
                 ab = a_ | (b_ << 16);
             }
+            if (d.phase_sym) {                                                  // spin-ordered inputs (nade.py:519-530)
+                uint32_t a_ = ab & 0xffffu, b_ = ab >> 16;
+                naqs::phase_order_inputs(d, P - 1, a_, b_);
+                ab = a_ | (b_ << 16);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = k8 + j;
@@ -1031,7 +1052,8 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_h(const NetDims d, co
         if (i < M) {
             const uint64_t key = keys[i];
             const int occ = (int)((key >> d.qa[P - 1]) & 1ull) + 2 * (int)((key >> d.qb[P - 1]) & 1ull);
-            const float ph = reinterpret_cast<const float *>(planes)[tid * 16 + occ];
+            float ph = reinterpret_cast<const float *>(planes)[tid * 16 + naqs::phase_out_row(d, occ)];
+            if (d.phase_sym) { uint32_t a_, b_; naqs::key_strings(d, key, a_, b_); ph += naqs::phase_sym_shift(d, a_, b_); }
             out[i] = make_float2(la, ph);
             if (feed.psi != nullptr) naqs::feed_psi(feed, i, la, ph);
         }
@@ -2145,6 +2167,8 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     d.min_n_set = cfg->n_alpha < 0 ? 0 : std::min(std::min(d.n_alpha, d.n_beta), std::min(d.n_alpha_down, d.n_beta_down));
     d.masking = cfg->masking;
     d.sym = cfg->use_amp_spin_sym ? 1 : 0;
+    d.phase_sym = cfg->use_phase_spin_sym ? 1 : 0;
+    const int n_out_phase = d.phase_sym ? 3 : 4;               // nade.py:281
     d.Ha = cfg->amp_hidden;
     d.n_out_amp = d.sym ? 5 : 4;
     for (int n = 0; n < P; ++n) { d.qa[n] = (uint8_t)cfg->qubit2model[2 * n]; d.qb[n] = (uint8_t)cfg->qubit2model[2 * n + 1]; }
@@ -2164,13 +2188,13 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         q = d;
         q.Ha = cfg->phase_hidden[0];
         q.sym = 0;
-        q.n_out_amp = 4;
+        q.n_out_amp = n_out_phase;             // (-phase_sym: 3 raw outputs, the middle one for |01> and |10>; q.phase_sym orders the inputs)
         int64_t poff2 = 0;
         for (int n = 0; n < P; ++n) {
             net->ph_src_off[n] = off;
             q.amp_off[n] = (int32_t)poff2;
             const int nin = n == 0 ? 1 : 2 * n;
-            off += (int64_t)q.Ha * nin + q.Ha + 4ll * q.Ha + 4;
+            off += (int64_t)q.Ha * nin + q.Ha + (int64_t)n_out_phase * q.Ha + n_out_phase;
             poff2 += (int64_t)q.Ha * ((nin + 1 + 5 + 3) & ~3) + 8;
         }
         net->ph_params = off - net->amp_params;
@@ -2202,7 +2226,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     int64_t src = off, dst = poff;
     int max_k = 0;
     for (int l = 0; l < d.n_lin; ++l) {
-        const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : 4;
+        const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : n_out_phase;
         if (Nout <= 0) { delete net; return NAQS_ERR_INVALID; }
         d.K_pad[l] = (K + 15) & ~15;
         d.N_pad[l] = (Nout + 15) & ~15;
@@ -2221,7 +2245,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
         int64_t hoff = 0;
         int Kh = std::max(1, 2 * (P - 1)), max_kh = 0;
         for (int l = 0; l < d.n_lin; ++l) {
-            const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : 4;
+            const int Nout = l < cfg->n_phase_hidden ? cfg->phase_hidden[l] : n_out_phase;
             d.Kh_pad[l] = (Kh + 31) & ~31;
             d.wh_off[l] = (int32_t)hoff;
             hoff += 3ll * d.N_pad[l] * d.Kh_pad[l];
@@ -2641,7 +2665,7 @@ static FormSel select_form(const naqs_net *net, const int64_t M, const int fmt, 
     const int ws_mode = naqs::env_int("NAQS_PHASE_WS", 1);
     int rb = naqs::env_int("NAQS_PHASE_RB", 0);
     if (rb < 1 || rb > rb_max) rb = (int)std::min<int64_t>(rb_max, std::max<int64_t>(1, (M + 16ll * net->cu_count - 1) / (16ll * net->cu_count)));
-    bool ws = ws_shape && ws_mode != 0;
+    bool ws = ws_shape && ws_mode != 0 && !d.phase_sym;        // (the spin-ordered inputs and the sign shift are phase_kernel_h's)
     if (ws) {
         const int rb_ws = std::min(rb, 3);
         if (rb_ws * lds_h16 + (size_t)d.P * rb_ws * 16 * 8 * sizeof(float) > 155 * 1024) ws = false;

@@ -23,6 +23,7 @@ struct NetDims {
     int32_t min_n_set;
     int32_t masking;                   // 0 NONE, 1 PARTIAL, 2 FULL
     int32_t sym;                       // amplitude spin symmetry
+    int32_t phase_sym;                 // phase spin symmetry (-phase_sym: spin-ordered inputs, 3 outputs for |00>, |01>=|10>, |11>, sign shift)
     int32_t Ha;                        // amplitude hidden width
     int32_t n_out_amp;                 // 5 with symmetry, 4 without
     uint8_t qa[MAXP], qb[MAXP];        // qubit (bit) index of the alpha / beta orbital of model pair n
@@ -50,6 +51,30 @@ struct PhaseScales { float sw[MAXL], c[MAXL], sn[MAXL], isn[MAXL]; };
 // readers, which may be workgroups of the SAME launch with higher block indices: value and flag are one word — no fence
 constexpr int BOUNDS_WG = 64;
 struct PhaseRaw { unsigned long long max_w[MAXL][BOUNDS_WG], max_rowsum[MAXL][BOUNDS_WG], max_b[MAXL][BOUNDS_WG]; };
+
+// ---- the phase block under use_phase_spin_sym (nade.py:281, 507-533, 590-610) ----
+// row of the phase block's output layer that the realised outcome `occ` (alpha + 2 beta) of the last pair selects: the outcome
+// itself, or — 3 outputs for |00>, |01> = |10>, |11> (nade.py:593-595: phase_i[:, [0, 1, 1, 2]]) — the shared row
+__host__ __device__ inline int phase_out_row(const NetDims &d, const int occ) { return d.phase_sym ? ((occ + 1) >> 1) : occ; }
+#if defined(__HIPCC__)
+// spin-ordered inputs (nade.py:519-530): the alpha and beta strings of the first `np` pairs change places when idx(alpha) > idx(beta)
+__device__ __forceinline__ void phase_order_inputs(const NetDims &d, const int np, uint32_t &a, uint32_t &b) {
+    if (d.phase_sym) {
+        const uint32_t mask = (1u << np) - 1u, ap = a & mask, bp = b & mask;
+        if (ap > bp) { a = (a & ~mask) | bp; b = (b & ~mask) | ap; }
+    }
+}
+// the sign by which spin-exchanged partners differ (nade.py:597-610): + pi (N_01 mod 2) where idx(alpha) < idx(beta) over all P
+// pairs, N_01 = pairs with the alpha orbital empty and the beta orbital occupied; float32 pi like the reference's tensor
+__device__ __forceinline__ float phase_sym_shift(const NetDims &d, const uint32_t a, const uint32_t b) {
+    if (!d.phase_sym || !(a < b)) return 0.0f;
+    return (__popc(~a & b & ((1u << d.P) - 1u)) & 1) ? 3.14159274101257324f : 0.0f;
+}
+__device__ __forceinline__ void key_strings(const NetDims &d, const uint64_t key, uint32_t &a, uint32_t &b) {
+    a = b = 0u;
+    for (int k = 0; k < d.P; ++k) { a |= (uint32_t)((key >> d.qa[k]) & 1ull) << k; b |= (uint32_t)((key >> d.qb[k]) & 1ull) << k; }
+}
+#endif
 
 // one packed row [W1[j][0..NIN) | b1[j] | W2[0..5)[j] | pad] from LDS as 16-byte reads (rows are 16-byte multiples);
 // element-wise `row[k]` reads compile to one ds_read_b32 each and those, not the FMAs, were the time of this loop

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void top_delta_kernel(const NetDims d, const i
     const int64_t i = e / ld;
     const int c = (int)(e - i * ld);
     const uint64_t key = keys[i];
-    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    const int occ = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
     delta[e] = c == occ ? g[i].y : 0.0f;
 }
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void vmc_seed_kernel(const NetDims d, const in
     const float two_w = 2.0f * (float)w[i];
     const float gx = ((float)el.x - m_re) * two_w, gy = -(((float)el.y - m_im) * two_w);
     const uint64_t key = keys[i];
-    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    const int occ = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
     delta[e] = c == occ ? gy : 0.0f;
     if (c == 0) { g[i] = make_float2(gx, gy); g_amp[i] = gx; }
 }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void delta_below_top_kernel(const NetDims d, c
     const int64_t i = e / k4;
     const int k = (int)(e - i * k4) << 2;
     const uint64_t key = keys[i];
-    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    const int occ = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
     const float gy = g[i].y;
     const f32x4 w = *reinterpret_cast<const f32x4 *>(Wtop + (int64_t)occ * Kp + k);
     const f32x4 a = *reinterpret_cast<const f32x4 *>(act + i * Kp + k);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, co
     const float two_w = 2.0f * (float)w[i];
     const float gx = ((float)el.x - m_re) * two_w, gy = -(((float)el.y - m_im) * two_w);
     const uint64_t key = keys[i];
-    const int occ = (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull);
+    const int occ = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
     const f32x4 wt = *reinterpret_cast<const f32x4 *>(Wtop + (int64_t)occ * Kp + k);
     const f32x4 a = *reinterpret_cast<const f32x4 *>(act + i * Kp + k);
     f32x4 o;

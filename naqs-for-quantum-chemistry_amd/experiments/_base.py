@@ -174,7 +174,8 @@ def _run(molecule_fname, hamiltonian_fname, exp_name, num_experiments, pretraine
          reweight_samples_by_psi, n_train, n_pretrain, output_freq, save_freq, n_lut, n_hid, n_layer, n_hid_phase,
          n_layer_phase, n_excitations_max, comb_amp_phase, use_amp_spin_sym, use_phase_spin_sym, aggregate_phase,
          use_restrictedH, loadH, presolveH, overwrite_pauli_hamiltonian, verbose, seed, device=None):
-    # (-phase_sym / -comb_amp_phase run as PyTorch modules on the device — no published script uses them; -n_pretrain is
+    # (-phase_sym runs on the HIP kernels since round 5, -comb_amp_phase as PyTorch modules on the device — no published script
+    # uses either; -n_pretrain is
     # OptimizerBase.pre_flatten; -weight_by_psi is accepted and, as in the reference, has no effect on this optimiser:
     # PartialSamplingOptimizer forces reweight_samples_by_psi = False, energy.py:744)
     rejected = [name for name, on in (("-n_lut", n_lut), ("-loadH", loadH), ("-overwriteH", overwrite_pauli_hamiltonian),

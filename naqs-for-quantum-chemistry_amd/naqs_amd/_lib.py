@@ -93,7 +93,8 @@ class NetConfig(ctypes.Structure):
     _fields_ = [("n_qubits", ctypes.c_int32), ("n_alpha", ctypes.c_int32), ("n_beta", ctypes.c_int32),
                 ("masking", ctypes.c_int32), ("use_amp_spin_sym", ctypes.c_int32), ("amp_hidden", ctypes.c_int32),
                 ("n_phase_hidden", ctypes.c_int32), ("phase_hidden", ctypes.c_int32 * NET_MAX_PHASE_LAYERS),
-                ("qubit2model", ctypes.c_int32 * (2 * NET_MAX_PAIRS)), ("aggregate_phase", ctypes.c_int32)]
+                ("qubit2model", ctypes.c_int32 * (2 * NET_MAX_PAIRS)), ("aggregate_phase", ctypes.c_int32),
+                ("use_phase_spin_sym", ctypes.c_int32)]
 
 
 class VmcEvent(ctypes.Structure):

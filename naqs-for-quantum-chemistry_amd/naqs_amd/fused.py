@@ -6,8 +6,10 @@ Supported architecture families:
     <= 128 units), a single phase block (``aggregate_phase=False``) of 1..8 hidden layers <= 512 wide;
   * the reference's default ansatz (experiments/run.py:11-31): the same amplitude blocks and one phase block per orbital
     pair (``aggregate_phase=True``), each with one hidden layer (multiple of 16, <= 128 units);
-no phase symmetry, <= 16 orbital pairs.  Anything else raises ``NotImplementedError`` — callers then stay on the
-PyTorch modules (same numbers, more launches), and ``wavefunction.fused()`` says so on stdout.
+both with or without the phase spin symmetry (``-phase_sym``, nade.py:281, 507-533, 590-610: spin-ordered inputs of the phase
+block(s), 3 outputs, the sign shift — since round 5), <= 16 orbital pairs.  Anything else (combined amplitude-phase blocks,
+look-up-table blocks) raises ``NotImplementedError`` — callers then stay on the PyTorch modules (same numbers, more launches),
+and ``wavefunction.fused()`` says so on stdout.
 """
 import ctypes
 import os
@@ -61,9 +63,10 @@ class FusedLogPsi:
         if m.device.type != "cuda":
             raise _lib.NaqsError("FusedLogPsi needs the network on a HIP device (no CPU fallback)")
         self.aggregate = bool(m.aggregate_phase)
-        if getattr(m, "use_phase_spin_sym", False) or getattr(m, "combined_amp_phase_blocks", False):
-            raise NotImplementedError("fused log-psi: phase spin symmetry / combined amplitude-phase blocks (no published "
-                                      "script uses them) run as PyTorch modules")
+        self.phase_sym = bool(getattr(m, "use_phase_spin_sym", False))
+        if getattr(m, "combined_amp_phase_blocks", False):
+            raise NotImplementedError("fused log-psi: combined amplitude-phase blocks (no published script uses them) run as "
+                                      "PyTorch modules")
         if len(m.phase_layers) != (m.P if self.aggregate else 1):
             raise NotImplementedError("fused log-psi: unexpected number of phase blocks")
         if len(m.amp_layers[0].linears()) != 2:
@@ -97,6 +100,7 @@ class FusedLogPsi:
         for i, q in enumerate(wf.qubit2model_permutation):
             cfg.qubit2model[i] = int(q)
         cfg.aggregate_phase = int(self.aggregate)
+        cfg.use_phase_spin_sym = int(self.phase_sym)          # -phase_sym with one phase block (nade.py:281, 507-533, 590-610)
         self._h = ctypes.c_void_p(None)
         st = self._lib.naqs_net_create(ctypes.byref(cfg), self.device.index or 0, ctypes.byref(self._h))
         _lib.check(st, "naqs_net_create")
@@ -106,8 +110,8 @@ class FusedLogPsi:
         self._samp = None
         self._grad_flat, self._grad_views = None, None
         self.train_mode = os.environ.get("NAQS_TRAIN_MODE", "hip")     # "hip" | "blas" (phase MLP through torch/rocBLAS)
-        if self.aggregate:
-            self.train_mode = "hip"                                     # (the per-pair phase blocks have no BLAS formulation here)
+        if self.aggregate or self.phase_sym:
+            self.train_mode = "hip"                                     # (the per-pair phase blocks / spin-ordered inputs have no BLAS formulation here)
         assert self.n_params == sum(p.numel() for p in m.parameters()), "parameter layout mismatch"
         _lib.check(self._lib.naqs_net_amp_param_count(self._h, ctypes.byref(n)), "naqs_net_amp_param_count")
         self.n_amp_params = n.value
@@ -139,8 +143,8 @@ class FusedLogPsi:
         pair, the phase MLP (three Linear layers) through PyTorch/rocBLAS.  Same function of the parameters as
         ``wavefunction.log_psi(states)``."""
         m = self.wf.model
-        if self.aggregate:
-            raise NotImplementedError("log_psi_train (autograd.Function form) for aggregate_phase networks: use "
+        if self.aggregate or self.phase_sym:
+            raise NotImplementedError("log_psi_train (autograd.Function form) for aggregate_phase / phase-symmetric networks: use "
                                       "forward_saved / backward_saved")
         keys = keys.contiguous()
         log_amp = _LogAmp.apply(self, keys, *self._amp_params)

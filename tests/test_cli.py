@@ -139,7 +139,8 @@ def test_open_shell_rule_follows_the_reference_integer_arithmetic(capsys):
 def test_cli_runs_the_live_options_no_published_script_uses(extra, suffix, tmp_path, monkeypatch, capsys):
     """experiments/_base.py:479, 497, 533-541 of the reference: -weight_by_psi (accepted, and without effect on this
     optimiser exactly like there: energy.py:744 forces reweight_samples_by_psi = False), -n_pretrain (pre_flatten),
-    -phase_sym and -comb_amp_phase (PyTorch modules; parity with the reference's vectors in test_variants.py)."""
+    -phase_sym and -comb_amp_phase (on the CPU: PyTorch modules; parity with the reference's vectors in test_variants.py;
+    on the GPU -phase_sym is inside the fused kernel families: test_variants_gpu.py)."""
     sys.path.insert(0, PKG)
     import oracle_backend
     from experiments import _base

@@ -23,6 +23,8 @@ torch = pytest.importorskip("torch")
 
 FUSED = ["LiH_noampsym", "LiH_fullmask", "N2_noampsym", "N2_nomask", "N2_0.75_fullmask", "N2_2.25_fullmask",
          "LiH_aggphase", "N2_aggphase",
+         # -phase_sym with the single phase block (round 5): spin-ordered inputs, 3 outputs, the sign shift — on the kernels
+         "LiH_phasesym", "LiH_phasesym_agg",
          # open shell restricted to m_s = S (experiments/_base.py:101-123): CH2 triplet, 5 alpha / 3 beta electrons, no amp symmetry
          "CH2_noampsym", "CH2_fullmask_noampsym"]
 EAGER = []
@@ -75,7 +77,7 @@ def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
     opt = _opt(mol, wf, tmp_path)
     from naqs_amd.flat_adam import FlatAdam
     assert wf.fused() is not None and isinstance(opt.optimizer, FlatAdam)
-    assert wf.fused().aggregate == fix.endswith("aggphase")
+    assert wf.fused().aggregate == (fix.endswith("aggphase") or fix.endswith("phasesym_agg"))
     states = torch.tensor(z["samp_states"], device="cuda")
     counts = torch.tensor(z["samp_counts"], device="cuda")
     keys = hil.state2idx(states).squeeze(-1)
@@ -100,9 +102,9 @@ def test_sgd_step_matches_reference_step_on_device(fix, tmp_path, capsys):
             assert d[flipped].max() < 2.1e-3 and g[flipped].max() <= 1e-3 * g.max(), (name, d[flipped].max())
 
 
-@pytest.mark.parametrize("fix", ["LiH_phasesym", "LiH_phasesym_agg", "LiH_combampphase"])
+@pytest.mark.parametrize("fix", ["LiH_combampphase"])
 def test_live_options_outside_the_fused_family_run_on_device(fix, tmp_path, capsys):
-    """-phase_sym / -comb_amp_phase (no published script uses them): PyTorch modules on the device, announced once, with
+    """-comb_amp_phase (no published script uses it): PyTorch modules on the device, announced once, with
     the HIP E_loc kernel underneath — log psi and one whole _SGD_step against the reference's recorded vectors."""
     mol, z, hil, wf = _wf(fix)
     assert wf.fused() is None
@@ -122,6 +124,62 @@ def test_live_options_outside_the_fused_family_run_on_device(fix, tmp_path, caps
         assert np.max(np.abs(p.detach().cpu().numpy() - z["sd_after:" + name])) < 2e-5, name
     opt.run(3, output_freq=10 ** 6)                       # and the training loop (PyTorch sampler, HIP E_loc) runs
     assert opt.n_steps == 3
+
+
+@pytest.mark.parametrize("fix,fmt", [("LiH_phasesym", "2"), ("LiH_phasesym", "1"), ("LiH_phasesym", "0"), ("LiH_phasesym_agg", "2")])
+def test_phase_spin_symmetry_on_the_kernels(fix, fmt, tmp_path, monkeypatch, capsys):
+    """-phase_sym (nade.py:281, 507-533, 590-610) inside the fused families — the single phase block (the phase kernels) and the
+    per-pair phase blocks of the run.py default (the amplitude kernels in raw mode, every block ordering ITS prefix): spin-ordered inputs
+    (alpha / beta strings of the first P-1 pairs exchanged where idx(alpha) > idx(beta)), a 3-output layer whose middle row
+    serves |01> and |10>, + pi (N_01 mod 2) where idx(alpha) < idx(beta).  log psi in all three number formats of the phase
+    kernels and the training gradients against autograd through the PyTorch modules (themselves held to the reference's
+    vectors in test_variants.py); then the whole loop — device sampler, one-call training steps — runs."""
+    monkeypatch.setenv("NAQS_PHASE_MODE", fmt)
+    mol, z, hil, wf = _wf(fix)
+    agg = fix.endswith("_agg")
+    fused = wf.fused()
+    assert fused is not None and fused.phase_sym and fused.aggregate == agg
+    assert all(blk.linears()[-1].out_features == 3 for blk in wf.model.phase_layers) and len(wf.model.phase_layers) == (wf.model.P if agg else 1)
+    keys = torch.as_tensor(np.concatenate([z["eval_keys"], z["samp_keys"]]).astype(np.int64), device="cuda")
+    states = hil.idx2state(keys)
+    # the fixture's rows exercise every branch: inputs exchanged / not, shifted / not, all four outcomes of the last pair
+    P = wf.model.P
+    bits = (states.reshape(len(keys), -1) > 0).long()[:, wf._q2m]               # model order: pair k = (alpha, beta) at columns 2k, 2k + 1
+    pw = (1 << torch.arange(P, device="cuda")).long()
+    ia, ib = (bits[:, 0::2] * pw).sum(1), (bits[:, 1::2] * pw).sum(1)
+    ia1, ib1 = (bits[:, 0:2 * (P - 1):2] * pw[:P - 1]).sum(1), (bits[:, 1:2 * (P - 1):2] * pw[:P - 1]).sum(1)
+    n01 = ((bits[:, 0::2] == 0) & (bits[:, 1::2] == 1)).sum(1)
+    assert (ia1 > ib1).any() and (ia1 < ib1).any() and ((ia < ib) & (n01 % 2 == 1)).any() and ((ia < ib) & (n01 % 2 == 0)).any()
+    assert len(torch.unique(bits[:, 2 * (P - 1)] + 2 * bits[:, 2 * (P - 1) + 1])) >= 3
+    lp_k = fused.log_psi(keys)
+    lp_t = wf.log_psi(states).reshape(-1, 2)
+    if not agg:
+        assert fused.last_kernel().startswith({"2": "phase_kernel_h<", "1": "phase_kernel_h<", "0": "phase_kernel<"}[fmt])
+    assert torch.max(torch.abs(lp_t.detach() - lp_k)).item() < 2e-5
+    if fmt != "2":
+        return
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g = torch.randn((len(keys), 2), device="cuda", generator=gen) / len(keys)
+    lp_s, saved = fused.forward_saved(keys)
+    assert torch.max(torch.abs(lp_s - lp_k)).item() < 1e-6
+    for p in wf.model.parameters():
+        p.grad = None
+    fused.backward_saved(saved, g)
+    mine = {n: p.grad.clone() for n, p in wf.model.named_parameters()}
+    for p in wf.model.parameters():
+        p.grad = None
+    (g * lp_t).sum().backward()
+    for n, p in wf.model.named_parameters():
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((mine[n] - p.grad).abs().max()) < 2e-5 * scale + 1e-10, n
+    assert all(float(blk.linears()[-1].weight.grad.abs().max(1).values.min()) > 0 for blk in wf.model.phase_layers)     # all three rows learn
+    for p in wf.model.parameters():
+        p.grad = None
+    opt = _opt(mol, wf, tmp_path)
+    assert opt._can_onecall()
+    opt.run(5, output_freq=10 ** 6, save_final=False)
+    assert opt.n_steps == 5 and np.isfinite(opt.log[__import__("naqs_amd.optimizer", fromlist=["LogKey"]).LogKey.E_LOC][-1][1])
+    assert "fused HIP network kernels not available" not in capsys.readouterr().out
 
 
 @pytest.mark.parametrize("fix", ["LiH_aggphase", "N2_aggphase"])
