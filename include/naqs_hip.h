@@ -486,6 +486,12 @@ int naqs_vmc_shard_update(naqs_net_t *net, const float *grad_dev, float *param_d
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */
 int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out);
 int naqs_rng_philox_host(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* The sampler's GROUP draws on the device (the code a tree level runs: `group` = 4 lanes per draw as in the first split of a
+ * prefix's count, 2 as in the second), for statistical tests: out_dev[i] = Binomial(n_dev[i % cases], p_dev[i % cases]) from
+ * stream (seed, i), i < reps — neighbouring draws of a wave take different cases, so waves hold the inversion and the BTRS
+ * regime side by side.  n <= 2^44.  No counterpart in the reference (numpy's generator, nade.py:20-37). */
+int naqs_rng_binomial_device(int group, int cases, const int64_t *n_dev, const double *p_dev, uint64_t seed, int64_t reps,
+                             int64_t *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1085,6 +1085,35 @@ NAQS_API int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t 
     return NAQS_OK;
 }
 
+// The group draws of the tree sampler on the device, for statistical tests of exactly the code the sampler runs: draw i is
+// binomial_group<G> of (n_i, p_i) — arrays of `cases` entries, draw i taking entry i % cases, so that one wave holds draws of
+// different regimes side by side like a tree level does — keyed by (seed, i).
+namespace {
+template <int G>
+__global__ __launch_bounds__(256) void binomial_group_test_kernel(const int64_t *__restrict__ n, const double *__restrict__ p,
+                                                                  const int cases, const uint32_t k0, const uint32_t k1,
+                                                                  const int64_t reps, int64_t *__restrict__ out) {
+    const int64_t lane_id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = lane_id / G;                          // the draw of this group of G lanes
+    const bool need = i < reps;
+    const int c = (int)(i % cases);
+    const int64_t v = naqs::binomial_group<G>(need, need ? n[c] : 0, need ? p[c] : 0.0, k0, k1, (uint32_t)i, (uint32_t)(i >> 32));
+    if (need && (lane_id % G) == 0) out[i] = v;
+}
+}  // namespace
+
+NAQS_API int naqs_rng_binomial_device(int group, int cases, const int64_t *n_dev, const double *p_dev, uint64_t seed, int64_t reps,
+                                      int64_t *out_dev, void *stream) {
+    if ((group != 2 && group != 4) || cases <= 0 || !n_dev || !p_dev || reps < 0 || (reps > 0 && !out_dev)) return NAQS_ERR_INVALID;
+    if (reps == 0) return NAQS_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((reps * group + 255) / 256);
+    if (group == 4) NAQS_KLAUNCH(binomial_group_test_kernel<4>, dim3(grid), dim3(256), 0, s, n_dev, p_dev, cases, (uint32_t)seed, (uint32_t)(seed >> 32), reps, out_dev);
+    else NAQS_KLAUNCH(binomial_group_test_kernel<2>, dim3(grid), dim3(256), 0, s, n_dev, p_dev, cases, (uint32_t)seed, (uint32_t)(seed >> 32), reps, out_dev);
+    HIP_TRY(hipGetLastError());
+    return NAQS_OK;
+}
+
 NAQS_API int naqs_rng_philox_host(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
     if (!counter || !key || !out) return NAQS_ERR_INVALID;
     const uint32_t c[4] = {counter[0], counter[1], counter[2], counter[3]};

@@ -82,6 +82,7 @@ SIGNATURES = {
     "naqs_vmc_loss_grad": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_loss_grad_ev": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_rng_binomial_host": (ctypes.c_int, [c_i64, ctypes.c_double, ctypes.c_uint64, c_i64, c_vp]),
+    "naqs_rng_binomial_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_uint64, c_i64, c_vp, c_vp]),
     "naqs_rng_philox_host": (ctypes.c_int, [c_vp, c_vp, c_vp]),
 }
 

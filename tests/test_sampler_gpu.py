@@ -197,3 +197,48 @@ def test_sampler_weights_are_counts_over_total():
     assert torch.equal(keys, k2) and torch.equal(counts, c2) and torch.equal(probs, p2)
     want = counts.double() / counts.sum().double()
     assert weights.dtype == torch.float64 and torch.equal(weights, want) and abs(weights.sum().item() - 1) < 1e-12
+
+
+# the generator itself on the device: exactly the group draws a tree level runs (binomial_group<4> / <2>, round 5: their own
+# log / exp, shared Stirling remainders, one quotient per lane), cases of both regimes interleaved within every wave
+GROUP_CASES = [(5, 0.3), (20, 0.4), (100, 0.05), (190, 0.05), (240, 0.05), (1000, 0.013), (1000, 0.5), (50, 0.9), (200, 0.94),
+               (5000, 0.37), (10 ** 6, 1e-5), (10 ** 6, 1.2e-5), (10 ** 9, 2e-8), (10 ** 12, 1e-11), (10 ** 12, 0.37), (2 ** 44, 0.5)]
+
+
+@pytest.mark.parametrize("group", [4, 2])
+def test_group_draws_on_the_device_match_the_binomial_pmf(group):
+    """chi-square of every case's draws against scipy's exact pmf (bins with >= 5 expected counts; for the two largest n the
+    first two moments instead), drawn in ONE launch with the cases interleaved lane group by lane group."""
+    import ctypes
+    from naqs_amd import _lib
+    lib = _lib.load_library()
+    C = len(GROUP_CASES)
+    per = 300000
+    reps = per * C
+    n = torch.tensor([c[0] for c in GROUP_CASES], dtype=torch.int64, device="cuda")
+    p = torch.tensor([c[1] for c in GROUP_CASES], dtype=torch.float64, device="cuda")
+    out = torch.empty(reps, dtype=torch.int64, device="cuda")
+    _lib.check(lib.naqs_rng_binomial_device(group, C, n.data_ptr(), p.data_ptr(), ctypes.c_uint64(20260000 + group), reps,
+                                            out.data_ptr(), torch.cuda.current_stream().cuda_stream), "naqs_rng_binomial_device")
+    torch.cuda.synchronize()
+    x_all = out.cpu().numpy().reshape(per, C)
+    for ci, (nn, pp) in enumerate(GROUP_CASES):
+        x = x_all[:, ci]
+        assert x.min() >= 0 and x.max() <= nn, (nn, pp)
+        mu, sd = nn * pp, np.sqrt(nn * pp * (1 - pp))
+        if nn >= 10 ** 12 and sd > 1e3:
+            z = (x.astype(np.float64) - mu) / sd
+            assert abs(z.mean()) < 5 / np.sqrt(per) and abs(z.var() - 1) < 5 * np.sqrt(2 / per), (nn, pp, z.mean(), z.var())
+            continue
+        lo, hi = int(max(0, np.floor(mu - 7 * sd))), int(min(nn, np.ceil(mu + 7 * sd)))
+        ks = np.arange(lo, hi + 1)
+        expect = stats.binom.pmf(ks, nn, pp) * per
+        obs = np.bincount(np.clip(x - lo, 0, hi - lo), minlength=hi - lo + 1)[:hi - lo + 1]
+        m = expect >= 5
+        chi2 = ((obs[m] - expect[m]) ** 2 / expect[m]).sum()
+        assert stats.chi2.sf(chi2, m.sum() - 1) > 1e-5, (group, nn, pp, chi2, m.sum() - 1)
+    # a pure function of (seed, i): the same call again gives the same draws
+    out2 = torch.empty_like(out)
+    _lib.check(lib.naqs_rng_binomial_device(group, C, n.data_ptr(), p.data_ptr(), ctypes.c_uint64(20260000 + group), reps,
+                                            out2.data_ptr(), torch.cuda.current_stream().cuda_stream), "naqs_rng_binomial_device")
+    assert torch.equal(out, out2)
