@@ -42,6 +42,20 @@ extern "C" __attribute__((visibility("default"))) int naqs_debug_sample_stats(un
 }
 #endif
 
+#if defined(NAQS_HEAD_CLOCKS)
+// (developer build only, tools/head_clock_probe.py) cycle stamps of sample_head_kernel's thread 0, accumulated over calls:
+// [level][0 level begins, 1 probabilities in registers, 2 both draws done, 3 children compacted and written] + [7][0] = calls
+__device__ long long g_head_clk[8][4];
+extern "C" __attribute__((visibility("default"))) int naqs_debug_head_clocks(long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_clk), 32 * sizeof(long long)) != hipSuccess) return -1;
+    long long zero[32] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_head_clk), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#define HEAD_MARK(level, stage) do { if (threadIdx.x == 0) g_head_clk[level][stage] += clock64() - head_t0; } while (0)
+#else
+#define HEAD_MARK(level, stage) do {} while (0)
+#endif
+
 namespace {
 
 using naqs::MAXP;
@@ -80,6 +94,22 @@ __global__ void sample_init_kernel(SampleBufs b, int64_t n_samples) {
 // level is known (the workgroup that closes the look-back chain), i.e. while the rest of that launch and the weights launch are
 // still running, and again by the finish job (the paths that do not end in the fused level kernel).)
 using naqs::publish_info;
+
+// inclusive prefix sum over the 64 lanes of a wave with DPP moves: shifts by 1, 2, 4, 8 within the rows of 16 lanes, then lane 15
+// of rows 0 / 2 to rows 1 / 3 and lane 31 to the upper half (row_bcast) — seven VALU instructions where six __shfl_up rounds go
+// through the LDS crossbar (ds_bpermute: ~100 cycles each on the chain that ends every tree level; round 5: 2.2-3.3 k cycles of
+// compaction per level in tools/head_clock_probe.py).  Integers: the same sums in any order.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#define NAQS_SCAN_STEP(CTRL, ROW_MASK) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false)
+    NAQS_SCAN_STEP(0x111, 0xF);      // row_shr:1 (lanes without a source add the `old` operand, 0)
+    NAQS_SCAN_STEP(0x112, 0xF);      // row_shr:2
+    NAQS_SCAN_STEP(0x114, 0xF);      // row_shr:4
+    NAQS_SCAN_STEP(0x118, 0xF);      // row_shr:8
+    NAQS_SCAN_STEP(0x142, 0xA);      // row_bcast:15 -> rows 1 and 3
+    NAQS_SCAN_STEP(0x143, 0xC);      // row_bcast:31 -> rows 2 and 3
+#undef NAQS_SCAN_STEP
+    return v;
+}
 
 // quad (4 consecutive lanes) sum: every lane of the quad gets the total
 __device__ __forceinline__ float quad_sum(float v) {
@@ -356,12 +386,7 @@ __global__ __launch_bounds__(SB) void sample_level_kernel(const NetDims d, const
 #pragma unroll
         for (int c = 0; c < 4; ++c) mine += out[c] > 0 ? 1u : 0u;
     // inclusive scan of `mine` over the workgroup (only quad owners contribute)
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
+    const uint32_t incl = wave_inclusive_scan(mine);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     uint32_t before = 0, total = 0;
@@ -523,12 +548,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         if (owner)
 #pragma unroll
             for (int c = 0; c < 4; ++c) mine += out[c] > 0 ? 1u : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
+        const uint32_t incl = wave_inclusive_scan(mine);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
         uint32_t before = 0, total = 0;
@@ -683,10 +703,15 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         if (AHEAD_OK) s_cand[0][0] = 0;
     }
     int U = 1;
+#if defined(NAQS_HEAD_CLOCKS)
+    const long long head_t0 = clock64();
+    if (threadIdx.x == 0) g_head_clk[7][0] += 1;
+#endif
 #pragma unroll 1
     for (int n = 0; n < HL; ++n) {                         // (not unrolled, one call site of the draws: see sample_multi_kernel)
         const int cur = n & 1, nxt = cur ^ 1;
         __syncthreads();                                   // previous level's LDS writes / everyone done with s_w
+        HEAD_MARK(n, 0);
         if (wamp == nullptr) stage_pair_weights(d, w, n, s_w, HT);
         const bool active = u < U;
         const uint32_t ab = active ? s_ab[cur][u] : 0u;
@@ -711,17 +736,14 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         } else {
             expand_probs(d, s_w, n, ab, p, phys, nullptr, wamp);
         }
+        HEAD_MARK(n, 1);
         if (draws) split_quad(n, ab, cnt, k0, k1, p, phys, out, nullptr);
+        HEAD_MARK(n, 2);
         uint32_t mine = 0;                                 // survivors of this quad's prefix, held by its first lane
         if (active && q == 0)
 #pragma unroll
             for (int c = 0; c < 4; ++c) mine += out[c] > 0 ? 1u : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
+        const uint32_t incl = wave_inclusive_scan(mine);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
         uint32_t before = 0, total = 0;
@@ -746,6 +768,7 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
         }
         U = (int)total;
         if (tid == 0) b.U[n + 1] = total;
+        HEAD_MARK(n, 3);
     }
 }
 
@@ -775,12 +798,7 @@ __global__ __launch_bounds__(SB) void sample_scatter_kernel(const NetDims d, con
         for (int c = 0; c < 4; ++c) { cc[c] = b.child_cnt[u * 4 + c]; mine += cc[c] > 0 ? 1u : 0u; }
     }
     // exclusive scan of `mine` over the workgroup
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
+    const uint32_t incl = wave_inclusive_scan(mine);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     int64_t base = 0;
