@@ -52,8 +52,18 @@ extern "C" __attribute__((visibility("default"))) int naqs_debug_head_clocks(lon
     return hipMemcpyToSymbol(HIP_SYMBOL(g_head_clk), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #define HEAD_MARK(level, stage) do { if (threadIdx.x == 0) g_head_clk[level][stage] += clock64() - head_t0; } while (0)
+// ... and of sample_multi_kernel's first and last workgroup: [launch: 0 not the last of the call, 1 the last][workgroup: 0 first,
+// 1 last][row: level 0..3 of the launch, 4 = look-back / children written / kernel ends, 5 = (launches counted, NL summed)][stage]
+__device__ long long g_multi_clk[2][2][6][4];
+extern "C" __attribute__((visibility("default"))) int naqs_debug_multi_clocks(long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_multi_clk), 96 * sizeof(long long)) != hipSuccess) return -1;
+    long long zero[96] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_multi_clk), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#define MULTI_MARK(row, stage) do { if (threadIdx.x == 0 && mm_wg >= 0) g_multi_clk[last ? 1 : 0][mm_wg][row][stage] += clock64() - mm_t0; } while (0)
 #else
 #define HEAD_MARK(level, stage) do {} while (0)
+#define MULTI_MARK(row, stage) do {} while (0)
 #endif
 
 namespace {
@@ -499,6 +509,11 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
     const int tid = threadIdx.x, u = tid >> 2, lane = tid & 63, wave = tid >> 6;
     const int entries = (int)min((int64_t)E, U - (int64_t)blockIdx.x * E);
     int U_loc = entries;
+#if defined(NAQS_HEAD_CLOCKS)
+    const long long mm_t0 = clock64();
+    const int mm_wg = blockIdx.x == 0 ? 0 : ((int64_t)blockIdx.x == nwg - 1 ? 1 : -1);
+    if (threadIdx.x == 0 && mm_wg >= 0) { g_multi_clk[last ? 1 : 0][mm_wg][5][0] += 1; g_multi_clk[last ? 1 : 0][mm_wg][5][1] += NL; g_multi_clk[last ? 1 : 0][mm_wg][5][2] += nwg; }
+#endif
     uint32_t mid_a = 0u, mid_b = 0u, mid_c = 0u;           // this workgroup's prefixes at the launch's 2nd (3rd, 4th) level
     // (not unrolled, and ONE call site of the binomial draws per level: the level body with its float64 generator inlined is
     // ~5 k instructions; NL unrolled copies with two call sites each were 190 KB of straight-line code for NL = 4, and no
@@ -524,6 +539,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
             stage_pair_weights(d, w, lev, s_w, SB);
         }
         __syncthreads();
+        MULTI_MARK(li, 0);
         int64_t out[4] = {0, 0, 0, 0};
         float p[4] = {0.f, 0.f, 0.f, 0.f};
         bool phys[4] = {false, false, false, false};
@@ -542,7 +558,9 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         } else {
             expand_probs(d, s_w, lev, ab, p, phys, nullptr, wamp);
         }
+        MULTI_MARK(li, 1);
         if (draws) split_quad(lev, ab, cnt, k0, k1, p, phys, out, nullptr);
+        MULTI_MARK(li, 2);
         const bool owner = active && (tid & 3) == 0;
         uint32_t mine = 0;
         if (owner)
@@ -551,6 +569,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         const uint32_t incl = wave_inclusive_scan(mine);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
+        MULTI_MARK(li, 3);
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < SB / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
@@ -612,6 +631,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
             if (lane == 0) { s_base[0] = all_ok ? part : -1; s_base[1] = part_a; s_base[2] = part_b; s_base[3] = part_c; }
         }
         __syncthreads();
+        MULTI_MARK(4, 0);
         const int64_t base = s_base[0];
         if (base < 0) {                                    // a look-back wait ran out (see sample_level_kernel)
             if (tid == 0) b.U[MAXP + 1] = 1;
@@ -659,6 +679,7 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
             if (over) b.U[MAXP + 1] = 1;
             if (last && early != nullptr) publish_info(early, over ? 0 : all, over ? 1 : 0, seq);
         }
+        MULTI_MARK(4, 1);
     }
 }
 

@@ -24,3 +24,23 @@ for n in range(4):
     t = a[n] / calls
     print(f"  level {n}: begins {t[0]:8.0f} | probabilities +{t[1] - t[0]:7.0f} | two draws +{t[2] - t[1]:7.0f} | compaction +{t[3] - t[2]:7.0f} | level total {t[3] - prev:7.0f}")
     prev = t[3]
+
+mbuf = (ctypes.c_longlong * 96)()
+assert raw.naqs_debug_multi_clocks(mbuf) == 0
+m = np.array(list(mbuf), dtype=np.float64).reshape(2, 2, 6, 4)
+for last in (0, 1):
+    for wg in (0, 1):
+        calls, nl, nwg = m[last, wg, 5, 0], m[last, wg, 5, 1], m[last, wg, 5, 2]
+        if not calls:
+            continue
+        print(f"  sample_multi_kernel, {'last' if last else 'first'} multi-level launch, {'last' if wg else 'first'} workgroup: {int(calls)} launches, "
+              f"{nl / calls:.1f} levels, {nwg / calls:.0f} workgroups")
+        prev = 0.0
+        for li in range(4):
+            t4 = m[last, wg, li] / calls
+            if t4[3] == 0:
+                continue
+            print(f"    level +{li}: begins {t4[0]:8.0f} | probabilities +{t4[1] - t4[0]:7.0f} | two draws +{t4[2] - t4[1]:7.0f} | scan + barrier +{t4[3] - t4[2]:7.0f} | since previous {t4[3] - prev:7.0f}")
+            prev = t4[3]
+        e = m[last, wg, 4] / calls
+        print(f"    look-back done {e[0]:8.0f} (+{e[0] - prev:.0f}) | children written {e[1]:8.0f} (+{e[1] - e[0]:.0f})")
