@@ -121,6 +121,31 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// Where lane c of a quad writes the prefix's child c: all four lanes hold the children counts `out` (split_quad) and the quad's
+// first lane holds the position `first` of the prefix's first surviving child (exclusive scan of the survivors); the children
+// stay in (prefix, outcome) order.  live: child c survived.  One store round per level instead of the first lane's loop.
+struct ChildSlot {
+    bool live; int pos; int64_t cnt;
+    __device__ __forceinline__ float p(const float (&pp)[4]) const { const int c = threadIdx.x & 3; return c == 0 ? pp[0] : (c == 1 ? pp[1] : (c == 2 ? pp[2] : pp[3])); }
+};
+struct ChildSlot64 {
+    bool live; int64_t pos; int64_t cnt;
+    __device__ __forceinline__ float p(const float (&pp)[4]) const { const int c = threadIdx.x & 3; return c == 0 ? pp[0] : (c == 1 ? pp[1] : (c == 2 ? pp[2] : pp[3])); }
+};
+__device__ __forceinline__ ChildSlot child_slot(const int64_t (&out)[4], const int first, const int c) {
+    const int f = naqs::dpp_quad<0x00>(first);            // the first lane's value to the whole quad
+    const int rank = (c > 0 && out[0] > 0 ? 1 : 0) + (c > 1 && out[1] > 0 ? 1 : 0) + (c > 2 && out[2] > 0 ? 1 : 0);
+    const int64_t mine = c == 0 ? out[0] : (c == 1 ? out[1] : (c == 2 ? out[2] : out[3]));
+    return ChildSlot{mine > 0, f + rank, mine};
+}
+__device__ __forceinline__ ChildSlot64 child_slot64(const int64_t (&out)[4], const int64_t first, const int c) {
+    const int lo = naqs::dpp_quad<0x00>((int)(uint32_t)first), hi = naqs::dpp_quad<0x00>((int)(uint32_t)((uint64_t)first >> 32));
+    const int64_t f = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    const int rank = (c > 0 && out[0] > 0 ? 1 : 0) + (c > 1 && out[1] > 0 ? 1 : 0) + (c > 2 && out[2] > 0 ? 1 : 0);
+    const int64_t mine = c == 0 ? out[0] : (c == 1 ? out[1] : (c == 2 ? out[2] : out[3]));
+    return ChildSlot64{mine > 0, f + rank, mine};
+}
+
 // quad (4 consecutive lanes) sum: every lane of the quad gets the total
 __device__ __forceinline__ float quad_sum(float v) {
     v += __int_as_float(naqs::dpp_quad<0xB1>(__float_as_int(v)));      // quad_perm [1, 0, 3, 2]: lane ^ 1
@@ -575,17 +600,15 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
         for (int i = 0; i < SB / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
         if (li + 1 < NL) {
             // next level of this launch: children -> LDS, in (prefix, outcome) order
-            if (owner && mine) {
-                int pos = (int)(before + (incl - mine));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (out[c] > 0) {
-                        s_ab[(li + 1) & 1][pos] = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
-                        s_cnt[(li + 1) & 1][pos] = out[c];
-                        s_prob[(li + 1) & 1][pos] = pr * p[c];
-                        s_cand[(li + 1) & 1][pos] = (uint8_t)(cand * 4 + c);
-                        ++pos;
-                    }
+            {   // (every lane of the quad writes its own child: child_slot)
+                const int c = tid & 3;
+                const ChildSlot cs = child_slot(out, (int)(before + (incl - mine)), c);
+                if (active && cs.live) {
+                    const int pos = cs.pos;
+                    s_ab[(li + 1) & 1][pos] = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
+                    s_cnt[(li + 1) & 1][pos] = cs.cnt;
+                    s_prob[(li + 1) & 1][pos] = pr * cs.p(p);
+                    s_cand[(li + 1) & 1][pos] = (uint8_t)(cand * 4 + c);
                 }
             }
             U_loc = (int)total;
@@ -637,34 +660,32 @@ __global__ __launch_bounds__(SB) void sample_multi_kernel(const NetDims d, const
             if (tid == 0) b.U[MAXP + 1] = 1;
             return;
         }
-        int64_t pos = base + before + (incl - mine);
-        if (owner && mine) {
+        {
             // the OTHER half of the global ping-pong arrays, whatever NL: this launch's workgroups read their entry prefixes
             // from half `cur` at their own pace (a workgroup may start after others have finished), so nothing may be written
             // there — with `(cur + NL) & 1` a two-level launch wrote its output over its own input
+            // (every lane of the quad writes its own child — child_slot — and forms its own key: these stores are the tail of
+            // the whole sampler call, 5-9 k cycles as one lane's loop over four children with the bit scatter inside)
             const int nxt = cur ^ 1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (out[c] > 0) {
-                    if (pos < cap) {
-                        const uint32_t child = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
-                        const float prc = pr * p[c];
-                        if (last) {
-                            uint64_t key = 0;
-                            for (int k = 0; k < d.P; ++k) {
-                                key |= (uint64_t)((child >> k) & 1u) << d.qa[k];
-                                key |= (uint64_t)((child >> (16 + k)) & 1u) << d.qb[k];
-                            }
-                            keys_out[pos] = key;
-                            counts_out[pos] = out[c];
-                            if (probs_out) probs_out[pos] = prc;
-                        } else {
-                            b.ab[nxt][pos] = child;
-                            b.cnt[nxt][pos] = out[c];
-                            b.prob[nxt][pos] = prc;
-                        }
+            const int c = tid & 3;
+            const ChildSlot64 cs = child_slot64(out, base + before + (incl - mine), c);
+            if (active && cs.live && cs.pos < cap) {
+                const int64_t pos = cs.pos;
+                const uint32_t child = ab | ((uint32_t)(c & 1) << lev) | ((uint32_t)(c >> 1) << (16 + lev));
+                const float prc = pr * cs.p(p);
+                if (last) {
+                    uint64_t key = 0;
+                    for (int k = 0; k < d.P; ++k) {
+                        key |= (uint64_t)((child >> k) & 1u) << d.qa[k];
+                        key |= (uint64_t)((child >> (16 + k)) & 1u) << d.qb[k];
                     }
-                    ++pos;
+                    keys_out[pos] = key;
+                    counts_out[pos] = cs.cnt;
+                    if (probs_out) probs_out[pos] = prc;
+                } else {
+                    b.ab[nxt][pos] = child;
+                    b.cnt[nxt][pos] = cs.cnt;
+                    b.prob[nxt][pos] = prc;
                 }
             }
         }
@@ -771,19 +792,16 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
 #pragma unroll
         for (int i = 0; i < HT / WAVE; ++i) { if (i < wave) before += s_wave[i]; total += s_wave[i]; }
         const bool to_global = n + 1 == HL;                // the last head level feeds the per-level kernels
-        if (mine) {
-            int pos = (int)(before + (incl - mine));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (out[c] > 0) {
-                    const uint32_t child = ab | ((uint32_t)(c & 1) << n) | ((uint32_t)(c >> 1) << (16 + n));
-                    if (to_global) {
-                        b.ab[(n + 1) & 1][pos] = child; b.cnt[(n + 1) & 1][pos] = out[c]; b.prob[(n + 1) & 1][pos] = pr * p[c];
-                    } else {
-                        s_ab[nxt][pos] = child; s_cnt[nxt][pos] = out[c]; s_prob[nxt][pos] = pr * p[c];
-                        if (AHEAD_OK) s_cand[nxt][pos] = (uint8_t)(cand * 4 + c);
-                    }
-                    ++pos;
+        {   // every lane of the quad writes ITS child (all four hold the counts): one store round instead of a loop of four
+            const ChildSlot cs = child_slot(out, (int)(before + (incl - mine)), q);
+            if (active && cs.live) {
+                const int c = q, pos = cs.pos;
+                const uint32_t child = ab | ((uint32_t)(c & 1) << n) | ((uint32_t)(c >> 1) << (16 + n));
+                if (to_global) {
+                    b.ab[(n + 1) & 1][pos] = child; b.cnt[(n + 1) & 1][pos] = cs.cnt; b.prob[(n + 1) & 1][pos] = pr * cs.p(p);
+                } else {
+                    s_ab[nxt][pos] = child; s_cnt[nxt][pos] = cs.cnt; s_prob[nxt][pos] = pr * cs.p(p);
+                    if (AHEAD_OK) s_cand[nxt][pos] = (uint8_t)(cand * 4 + c);
                 }
             }
         }
