@@ -29,6 +29,7 @@ in it is measured by this run except the fields tagged `"replayed": true` (hardw
 rocprofv3 --pmc pass can produce: they are read from the committed profiles/ file named beside them).
 """
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -263,10 +264,15 @@ def train_step_probe(dev, molecule, steps=300, warmup=40, n_samples=1000000):
         s_ms, s_n = fused.prof_read()
         fused.prof_enable(0)
         _lib.check(lib.naqs_net_prof_select(fused._h, 0), "naqs_net_prof_select")
+        # the training forward is queued behind the sampler before the host knows M (naqs_net_spec_counts): launched / stood
+        spec = (ctypes.c_int64 * 2)()
+        _lib.check(lib.naqs_net_spec_counts(fused._h, spec), "naqs_net_spec_counts")
     m = [x[1] for x in opt.log[LogKey.N_UNIQUE_SAMP][-steps:]]
     return {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "sampler_us": s_ms / max(s_n, 1) * 1e3,
             "launches_per_step": (l1 - l0) / steps, "unique_samples_mean": float(np.mean(m)), "unique_samples_last": int(m[-1]),
-            "n_samples": int(opt.n_samples), "E_loc_last": float(opt.log[LogKey.E_LOC][-1][1]), "path": path}
+            "n_samples": int(opt.n_samples), "E_loc_last": float(opt.log[LogKey.E_LOC][-1][1]), "path": path,
+            "forward_ahead_of_M": {"launched": int(spec[0]), "stood": int(spec[1]), "over": "warm-up + timed steps"},
+            "sampler_us_note": "the sampler's own launches; its one-workgroup finish job rides in the forward launch"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
