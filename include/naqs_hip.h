@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 7
+#define NAQS_ABI_VERSION 8
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -486,6 +486,10 @@ int naqs_vmc_shard_update(naqs_net_t *net, const float *grad_dev, float *param_d
  * out[i] = Binomial(n, p) drawn from stream (seed, i);  Philox4x32-10 block function. */
 int naqs_rng_binomial_host(int64_t n, double p, uint64_t seed, int64_t reps, int64_t *out);
 int naqs_rng_philox_host(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* The generator's own elementary functions on the host (the code the device runs, except for its refined reciprocal), for
+ * accuracy tests: y[i] = f(x[i]) with fn 0: log (x > 0, normal), 1: log(1 - x) (0 < x <= 1/2), 2: exp (-745 < x <= 0),
+ * 3: the uniform on (0, 1) made from the two 32-bit words packed in x[i]'s bit pattern (hi << 32 | lo). */
+int naqs_rng_math_host(int fn, int64_t n, const double *x, double *y);
 /* The sampler's GROUP draws on the device (the code a tree level runs: `group` = 4 lanes per draw as in the first split of a
  * prefix's count, 2 as in the second), for statistical tests: out_dev[i] = Binomial(n_dev[i % cases], p_dev[i % cases]) from
  * stream (seed, i), i < reps — neighbouring draws of a wave take different cases, so waves hold the inversion and the BTRS

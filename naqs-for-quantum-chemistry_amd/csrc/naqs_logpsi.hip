@@ -1287,7 +1287,10 @@ __global__ __launch_bounds__(PH_THREADS) void phase_kernel_ws(const NetDims d, c
     const int tile = SPLIT && !producer ? bx - n_tiles : bx;
     const int64_t row0 = (int64_t)tile * BM;
     if (split.spec_U != nullptr) {                        // launched ahead of the host's look at the sampler's M (workgroup-uniform)
-        M = split.spec_U[MAXP + 1] != 0 ? 0 : split.spec_U[split.spec_P];
+        // never more rows than the launch was sized for (the argument: the host's cover) — the scratch behind `save`, `feed`
+        // and `out` is only guaranteed for that many; a table that outgrew the cover is a miss the host relaunches anyway
+        const int64_t m_dev = split.spec_U[MAXP + 1] != 0 ? 0 : split.spec_U[split.spec_P];
+        M = m_dev < M ? m_dev : M;
         if (row0 >= M) return;                            // (both halves of a shared tile leave)
     }
     const int P = d.P, ldh = d.ldh;

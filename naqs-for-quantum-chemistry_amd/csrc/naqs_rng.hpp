@@ -86,6 +86,10 @@ NAQS_HD double rcp_fast(double x) {
 // float64 generator meets with a margin of 2^-9 at the largest supported n (2^44).  Host and device run the same arithmetic
 // except for the reciprocal (rcp_fast).
 // log(x), x > 0 finite and normal: x = 2^e m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716
+// (No guard for x <= 0, on purpose — it would sit on every draw's critical chain: the smallest argument this generator ever forms
+// is the exact test's v alpha us^2 / (a + b us^2) with v, us >= 2^-54 (u01 below never returns 0: its smallest value is
+// (0 + 1/2) 2^-53), alpha = O(1) and a + b us^2 <= a + b / 4 = O(sqrt(n)) <= 2^23, i.e. >= 2^-190: normal.  The host test
+// test_generator_log_has_no_zero_argument holds u01's bounds.)
 NAQS_HD double log_fast(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double m = __builtin_amdgcn_frexp_mant(x);                  // [1/2, 1)

@@ -1179,3 +1179,20 @@ NAQS_API int naqs_rng_philox_host(const uint32_t counter[4], const uint32_t key[
     for (int i = 0; i < 4; ++i) out[i] = r[i];
     return NAQS_OK;
 }
+
+NAQS_API int naqs_rng_math_host(int fn, int64_t n, const double *x, double *y) {
+    if (fn < 0 || fn > 3 || n < 0 || (n > 0 && (!x || !y))) return NAQS_ERR_INVALID;
+    for (int64_t i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: y[i] = naqs::log_fast(x[i]); break;
+            case 1: y[i] = naqs::log1m_fast(x[i]); break;
+            case 2: y[i] = naqs::exp_fast(x[i]); break;
+            default: {
+                uint64_t b;
+                __builtin_memcpy(&b, &x[i], sizeof(b));
+                y[i] = naqs::u01((uint32_t)(b >> 32), (uint32_t)b);
+            }
+        }
+    }
+    return NAQS_OK;
+}

@@ -460,7 +460,8 @@ class FusedLogPsi:
     def vmc_run(self, ham, n_steps, adam, n_samples, n_samples_max, n_unq_min, n_unq_max, seed_base, sample_calls, ring=None, ring_off=0):
         """``n_steps`` training steps in ONE library call (``naqs_vmc_run``): the loop of ``PartialSamplingOptimizer.run``
         with get_samples' adaptive sample count in C.  ``ring``: the optimiser's tracking buffer (int64; the keys of step i go to
-        ``ring[off:off + M]``) or None.  -> dict(steps, stop_reason, events [(step, n_unique, overflow, action, n_samples)],
+        ``ring[off:off + M]``) or None.  -> dict(steps, stop_reason, error [the NaqsError of a failed call, for the caller to raise
+        once it has booked the ``steps`` that did finish; None otherwise], events [(step, n_unique, overflow, action, n_samples)],
         n_samples, sample_calls, ring_off, M [steps], ns [steps], t [steps], ev [steps, 2], sums [steps, 4], and the last step's
         table views keys / counts / probs / weights / log_psi / eloc / g)."""
         dev, cap = self.device, int(n_unq_max)
@@ -510,7 +511,14 @@ class FusedLogPsi:
         a.m_log_host, a.ns_log_host, a.t_log_host = m_log, ns_log, t_log
         a.events, a.events_cap = events, ev_cap
         st = self._lib.naqs_vmc_run(self._h, ham._h, n, ctypes.byref(a), _stream_ptr(dev))
-        _lib.check(st, "naqs_vmc_run")
+        # A failure part-way through (a bounded device wait expiring, a HIP error at step k) leaves k finished steps behind:
+        # k Adam updates are applied and the counters in `a` have advanced.  They are copied back below like a good run's, and
+        # the error travels in the result ("error") so that the caller books the finished steps BEFORE it raises.
+        error = None
+        try:
+            _lib.check(st, "naqs_vmc_run")
+        except _lib.NaqsError as exc:
+            error = exc
         done = int(a.steps_done)
         if done:
             if not adam.state:
@@ -520,7 +528,7 @@ class FusedLogPsi:
             self._flat = adam._flat
         m_last = int(m_log[done - 1]) if done else 0
         k0 = int(a.last_keys_off)
-        return dict(steps=done, stop_reason=int(a.stop_reason),
+        return dict(steps=done, stop_reason=int(a.stop_reason), error=error,
                     events=[(int(e.step), int(e.n_unique), bool(e.overflow), int(e.action), int(e.n_samples)) for e in events[:int(a.n_events)]],
                     n_samples=int(a.n_samples), sample_calls=int(a.sample_calls), ring_off=int(a.ring_off),
                     M=[int(x) for x in m_log[:done]], ns=[int(x) for x in ns_log[:done]], t=[float(x) for x in t_log[:done]],

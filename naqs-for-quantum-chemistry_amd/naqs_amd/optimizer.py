@@ -998,8 +998,6 @@ class PartialSamplingOptimizer(OptimizerBase):
         wf._sample_calls = res["sample_calls"]
         if self.track_sampled_idxs:
             self._sampled_ring_off = res["ring_off"]
-        if res["stop_reason"] == 3:
-            raise RuntimeError(f"VMC step abandoned without a reason to re-sample (M={res['events'][-1][1] if res['events'] else '?'})")
         done = res["steps"]
         for i in range(done):
             self.n_steps += 1
@@ -1011,6 +1009,12 @@ class PartialSamplingOptimizer(OptimizerBase):
             self._last_M = res["M"][-1]
             self._sample_keys, self._sample_weights, self._prefused = res["keys"], res["weights"], None
             self._loss_terms, self._last_loss = (res["g"], res["log_psi"]), None
+        # failures are raised only now: the `done` steps that finished are applied updates, and the counters above (Adam's step,
+        # the sampler's call number, the tracking ring, the log) have to describe the parameters as they are
+        if res["error"] is not None:
+            raise res["error"]
+        if res["stop_reason"] == 3:
+            raise RuntimeError(f"VMC step abandoned without a reason to re-sample (M={res['events'][-1][1] if res['events'] else '?'})")
         return res["counts"], res["weights"], done
 
     def _run_epochs(self, n_epochs, save_freq, output_freq, run_time_at_last_log, steps_at_last_log):
@@ -1027,7 +1031,13 @@ class PartialSamplingOptimizer(OptimizerBase):
                 chunk = min(remaining, 1 if self.n_epochs == 0 else output_freq - self.n_epochs % output_freq)
                 if save_freq is not None and save_freq > 0:
                     chunk = min(chunk, save_freq - self.n_epochs % save_freq)
+                if self._dist_mode == "replicated" and self.replica_proof_every > 0:
+                    # several ranks, every one running the identical single-GPU loop: a chunk ends where the ranks owe each
+                    # other the same-table proof (and where a switch to the sharded step may be decided on its agreed count)
+                    chunk = min(chunk, self.replica_proof_every - self.n_steps % self.replica_proof_every)
                 counts, weights, done = self._library_run(chunk)
+                if done and self._dist_mode == "replicated":
+                    self._replica_proof(self._sample_keys)       # (gates on n_steps % replica_proof_every itself)
                 remaining -= done
                 if done == 0:
                     continue                         # (the tracking buffer was full: folded on the way back in)

@@ -257,6 +257,71 @@ def test_ranks_switch_between_replicated_and_sharded_steps_on_an_agreed_count(tm
     assert r0["same"] and r1["same"] and r0["n_steps"] == r1["n_steps"] == 7
 
 
+def _library_loop_worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "naqs-for-quantum-chemistry_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle_backend
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle_backend.install(__import__("naqs_amd.optimizer").optimizer)
+    z, hil, wf, opt = make_opt("LiH", os.path.join(tmp, f"r{rank}"), None, seed=11, n_samples=5000)
+    opt.shard_min_rows, opt.shard_min_table, opt.replica_proof_every = 1, 1, 4
+    # the replicated ranks take the loop-in-the-library path (naqs_vmc_run on the GPU): here a stand-in that runs the same steps
+    # through the per-step calls and books them the way `_library_run` does, so that what is under test is the loop around it
+    chunks, proofs = [], []
+
+    def library_run(n_steps):
+        chunks.append((opt.n_steps, int(n_steps)))
+        for _ in range(int(n_steps)):
+            states, counts, probs = opt.get_samples(lazy=True)
+            ev = opt._SGD_step(states, opt._sample_keys, None, sample_weights=opt._sample_weights, lazy=True)
+            opt.n_steps += 1
+            opt.n_epochs += 1
+            opt._pending_log.append((opt.n_steps, ev, len(opt._sample_weights), opt.run_time))
+        opt._last_M = len(opt._sample_weights)
+        return counts, opt._sample_weights, int(n_steps)
+
+    proof = opt._replica_proof
+
+    def replica_proof(keys):
+        if opt.n_steps % opt.replica_proof_every == 0:
+            proofs.append(opt.n_steps)
+        return proof(keys)
+
+    opt._library_run, opt._replica_proof = library_run, replica_proof
+    opt._can_onecall = lambda: opt._dist_mode != "sharded"
+    opt._can_shard_onecall = lambda: False
+    opt._can_run_in_library = lambda: True
+    opt.run(10, output_freq=10 ** 6)
+    params = torch.cat([p.detach().reshape(-1) for p in wf.model.parameters()])
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    torch.save({"modes": list(opt.dist_mode_log), "chunks": chunks, "proofs": proofs, "n_steps": opt.n_steps,
+                "same": all(torch.equal(g, gathered[0]) for g in gathered)}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_library_loop_of_replicated_ranks_stops_for_the_replica_proof(tmp_path):
+    """Round-5 advice: replicated ranks run their steps through the loop in the library, chunk by chunk; a chunk must end where
+    the ranks owe each other the same-table proof (every `replica_proof_every` steps), the proof must run there, and the
+    switch to the sharded step — only ever taken on a proof's agreed count — must stay reachable."""
+    import torch.multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "lib")
+    mp.spawn(_library_loop_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in range(2))
+    for r in (r0, r1):
+        assert r["chunks"] == [(0, 1), (1, 3)], r            # the first epoch's own line, then up to the proof at step 4
+        assert r["proofs"] == [4] and r["modes"] == [(0, "replicated"), (4, "sharded")], r
+        assert r["same"] and r["n_steps"] == 10
+
+
 def test_step_form_is_decided_again_on_every_run_and_optimizer_reset(tmp_path, monkeypatch):
     """The cached decision (one library call per step or the pieces) must not outlive a run(): use_fused, grad_clip_factor,
     normalize_grads or the optimiser itself may have changed in between (a plain torch optimiser cannot take the one-call

@@ -240,6 +240,22 @@ def test_small_tables_are_replicated_not_sharded(tmp_path):
     assert [m for _, m in gloo2[0]["dist_modes"]] == ["replicated"] and single["dist_modes"] == []
 
 
+def test_replicated_ranks_in_the_library_loop_prove_their_tables_and_reach_the_sharded_step(tmp_path):
+    """Round-5 advice: replicated ranks run `naqs_vmc_run` chunks; a chunk has to end at the replica proof (every 8 steps
+    here), the proof has to run, and the replicated -> sharded switch — only taken on a proof's agreed count — has to stay
+    reachable under the library loop.  gloo world 2 on one GPU, a policy under which H2O's table counts as big enough: the
+    first 8 steps are the single-process trajectory bit for bit, then both ranks shard at step 8 and stay together."""
+    single = _run_workers(tmp_path, "none", 1, 29592)[0]
+    env = {"NAQS_SHARD_MIN_TABLE": "2", "NAQS_REPLICA_PROOF_EVERY": "8"}
+    gloo2 = _run_workers(tmp_path, "gloo", 2, 29593, shard_min_rows=1, tag="_libloop", extra_env=env)
+    for r in gloo2:
+        assert r["dist_modes"] == [(0, "replicated"), (8, "sharded")], r["dist_modes"]
+        assert r["energies"][:8] == single["energies"][:8]
+    assert torch.equal(gloo2[0]["params"], gloo2[1]["params"]), "ranks diverged"
+    d = np.abs(np.array(gloo2[0]["energies"]) - np.array(single["energies"]))
+    assert d[:20].max() < 1e-6 and d.max() < 5e-3, d
+
+
 def test_fused_kernels_follow_parameter_changes(tmp_path):
     """load_state_dict / in-place edits / checkpoint loads must reach the packed weights of the HIP kernels (their
     copy is refreshed from the tensors' version counters), also once the parameters are views of the flat buffer."""

@@ -72,3 +72,27 @@ def test_binomial_edge_cases_and_determinism(lib):
     a, b = _draw(lib, 1000, 0.3, 1000, 5), _draw(lib, 1000, 0.3, 1000, 5)
     assert np.array_equal(a, b) and not np.array_equal(a, _draw(lib, 1000, 0.3, 1000, 6))
     assert lib.naqs_rng_binomial_host(-1, 0.5, 0, 1, np.zeros(1, dtype=np.int64).ctypes.data) == -1     # NAQS_ERR_INVALID
+
+
+def test_generator_log_has_no_zero_argument(lib):
+    """Round-5 advice: `log_fast` has no guard for x <= 0 (it sits on every draw's critical chain).  It needs none: the
+    uniforms are on the OPEN interval — u01(0, 0) = 2^-54, never 0 — so the exact acceptance test's smallest argument
+    v alpha us^2 / (a + b us^2) stays a normal float64; and over the range the generator uses them the three elementary
+    functions are within a few ulp of libm's."""
+    def call(fn, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        _lib.check(lib.naqs_rng_math_host(fn, len(x), x.ctypes.data, y.ctypes.data), "rng_math")
+        return y
+    words = np.array([0, 0xFFFFFFFFFFFFFFFF, 0x00000020_00000000, 0x00000000_00000040], dtype=np.uint64)
+    u = call(3, words.view(np.float64))
+    assert u[0] == 2.0 ** -54 and 0.0 < u.min() and u.max() <= 1.0
+    assert u[2] == (2 ** 26 + 0.5) * 2.0 ** -53 and u[3] == 1.5 * 2.0 ** -53          # hi >> 5 and lo >> 6 land where they should
+    rs = np.random.RandomState(5)
+    x = np.concatenate([np.exp(rs.uniform(-440, 60, 200000)), [2.0 ** -190, 2.0 ** -162, 0.5, 1.0, 2.0 ** 44]])
+    ulp = lambda got, want: np.max(np.abs(got - want) / np.spacing(np.abs(want)))
+    assert ulp(call(0, x), np.log(x)) <= 3
+    p = np.concatenate([rs.uniform(0, 0.5, 100000), np.exp(rs.uniform(-40, np.log(0.5), 100000)), [0.5, 2.0 ** -60]])
+    assert ulp(call(1, p), np.log1p(-p)) <= 4
+    t = -np.concatenate([rs.uniform(0, 40, 100000), np.exp(rs.uniform(-30, np.log(700), 100000))])
+    assert ulp(call(2, t), np.exp(t)) <= 2
