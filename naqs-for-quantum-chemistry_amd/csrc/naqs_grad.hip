@@ -222,6 +222,8 @@ NAQS_API int naqs_net_logamp(naqs_net_t *net, int64_t M, const uint64_t *keys_de
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    st = naqs::net_flush_amp_pack(net, s);                 // (a training step's re-pack still waiting for a launch to host it)
+    if (st != NAQS_OK) return st;
     st = naqs::net_amp_forward(net, M, keys_dev, s);
     if (st != NAQS_OK) return st;
     NAQS_KLAUNCH(logamp_sum_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, net->dims.P, M, net->d_scratch,
@@ -317,6 +319,8 @@ NAQS_API int naqs_net_amp_backward(naqs_net_t *net, int64_t M, const uint64_t *k
     if (!net->have_amp_weights) return NAQS_ERR_INVALID;
     DeviceGuard guard;
     int st = guard.init(net->device);
+    if (st != NAQS_OK) return st;
+    st = naqs::net_flush_amp_pack(net, reinterpret_cast<hipStream_t>(stream));
     if (st != NAQS_OK) return st;
     return naqs::net_blocks_backward(net, net->dims, net->d_w, net->amp_src_off, net->amp_params, M, keys_dev, g_dev, grad_dev, 0,
                                      reinterpret_cast<hipStream_t>(stream));

@@ -1941,121 +1941,36 @@ __device__ __forceinline__ void pack_phase_bf16(const float *__restrict__ src, i
         Wd[e] = h1; Wd[(size_t)total + e] = h2; Wd[2 * (size_t)total + e] = h3;
     }
 }
-// re-pack the flat state_dict-order parameters into the kernels' layout
-// amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]] ->
-// Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
-struct AmpSrcOff { int64_t off[MAXP]; };
-
-// amplitude blocks as MFMA operand fragments of the transposed f16x2 item (naqs_amp_mfma.hpp): per pair W1 planes
-// [2][Ha/16][64][8] (A operand: lane (m, kg) = hidden unit 16 ct + m, inputs 8 kg..8 kg + 7, input 31 = b1), W2 planes
-// [2][Ha/32][64][8] (A operand: lane (m, kg) = output m, slot j = hidden unit 16 (2 kc + (j >> 2)) + 4 kg + (j & 3)), then
-// 16 floats {b2[8], c1, c2}.  Every block of a pair derives the pair's scales itself (<= 1.6 k parameters).
-__device__ __forceinline__ void pack_amp_mfma_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
-                                                   ushort_t *__restrict__ wamp, const int n) {
-    __shared__ float s_red[3][4];
-    const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
-    const int CT = Ha >> 4, KC = Ha >> 5;
-    // (the launch is sized for the biggest job: a surplus workgroup must leave before it derives the pair's scales — with
-    // 256 workgroups per job doing that for nothing this launch took 38 us instead of 10)
-    if ((int)blockIdx.x * 256 >= (CT + KC) * 512) return;
-    const float *src = flat + so.off[n];
-    const float *W1 = src, *b1 = src + Ha * nin, *W2 = src + Ha * nin + Ha;
-    // maxima: |W1|, |b1| (one scale: b1 rides in the W1 fragments), row bound sum_k |W1[j][k]| + |b1[j]| (inputs +-1), |W2|
-    float mw1 = 0.0f, mrow = 0.0f, mw2 = 0.0f;
-    for (int j = threadIdx.x; j < Ha; j += 256) {
-        float sum = fabsf(b1[j]);
-        mw1 = fmaxf(mw1, sum);
-        if (n > 0)
-            for (int k = 0; k < nin; ++k) { const float v = fabsf(W1[j * nin + k]); sum += v; mw1 = fmaxf(mw1, v); }
-        mrow = fmaxf(mrow, sum);
-        for (int c = 0; c < nout; ++c) mw2 = fmaxf(mw2, fabsf(W2[c * Ha + j]));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mw1 = fmaxf(mw1, __shfl_xor(mw1, o, 64)); mrow = fmaxf(mrow, __shfl_xor(mrow, o, 64)); mw2 = fmaxf(mw2, __shfl_xor(mw2, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = mw1; s_red[1][threadIdx.x >> 6] = mrow; s_red[2][threadIdx.x >> 6] = mw2; }
-    __syncthreads();
-    mw1 = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
-    mrow = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
-    mw2 = fmaxf(fmaxf(s_red[2][0], s_red[2][1]), fmaxf(s_red[2][2], s_red[2][3]));
-    const float sw1 = pow2_clamped(13 - exp_of(mw1)), sh = pow2_clamped(14 - exp_of(mrow)), sw2 = pow2_clamped(13 - exp_of(mw2));
-    const size_t pair = amp_mfma_pair_elems(Ha);
-    ushort_t *dst = wamp + (size_t)n * pair;
-    if (blockIdx.x == 0 && threadIdx.x < 16) {
-        float v = 0.0f;
-        if ((int)threadIdx.x < nout) v = src[Ha * nin + Ha + nout * Ha + threadIdx.x];
-        else if (threadIdx.x == 8) v = sh / sw1;
-        else if (threadIdx.x == 9) v = (1.0f / sh) / sw2;
-        reinterpret_cast<float *>(dst + (size_t)2 * 512 * (CT + KC))[threadIdx.x] = v;
-    }
-    const int frag1 = CT * 512, frag2 = KC * 512;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < frag1 + frag2; e += gridDim.x * 256) {
-        float x;
-        size_t o0, plane;
-        if (e < frag1) {            // e = (ct * 64 + l) * 8 + j  <-  W1[16 ct + (l & 15)][8 (l >> 4) + j]
-            const int j = e & 7, l = (e >> 3) & 63, ct = e >> 9;
-            const int h = 16 * ct + (l & 15), k = 8 * (l >> 4) + j;
-            x = ((n > 0 && k < nin) ? W1[h * nin + k] : (k == 31 ? b1[h] : 0.0f)) * sw1;        // input 31 == 1 carries b1
-            o0 = (size_t)e; plane = (size_t)frag1;
-        } else {                    // e' = (kc * 64 + l) * 8 + j  <-  W2[l & 15][16 (2 kc + (j >> 2)) + 4 (l >> 4) + (j & 3)]
-            const int e2 = e - frag1;
-            const int j = e2 & 7, l = (e2 >> 3) & 63, kc = e2 >> 9;
-            const int c = l & 15, k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);
-            x = c < nout ? W2[c * Ha + k] * sw2 : 0.0f;
-            o0 = (size_t)2 * frag1 + e2; plane = (size_t)frag2;
-        }
-        ushort_t h1, h2;
-        split2(x, h1, h2);
-        dst[o0] = h1; dst[o0 + plane] = h2;
-    }
-}
+// (AmpSrcOff, pack_amp_body and pack_amp_mfma_body — the amplitude blocks' re-pack — live in naqs_pack.hpp: the sampler's first
+// launch hosts them too)
+using naqs::AmpSrcOff;
+using naqs::pack_amp_body;
+using naqs::pack_amp_mfma_body;
 
 __global__ __launch_bounds__(256) void pack_amp_mfma_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
                                                             ushort_t *__restrict__ wamp) {
-    pack_amp_mfma_body(flat, d, so, wamp, blockIdx.y);
-}
-
-// every amplitude block in one launch: blockIdx.y = pair n, rows [W1[j][:] | b1[j] | W2[:][j] | pad] + b2
-__device__ __forceinline__ void pack_amp_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
-                                              float *__restrict__ w, const int n) {
-    const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
-    const float *src = flat + so.off[n];
-    float *dst = w + d.amp_off[n];
-    const int S = (nin + 1 + 5 + 3) & ~3, total = Ha * S + 8;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        float v = 0.0f;
-        if (e < Ha * S) {
-            const int j = e / S, c = e - j * S;
-            if (c < nin) v = src[j * nin + c];
-            else if (c == nin) v = src[Ha * nin + j];
-            else if (c - nin - 1 < nout) v = src[Ha * nin + Ha + (c - nin - 1) * Ha + j];
-        } else if (e - Ha * S < nout) {
-            v = src[Ha * nin + Ha + nout * Ha + (e - Ha * S)];
-        }
-        dst[e] = v;
-    }
+    pack_amp_mfma_body(flat, d, so, wamp, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void pack_amp_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
                                                        float *__restrict__ w) {
-    pack_amp_body(flat, d, so, w, blockIdx.y);
+    pack_amp_body(flat, d, so, w, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 // the amplitude blocks alone (naqs_net_set_amp_weights): the VALU rows (blockIdx.z = 0) and the matrix-core fragments (1) in
 // one launch, so that the sampler takes the same form of the block MLPs whichever call packed the weights last
 __global__ __launch_bounds__(256) void pack_amp_both_kernel(const float *__restrict__ flat, const NetDims d, const AmpSrcOff so,
                                                             float *__restrict__ w, ushort_t *__restrict__ wamp) {
-    if (blockIdx.z == 0) pack_amp_body(flat, d, so, w, blockIdx.y);
-    else pack_amp_mfma_body(flat, d, so, wamp, blockIdx.y);
+    if (blockIdx.z == 0) pack_amp_body(flat, d, so, w, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+    else pack_amp_mfma_body(flat, d, so, wamp, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 // aggregate_phase: both sets of per-pair blocks (blockIdx.z = 0, 1) and, when they exist, the amplitude blocks' matrix-core
 // fragments (2) in one launch
 __global__ __launch_bounds__(256) void pack_amp2_kernel(const float *__restrict__ flat, const NetDims d0, const AmpSrcOff so0,
                                                         float *__restrict__ w0, const NetDims d1, const AmpSrcOff so1,
                                                         float *__restrict__ w1, ushort_t *__restrict__ wamp) {
-    if (blockIdx.z == 0) pack_amp_body(flat, d0, so0, w0, blockIdx.y);
-    else if (blockIdx.z == 1) pack_amp_body(flat, d1, so1, w1, blockIdx.y);
-    else pack_amp_mfma_body(flat, d0, so0, wamp, blockIdx.y);
+    if (blockIdx.z == 0) pack_amp_body(flat, d0, so0, w0, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+    else if (blockIdx.z == 1) pack_amp_body(flat, d1, so1, w1, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+    else pack_amp_mfma_body(flat, d0, so0, wamp, blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __device__ __forceinline__ void pack_phase_f32(const float *__restrict__ src, int K, int N, int K_pad, int N_pad,
@@ -2121,10 +2036,10 @@ __global__ __launch_bounds__(256) void pack_net_kernel(const float *__restrict__
                                                        naqs::PhaseScales *__restrict__ scales, const int y_base, const uint32_t tag,
                                                        const naqs::PollCtl *ctl) {
     int y = blockIdx.y + y_base;
-    if (y < d.P) { pack_amp_body(flat, d, so, w, y); return; }
+    if (y < d.P) { pack_amp_body(flat, d, so, w, y, (int)blockIdx.x, (int)gridDim.x); return; }
     y -= d.P;
     if (wamp != nullptr) {
-        if (y < d.P) { pack_amp_mfma_body(flat, d, so, wamp, y); return; }
+        if (y < d.P) { pack_amp_mfma_body(flat, d, so, wamp, y, (int)blockIdx.x, (int)gridDim.x); return; }
         y -= d.P;
     }
     if (y < d.n_lin) { pack_phase_body(flat, d, jobs, w, wh, with_f32, y, fmt, raw, scales, tag, ctl); return; }
@@ -2411,6 +2326,7 @@ NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, in
     if (st != NAQS_OK) return st;
     net->have_weights = net->have_wb = false;   // the packed phase layers no longer belong to these parameters
     net->have_amp_weights = false;
+    net->amp_head_packed = 0;
     // rows AND fragments: the sampler picks the matrix-core form of the block MLPs whenever the fragments are current, and the
     // two forms round differently — the same (parameters, seed) must not draw differently depending on which call packed last
     st = pack_amp_both(net, flat_dev, reinterpret_cast<hipStream_t>(stream));
@@ -2423,8 +2339,13 @@ NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, in
 // (naqs_vmc_step, f16x2 format): the amplitude jobs only — what the next sampler call reads — and the phase share stays
 // PENDING: the sampler's first launch hosts it (PACK_TAKE fills the arguments: naqs_pack.hpp), or whoever reads the phase
 // layers first starts it in order (PACK_PHASE).
-enum PackMode { PACK_ALL = 0, PACK_AMP = 1, PACK_PHASE = 2, PACK_TAKE = 3 };
-static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s, const PackMode mode, naqs::PackPhaseArgs *take) {
+// PACK_DEFER (round 6; naqs_vmc_step with NAQS_PACK_OVERLAP=2, the default): NOTHING is launched — the amplitude share is pending too
+// (net->pack_pending_amp) and the next sampler call's first launch hosts all of it (PACK_TAKE with `head_pairs` > 0: the fragments
+// of pairs 0 .. head_pairs - 1, the ones that launch's own first workgroup reads, were packed by the update's launch —
+// grad_finish_kernel's first workgroups, net->amp_head_packed); any other reader of the amplitude blocks starts the amplitude
+// jobs in order first (net_flush_pack).
+enum PackMode { PACK_ALL = 0, PACK_AMP = 1, PACK_PHASE = 2, PACK_TAKE = 3, PACK_DEFER = 4 };
+static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s, PackMode mode, naqs::PackPhaseArgs *take, const int head_pairs = 0) {
     const NetDims &d = net->dims;
     PhasePackJobs jobs{};
     int biggest = d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8;                 // an amplitude block's packed rows
@@ -2447,14 +2368,15 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
     const int gx = std::min(256, (biggest + 255) / 256);
     const int gy_amp = d.P + (net->d_wamp ? d.P : 0), gy_phase = d.n_lin + wb.n;
     naqs::PhaseRaw *raw = net->d_raw;
-    if (mode == PACK_ALL || mode == PACK_AMP) {
+    if (mode == PACK_DEFER && (fmt != 2 || net->d_wamp == nullptr || net->amp_head_packed <= 0)) mode = PACK_AMP;      // (nothing to host the amplitude share with)
+    if (mode == PACK_ALL || mode == PACK_AMP || mode == PACK_DEFER) {
         net->packed_f32 = with_f32 != 0;
         net->packed_fmt = fmt;
         net->wamp_fresh = false;
     }
     if (mode != PACK_TAKE) net->have_wt = false;          // (a re-pack of any kind: phase_kernel_wt's copy is only refreshed by PACK_ALL, below)
     const bool split = mode != PACK_ALL && fmt == 2;      // (PACK_AMP on another format: everything now, nothing pending)
-    if (fmt == 2 && (!split || mode >= PACK_PHASE)) {
+    if (fmt == 2 && (!split || mode == PACK_PHASE || mode == PACK_TAKE)) {
         if (++net->pack_seq == 0u) {                       // the 32-bit tag is about to repeat: forget every old word
             HIP_TRY(hipMemsetAsync(raw, 0, sizeof(naqs::PhaseRaw), s));
             net->pack_seq = 1u;
@@ -2470,6 +2392,7 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
                            with_f32, fmt, raw, net->d_scales, 0, net->pack_seq, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = nullptr;
+        net->pack_pending_amp = false;
         // the big layer once more in phase_kernel_wt's order (inference on tables of a few thousand rows and up; the training
         // step's re-packs leave it stale and its forward passes never read it)
         if (fmt == 2 && d.n_lin == 3 && jobs.N[0] == 512 && jobs.K[1] == 512 && jobs.N[1] == 512 && naqs::env_int("NAQS_PHASE_WT", 0) != 0) {
@@ -2483,6 +2406,11 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
                            net->d_wh, net->d_wamp, with_f32, fmt, raw, net->d_scales, 0, 0u, net->ctl);
         HIP_TRY(hipGetLastError());
         net->pack_pending = flat_dev;
+        net->pack_pending_amp = false;
+        net->pack_stream = s;
+    } else if (mode == PACK_DEFER) {
+        net->pack_pending = flat_dev;
+        net->pack_pending_amp = true;
         net->pack_stream = s;
     } else if (mode == PACK_PHASE) {
         NAQS_KLAUNCH(net_bounds_kernel, dim3(naqs::BOUNDS_WG, d.n_lin), dim3(256), 0, s, flat_dev, jobs, raw, net->pack_seq, net->ctl);
@@ -2495,9 +2423,17 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
         take->flat = flat_dev; take->jobs = jobs; take->wb = wb; take->w = net->d_w; take->wh = net->d_wh; take->raw = raw;
         take->scales = net->d_scales; take->tag = net->pack_seq; take->gx = gx; take->ctl = net->ctl;
         take->n_wgs = d.n_lin * naqs::BOUNDS_WG + gy_phase * gx;
+        if (net->pack_pending_amp) {                       // the amplitude share rides along, in front (naqs_pack.hpp)
+            take->amp = 1; take->so = so; take->wamp = net->d_wamp; take->head_pairs = std::min(head_pairs, d.P);
+            take->gxa = std::max(1, ((d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) + 255) / 256);
+            take->gxf = std::max(1, ((d.Ha / 16 + d.Ha / 32) * 512 + 255) / 256);
+            take->n_amp_wgs = d.P * take->gxa + (d.P - take->head_pairs) * take->gxf;
+            take->n_wgs += take->n_amp_wgs;
+        }
         net->pack_pending = nullptr;
+        net->pack_pending_amp = false;
     }
-    if (mode == PACK_ALL || mode == PACK_AMP) {
+    if (mode == PACK_ALL || mode == PACK_AMP || mode == PACK_DEFER) {
         net->wamp_fresh = net->d_wamp != nullptr;
         net->have_wb = true;
     }
@@ -2513,12 +2449,26 @@ static int pack_follow_update(naqs_net *net, hipStream_t s) {
     }
     return NAQS_OK;
 }
-int naqs::net_take_pending_pack(naqs_net *net, hipStream_t s, naqs::PackPhaseArgs *out) {
+int naqs::net_take_pending_pack(naqs_net *net, hipStream_t s, naqs::PackPhaseArgs *out, const int head_pairs) {
     *out = naqs::PackPhaseArgs{};
     if (net->pack_pending == nullptr) return NAQS_OK;
+    int st = pack_follow_update(net, s);
+    if (st != NAQS_OK) return st;
+    // the amplitude share rides along only if what the host's own workgroup reads — the fragments of its `head_pairs` leading
+    // pairs — was packed by the update itself; else the amplitude jobs as a launch first
+    if (net->pack_pending_amp && (head_pairs <= 0 || net->amp_head_packed < head_pairs)) {
+        st = pack_single_phase(net, net->pack_pending, s, PACK_AMP, nullptr);
+        if (st != NAQS_OK || net->pack_pending == nullptr) return st;
+    }
+    return pack_single_phase(net, net->pack_pending, s, PACK_TAKE, out, net->amp_head_packed);
+}
+// the amplitude blocks' share alone, if a training step left it pending (every reader of d_w's amplitude rows / d_wamp that is
+// not the hosting sampler launch); the phase share stays pending
+int naqs::net_flush_amp_pack(naqs_net *net, hipStream_t s) {
+    if (net->pack_pending == nullptr || !net->pack_pending_amp) return NAQS_OK;
     const int st = pack_follow_update(net, s);
     if (st != NAQS_OK) return st;
-    return pack_single_phase(net, net->pack_pending, s, PACK_TAKE, out);
+    return pack_single_phase(net, net->pack_pending, s, PACK_AMP, nullptr);
 }
 int naqs::net_flush_pack(naqs_net *net, hipStream_t s) {
     if (net->phase_pending) {                              // naqs_vmc_run's deferred phase chain: `s` goes behind it
@@ -2526,8 +2476,12 @@ int naqs::net_flush_pack(naqs_net *net, hipStream_t s) {
         net->phase_pending = false;
     }
     if (net->pack_pending == nullptr) return NAQS_OK;
-    const int st = pack_follow_update(net, s);
+    int st = pack_follow_update(net, s);
     if (st != NAQS_OK) return st;
+    if (net->pack_pending_amp) {
+        st = pack_single_phase(net, net->pack_pending, s, PACK_AMP, nullptr);
+        if (st != NAQS_OK || net->pack_pending == nullptr) return st;      // (another number format by now: that launch packed everything)
+    }
     return pack_single_phase(net, net->pack_pending, s, PACK_PHASE, nullptr);
 }
 int naqs::net_finish_pending(naqs_net *net, hipStream_t s) { return naqs::net_flush_pack(net, s); }
@@ -2553,6 +2507,8 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
     }
     net->have_weights = net->have_amp_weights = net->have_wb = false;
     net->pack_pending = nullptr;                          // (whatever was pending is superseded by this re-pack)
+    net->pack_pending_amp = false;
+    if (net->overlap_next_pack != 2) net->amp_head_packed = 0;      // (only naqs_vmc_step's update packs leading pairs itself)
     if (net->aggregate) {                                   // the phase blocks in the amplitude rows' layout; nothing else to pack
         if (net->dims.P == net->dph.P && (naqs::env_int("NAQS_AGG_MERGE", 7) & 4)) {
             AmpSrcOff so0, so1;
@@ -2577,7 +2533,7 @@ NAQS_API int naqs_net_set_weights(naqs_net_t *net, const float *flat_dev, int64_
         net->have_weights = net->have_amp_weights = net->have_wb = true;
         return NAQS_OK;
     }
-    st = pack_single_phase(net, flat_dev, s, net->overlap_next_pack ? PACK_AMP : PACK_ALL, nullptr);
+    st = pack_single_phase(net, flat_dev, s, net->overlap_next_pack == 2 ? PACK_DEFER : (net->overlap_next_pack ? PACK_AMP : PACK_ALL), nullptr);
     if (st != NAQS_OK) return st;
     net->have_weights = net->have_amp_weights = true;
     return NAQS_OK;

@@ -272,7 +272,12 @@ struct naqs_net {
     uint32_t sums_seq = 0;
     uint32_t pack_seq = 0;                     // tag of the last re-pack's PhaseRaw words
     const float *pack_pending = nullptr;       // parameters whose phase share of the re-pack has not been started (naqs_vmc_step; naqs_pack.hpp)
-    bool overlap_next_pack = false;            // naqs_vmc_step -> naqs_net_set_weights: amplitude jobs now, phase jobs pending
+    bool pack_pending_amp = false;             // ... and the amplitude blocks' share has not been started either (round 6)
+    int amp_head_packed = 0;                   // leading pairs whose fragments the update's own launch packed from the parameters it had just
+                                               // written (grad_finish_kernel's first workgroups; 0 after any other update / re-pack)
+    int overlap_next_pack = 0;                 // naqs_vmc_step -> naqs_net_set_weights: 1 = amplitude jobs now, phase jobs pending; 2 = everything
+                                               // pending (the next sampler call's first launch hosts the whole re-pack, its first workgroup
+                                               // packing the fragments of its own levels' pairs itself)
     bool have_amp_weights = false;          // amplitude layers packed (naqs_net_set_amp_weights leaves the phase stale)
     float *d_gpart = nullptr;               // per-workgroup partial gradients (naqs_grad.hip)
     void *d_train = nullptr;                // phase activations / deltas / GEMM partials (naqs_phase_grad.hip)
@@ -346,6 +351,9 @@ int net_backward_pack_jobs(naqs_net *net, WbPackJobs *jobs);
 // naqs_logpsi.hip: order `s` behind whatever this handle still has in flight elsewhere (the deferred phase chain of
 // naqs_vmc_run), and start a pending re-pack of the phase layers on it
 int net_finish_pending(naqs_net *net, hipStream_t s);
+// naqs_logpsi.hip: the amplitude blocks' share of a training step's re-pack, if it is still waiting for a launch to host it
+// (naqs_pack.hpp) — for every reader of the amplitude rows / fragments that is not that launch
+int net_flush_amp_pack(naqs_net *net, hipStream_t s);
 // naqs_grad.hip: d/d theta sum_i g_i f(key_i) for one set of per-pair blocks (amplitude blocks, or the phase blocks of an
 // aggregate-phase network with raw = 1); grad_dev receives n_block_params floats in state_dict order
 // With `defer` the fixed-order reduction of the workgroups' partial sums is not launched but described there, for the
@@ -380,7 +388,7 @@ inline AdamArgs adam_args(float *p, float *m, float *v, double lr, double beta1,
     return a;
 }
 #if defined(__HIPCC__)
-__device__ __forceinline__ void adam_update(const AdamArgs &a, const int64_t i, float gi) {
+__device__ __forceinline__ float adam_update(const AdamArgs &a, const int64_t i, float gi) {      // -> the updated parameter
     const float pi = a.p[i];
     if (a.weight_decay != 0.0f) gi = fmaf(a.weight_decay, pi, gi);
     const float mi = a.m[i] + (gi - a.m[i]) * (1.0f - a.beta1);
@@ -388,7 +396,9 @@ __device__ __forceinline__ void adam_update(const AdamArgs &a, const int64_t i, 
     a.m[i] = mi;
     a.v[i] = vi;
     const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    a.p[i] = pi - a.step_size * (mi / denom);
+    const float pn = pi - a.step_size * (mi / denom);
+    a.p[i] = pn;
+    return pn;
 }
 #endif
 // naqs_sample.hip

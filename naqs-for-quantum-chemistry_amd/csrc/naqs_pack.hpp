@@ -1,5 +1,5 @@
-// naqs_pack.hpp — the phase layers' share of the single-phase network's re-pack in the f16x2 format, as device functions two
-// kernels use: pack_net_kernel (naqs_logpsi.hip: naqs_net_set_weights, everything in one launch behind net_bounds_kernel) and
+// naqs_pack.hpp — the single-phase network's re-pack in the f16x2 format (the phase layers' share; since round 6 the amplitude
+// blocks' too), as device functions two kernels use: pack_net_kernel (naqs_logpsi.hip: naqs_net_set_weights, everything in one launch behind net_bounds_kernel) and
 // the sampler's first launch of a training step (naqs_sample.hip: sample_head_kernel<256, 4> is ONE workgroup for ~30 us and
 // reads nothing but the amplitude blocks — the workgroups behind it re-pack the phase layers of the last update meanwhile,
 // instead of 13 us of launches between the update and the sampler).  Inside that launch the weight maxima are the first jobs
@@ -141,6 +141,121 @@ __device__ __forceinline__ void pack_phase_job_f16x2(const float *__restrict__ f
     pack_phase_f16(src, jobs.K[l], jobs.N[l], d.Kh_pad[l], d.N_pad[l], wh + d.wh_off[l], sw, bx, nbx);
 }
 
+// ---- the amplitude blocks' share of a re-pack (moved here from naqs_logpsi.hip in round 6: the sampler's first launch hosts it too) ----
+// flat state_dict-order parameters of an amplitude block: src = [W1 [Ha][nin] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]]
+struct AmpSrcOff { int64_t off[MAXP]; };
+
+// the pair's three f16x2 scales from its weight maxima: |W1| and |b1| (one scale: b1 rides in the W1 fragments), the row bound
+// max_j (|b1[j]| + sum_k |W1[j][k]|) (inputs +-1) and |W2|.  Maxima are exact whatever the order they are taken in, so every
+// way of splitting the rows over threads gives the same scales.
+struct AmpScales { float sw1, sh, sw2; };
+__device__ __forceinline__ void amp_row_maxima(const float *W1, const float *b1, const float *W2,
+                                               const int Ha, const int nin, const int nout, const int n, const int j0, const int dj,
+                                               float &mw1, float &mrow, float &mw2) {
+    for (int j = j0; j < Ha; j += dj) {
+        float sum = fabsf(b1[j]);
+        mw1 = fmaxf(mw1, sum);
+        if (n > 0)
+            for (int k = 0; k < nin; ++k) { const float v = fabsf(W1[j * nin + k]); sum += v; mw1 = fmaxf(mw1, v); }
+        mrow = fmaxf(mrow, sum);
+        for (int c = 0; c < nout; ++c) mw2 = fmaxf(mw2, fabsf(W2[c * Ha + j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mw1 = fmaxf(mw1, __shfl_xor(mw1, o, 64)); mrow = fmaxf(mrow, __shfl_xor(mrow, o, 64)); mw2 = fmaxf(mw2, __shfl_xor(mw2, o, 64));
+    }
+}
+__device__ __forceinline__ AmpScales amp_scales_of(const float mw1, const float mrow, const float mw2) {
+    return AmpScales{pow2_clamped(13 - exp_of(mw1)), pow2_clamped(14 - exp_of(mrow)), pow2_clamped(13 - exp_of(mw2))};
+}
+// elements [e0, e1) step de of a pair's fragments and (first == true) its 16 trailing floats
+__device__ __forceinline__ void amp_fragments_write(const float *src, const int Ha, const int nin, const int nout, const int n,
+                                                    const AmpScales sc, ushort_t *__restrict__ dst, const int e0, const int de, const bool first,
+                                                    const int t16) {
+    const int CT = Ha >> 4, KC = Ha >> 5;
+    const float *W1 = src, *b1 = src + Ha * nin, *W2 = src + Ha * nin + Ha;
+    if (first && t16 < 16) {
+        float v = 0.0f;
+        if (t16 < nout) v = src[Ha * nin + Ha + nout * Ha + t16];
+        else if (t16 == 8) v = sc.sh / sc.sw1;
+        else if (t16 == 9) v = (1.0f / sc.sh) / sc.sw2;
+        reinterpret_cast<float *>(dst + (size_t)2 * 512 * (CT + KC))[t16] = v;
+    }
+    const int frag1 = CT * 512, frag2 = KC * 512;
+    for (int e = e0; e < frag1 + frag2; e += de) {
+        float x;
+        size_t o0, plane;
+        if (e < frag1) {            // e = (ct * 64 + l) * 8 + j  <-  W1[16 ct + (l & 15)][8 (l >> 4) + j]
+            const int j = e & 7, l = (e >> 3) & 63, ct = e >> 9;
+            const int h = 16 * ct + (l & 15), k = 8 * (l >> 4) + j;
+            x = ((n > 0 && k < nin) ? W1[h * nin + k] : (k == 31 ? b1[h] : 0.0f)) * sc.sw1;        // input 31 == 1 carries b1
+            o0 = (size_t)e; plane = (size_t)frag1;
+        } else {                    // e' = (kc * 64 + l) * 8 + j  <-  W2[l & 15][16 (2 kc + (j >> 2)) + 4 (l >> 4) + (j & 3)]
+            const int e2 = e - frag1;
+            const int j = e2 & 7, l = (e2 >> 3) & 63, kc = e2 >> 9;
+            const int c = l & 15, k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+            x = c < nout ? W2[c * Ha + k] * sc.sw2 : 0.0f;
+            o0 = (size_t)2 * frag1 + e2; plane = (size_t)frag2;
+        }
+        ushort_t h1, h2;
+        split2(x, h1, h2);
+        dst[o0] = h1; dst[o0 + plane] = h2;
+    }
+}
+
+// amplitude blocks as MFMA operand fragments of the transposed f16x2 item (naqs_amp_mfma.hpp): per pair W1 planes
+// [2][Ha/16][64][8] (A operand: lane (m, kg) = hidden unit 16 ct + m, inputs 8 kg..8 kg + 7, input 31 = b1), W2 planes
+// [2][Ha/32][64][8] (A operand: lane (m, kg) = output m, slot j = hidden unit 16 (2 kc + (j >> 2)) + 4 kg + (j & 3)), then
+// 16 floats {b2[8], c1, c2}.  Every block of a pair derives the pair's scales itself (<= 1.6 k parameters).
+// (256-thread workgroups; bx of nbx: the workgroup's index within pair n's job)
+// (pack_amp_mfma_src: from the pair's parameter block wherever it is — grad_finish_kernel's first workgroups hand over the LDS
+// copy of what they have just updated)
+__device__ __forceinline__ void pack_amp_mfma_src(const float *src, const int Ha, const int nout, ushort_t *__restrict__ wamp, const int n,
+                                                  const int bx, const int nbx) {
+    __shared__ float s_red[3][4];
+    const int nin = n == 0 ? 1 : 2 * n;
+    const int CT = Ha >> 4, KC = Ha >> 5;
+    // (the launch is sized for the biggest job: a surplus workgroup must leave before it derives the pair's scales — with
+    // 256 workgroups per job doing that for nothing this launch took 38 us instead of 10)
+    if (bx * 256 >= (CT + KC) * 512) return;
+    float mw1 = 0.0f, mrow = 0.0f, mw2 = 0.0f;
+    amp_row_maxima(src, src + Ha * nin, src + Ha * nin + Ha, Ha, nin, nout, n, (int)threadIdx.x, 256, mw1, mrow, mw2);
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = mw1; s_red[1][threadIdx.x >> 6] = mrow; s_red[2][threadIdx.x >> 6] = mw2; }
+    __syncthreads();
+    mw1 = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+    mrow = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    mw2 = fmaxf(fmaxf(s_red[2][0], s_red[2][1]), fmaxf(s_red[2][2], s_red[2][3]));
+    amp_fragments_write(src, Ha, nin, nout, n, amp_scales_of(mw1, mrow, mw2), wamp + (size_t)n * amp_mfma_pair_elems(Ha), bx * 256 + (int)threadIdx.x,
+                        nbx * 256, bx == 0, (int)threadIdx.x);
+}
+__device__ __forceinline__ void pack_amp_mfma_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
+                                                   ushort_t *__restrict__ wamp, const int n, const int bx, const int nbx) {
+    pack_amp_mfma_src(flat + so.off[n], d.Ha, d.n_out_amp, wamp, n, bx, nbx);
+}
+// parameters of pair n's block: W1 [Ha][max(1, 2n)] | b1 [Ha] | W2 [nout][Ha] | b2 [nout]
+__host__ __device__ __forceinline__ int amp_raw_floats(const int Ha, const int nout, const int n) { return Ha * (n == 0 ? 1 : 2 * n) + Ha + nout * Ha + nout; }
+
+// every amplitude block's VALU rows: Ha rows [W1[j][:] | b1[j] | W2[0..5)[j] | 0-pad to a multiple of 4 floats], then b2 padded to 8
+__device__ __forceinline__ void pack_amp_body(const float *__restrict__ flat, const NetDims &d, const AmpSrcOff &so,
+                                              float *__restrict__ w, const int n, const int bx, const int nbx) {
+    const int Ha = d.Ha, nout = d.n_out_amp, nin = n == 0 ? 1 : 2 * n;
+    const float *src = flat + so.off[n];
+    float *dst = w + d.amp_off[n];
+    const int S = (nin + 1 + 5 + 3) & ~3, total = Ha * S + 8;
+    for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+        float v = 0.0f;
+        if (e < Ha * S) {
+            const int j = e / S, c = e - j * S;
+            if (c < nin) v = src[j * nin + c];
+            else if (c == nin) v = src[Ha * nin + j];
+            else if (c - nin - 1 < nout) v = src[Ha * nin + Ha + (c - nin - 1) * Ha + j];
+        } else if (e - Ha * S < nout) {
+            v = src[Ha * nin + Ha + nout * Ha + (e - Ha * S)];
+        }
+        dst[e] = v;
+    }
+}
+
 // row-major zero-padded copy y of the phase weights (what the backward GEMMs read)
 __device__ __forceinline__ void pack_wb_job(const float *__restrict__ flat, const WbPackJobs &wb, const int y, const int bx, const int nbx) {
     const int total = wb.Np[y] * wb.Kp[y];
@@ -163,8 +278,23 @@ struct PackPhaseArgs {
     uint32_t tag = 0;
     int gx = 0, n_wgs = 0;
     const PollCtl *ctl = nullptr;
+    // round 6 — the amplitude blocks' share as well (amp != 0): [rows: P x gxa][fragments of the pairs from head_pairs on:
+    // (P - head_pairs) x gxf] in FRONT of the phase jobs; the fragments of pairs 0 .. head_pairs - 1 — what the hosting launch's
+    // own first workgroup reads — exist already: the update's launch packed them (grad_finish_kernel's first workgroups)
+    int amp = 0, gxa = 0, gxf = 0, n_amp_wgs = 0, head_pairs = 0;
+    AmpSrcOff so;
+    ushort_t *wamp = nullptr;
 };
 __device__ __forceinline__ void pack_phase_dispatch(const NetDims &d, const PackPhaseArgs &a, int bid) {
+    if (a.amp) {
+        if (bid < a.n_amp_wgs) {
+            const int rows = d.P * a.gxa;
+            if (bid < rows) pack_amp_body(a.flat, d, a.so, a.w, bid / a.gxa, bid % a.gxa, a.gxa);
+            else { bid -= rows; pack_amp_mfma_body(a.flat, d, a.so, a.wamp, a.head_pairs + bid / a.gxf, bid % a.gxf, a.gxf); }
+            return;
+        }
+        bid -= a.n_amp_wgs;
+    }
     const int nb = d.n_lin * BOUNDS_WG;
     if (bid < nb) { net_bounds_body(a.flat, a.jobs, a.raw, bid / BOUNDS_WG, a.tag, bid % BOUNDS_WG, a.ctl); return; }
     bid -= nb;
@@ -175,7 +305,10 @@ __device__ __forceinline__ void pack_phase_dispatch(const NetDims &d, const Pack
 
 // naqs_logpsi.hip: the pending phase share of the last re-pack (naqs_vmc_step), for a launch that can host it (`out` filled,
 // nothing pending afterwards) ...
-int net_take_pending_pack(naqs_net *net, hipStream_t s, PackPhaseArgs *out);
+// (host_levels: the leading pairs the host launch's own first workgroup reads — a pending amplitude share can only ride along
+// when the fragments of those pairs were packed by the update itself, net->amp_head_packed; otherwise, or with 0, it is launched
+// in order first)
+int net_take_pending_pack(naqs_net *net, hipStream_t s, PackPhaseArgs *out, int host_levels = 0);
 // ... or as launches of its own, in order on `s` (any other reader of the phase layers)
 int net_flush_pack(naqs_net *net, hipStream_t s);
 

@@ -325,11 +325,68 @@ struct GradFinish {
     int64_t set_out[2] = {0, 0};       // where each set starts in the flat gradient
     int64_t total = 0;                 // sets + MLP elements
 };
+// Round 6 — the launch's first workgroups, ONE per leading amplitude pair (naqs_vmc_step: the pairs the next sampler call's
+// single busy workgroup reads).  Such a workgroup finishes ALL of its pair's gradient elements (up to HEAD_EPT per thread, the
+// loads of all of them in flight together; each element's sum in ordered_sum's order: the same bits), applies Adam's update,
+// keeps the updated parameters in LDS and packs the pair's matrix-core fragments from them (naqs_pack.hpp: the arithmetic of
+// pack_amp_mfma_body on the same values) — so that the amplitude blocks' whole re-pack can wait for the sampler's first launch
+// to host it (PACK_DEFER) instead of being a launch between the update and the sampler.  The pair's scales need every one of
+// its parameters, which is why a pair is one workgroup's; 773 parameters for pair 3 of 64-unit blocks.
+constexpr int HEAD_EPT = 4, HEAD_MAX_PAIRS = 4;
+struct HeadPairs {
+    int pairs = 0;                         // 0: no such workgroups
+    int Ha = 0, nout = 0;
+    int64_t off[HEAD_MAX_PAIRS] = {0, 0, 0, 0};      // pair p's first element within set 0
+    int64_t skip = 0;                      // the elements of set 0 these workgroups cover: [0, skip)
+    unsigned short *wamp = nullptr;
+};
+__device__ __forceinline__ void head_pair_finish(const GradFinish &F, float *__restrict__ grad, const naqs::AdamArgs &A, const HeadPairs &H,
+                                                 const int p) {
+    __shared__ float s_new[HEAD_EPT * 256];
+    const int tid = threadIdx.x;
+    const int nin = p == 0 ? 1 : 2 * p;
+    const int cnt = H.Ha * nin + H.Ha + H.nout * H.Ha + H.nout;            // <= HEAD_EPT * 256 (the host checked)
+    const float *__restrict__ part = F.set[0].partial + H.off[p];
+    const int64_t stride = F.set[0].stride;
+    const int np = F.set[0].n_partials;
+    constexpr int U = 8;                                   // (sixteen: 73 registers, six waves per SIMD for every workgroup of the launch — 12.1 us against 11.0)
+    float s[HEAD_EPT];
+#pragma unroll
+    for (int k = 0; k < HEAD_EPT; ++k) s[k] = 0.0f;
+    for (int b0 = 0; b0 < np; b0 += U) {
+        float v[HEAD_EPT][U];
+#pragma unroll
+        for (int k = 0; k < HEAD_EPT; ++k)
+#pragma unroll
+            for (int j = 0; j < U; ++j) v[k][j] = (tid + 256 * k < cnt && b0 + j < np) ? part[(int64_t)(b0 + j) * stride + tid + 256 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < HEAD_EPT; ++k)
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (b0 + j < np) s[k] += v[k][j];
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_EPT; ++k) {
+        const int e = tid + 256 * k;
+        if (e < cnt) {
+            const int64_t o = F.set_out[0] + H.off[p] + e;
+            grad[o] = s[k];
+            s_new[e] = naqs::adam_update(A, o, s[k]);
+        }
+    }
+    __syncthreads();
+    naqs::pack_amp_mfma_src(s_new, H.Ha, H.nout, H.wamp, p, 0, 1);
+}
+
 // (e0, e1: the elements this launch covers — all of them, or the block sets' and the MLP's as two launches on two streams)
 __global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, const GradWJobs J, const float *__restrict__ cpart_base,
                                                           const float *__restrict__ bpart_base, float *__restrict__ grad,
-                                                          const naqs::AdamArgs A, const int64_t e0, const int64_t e1) {
-    int64_t e = e0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                          const naqs::AdamArgs A, const int64_t e0, const int64_t e1, const HeadPairs H) {
+    if ((int)blockIdx.x < H.pairs) {                       // (workgroup-uniform)
+        head_pair_finish(F, grad, A, H, (int)blockIdx.x);
+        return;
+    }
+    int64_t e = e0 + H.skip + (int64_t)((int)blockIdx.x - H.pairs) * 256 + threadIdx.x;
     if (e >= e1) return;
     const int64_t sets_total = F.n_sets > 0 ? F.set_end[F.n_sets - 1] : 0;
     float s = 0.0f;
@@ -807,11 +864,13 @@ NAQS_API int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int6
 // (E_loc, w, sums) together with its amplitude column and the output delta (naqs_net_train_backward_vmc, single-phase only)
 struct VmcSeeds { const double *eloc, *w, *sums; float *g_out; double *ev; bool form_sums = false; };   // form_sums: `sums` is an OUTPUT of the seed kernel
 static int launch_grad_finish(const GradFinish &F, const GradWJobs &J, const float *cpart, const float *bpart, float *grad_dev,
-                              const naqs::AdamArgs *adam, hipStream_t s, int64_t e0 = 0, int64_t e1 = -1) {
+                              const naqs::AdamArgs *adam, hipStream_t s, int64_t e0 = 0, int64_t e1 = -1, const HeadPairs *hp = nullptr) {
     if (e1 < 0) e1 = F.total;
     if (e1 <= e0) return NAQS_OK;
-    NAQS_KLAUNCH(grad_finish_kernel, dim3((unsigned)((e1 - e0 + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
-                       adam ? *adam : naqs::AdamArgs{}, e0, e1);
+    const HeadPairs H = hp ? *hp : HeadPairs{};
+    if (H.pairs > 0 && (e0 != 0 || adam == nullptr || H.skip > e1)) return NAQS_ERR_INVALID;
+    NAQS_KLAUNCH(grad_finish_kernel, dim3((unsigned)(H.pairs + (e1 - e0 - H.skip + 255) / 256)), dim3(256), 0, s, F, J, cpart, bpart, grad_dev,
+                       adam ? *adam : naqs::AdamArgs{}, e0, e1, H);
     HIP_TRY(hipGetLastError());
     return NAQS_OK;
 }
@@ -1053,7 +1112,26 @@ static int train_backward_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_
         net->phase_pending = true;                           // (the re-pack and ev_phase_done follow: naqs_vmc_step)
         return NAQS_OK;
     }
-    return launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, s);
+    // naqs_vmc_step (NAQS_PACK_OVERLAP=2, the default): the launch's first workgroups each finish, update and PACK one of the
+    // pairs the next sampler call's own first workgroup reads, so that the rest of the amplitude re-pack can ride in that call's
+    // first launch (naqs_pack.hpp).  Conditions: what that launch needs to be the four-level head with the block MLPs on the matrix
+    // cores (more than four pairs, fragments allocated, f16x2 format) and a pair's parameters within a workgroup's reach.
+    HeadPairs hp;
+    net->amp_head_packed = 0;
+    if (adam != nullptr && naqs::env_int("NAQS_PACK_OVERLAP", 2) >= 2 && net->d_wamp != nullptr && net->packed_fmt == 2 && d.P > HEAD_MAX_PAIRS &&
+        naqs::amp_raw_floats(d.Ha, d.n_out_amp, HEAD_MAX_PAIRS - 1) <= HEAD_EPT * 256 && F.set_out[0] == 0) {
+        hp.pairs = HEAD_MAX_PAIRS; hp.Ha = d.Ha; hp.nout = d.n_out_amp; hp.wamp = net->d_wamp;
+        bool contiguous = net->amp_src_off[0] == 0;
+        for (int p = 0; p < HEAD_MAX_PAIRS; ++p) {
+            hp.off[p] = net->amp_src_off[p] - net->amp_src_off[0];
+            contiguous = contiguous && net->amp_src_off[p + 1] - net->amp_src_off[p] == naqs::amp_raw_floats(d.Ha, d.n_out_amp, p);
+        }
+        hp.skip = net->amp_src_off[HEAD_MAX_PAIRS] - net->amp_src_off[0];
+        if (!contiguous) hp = HeadPairs{};
+    }
+    st = launch_grad_finish(F, J, cpart, bpart, grad_dev, adam, s, 0, -1, hp.pairs > 0 ? &hp : nullptr);
+    if (st == NAQS_OK) net->amp_head_packed = hp.pairs;
+    return st;
 }
 
 static int train_backward_vmc_impl(naqs_net_t *net, int64_t M, const uint64_t *keys_dev, const double *eloc_dev,
@@ -1144,13 +1222,17 @@ NAQS_API int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, 
                                  adam_step >= 1 ? &adam : nullptr, form_sums);
     if (st != NAQS_OK) return st;
     if (adam_step >= 1) {
-        // the next sampling call reads the amplitude blocks; the phase layers' share of the re-pack rides in that call's
-        // first launch (naqs_pack.hpp; NAQS_PACK_OVERLAP=0: everything here, in order)
+        // the whole re-pack rides in the next sampling call's first launch, in the workgroups behind its one busy workgroup — the
+        // fragments of the four pairs THAT workgroup reads were packed by the update's own launch, from the values it had just
+        // written (grad_finish_kernel's first workgroups); naqs_pack.hpp.  NAQS_PACK_OVERLAP=1: round 4's form — the amplitude
+        // jobs as a launch here, the phase layers' share hosted; 0: everything here, in order
         const bool deferred = net->phase_pending;            // (train_backward_impl put the phase MLP's half on the side stream)
         net->phase_pending = false;                          // (naqs_net_set_weights must not wait for what it is part of)
-        net->overlap_next_pack = deferred || naqs::env_int("NAQS_PACK_OVERLAP", 1) != 0;
+        const int overlap = naqs::env_int("NAQS_PACK_OVERLAP", 2);
+        // (2 needs the update to have packed the leading pairs' fragments: train_backward_impl, net->amp_head_packed)
+        net->overlap_next_pack = deferred ? 1 : std::min(net->amp_head_packed > 0 ? 2 : 1, std::max(0, overlap));
         st = naqs_net_set_weights(net, param_dev, net->n_params, stream);
-        net->overlap_next_pack = false;
+        net->overlap_next_pack = 0;
         if (st != NAQS_OK) return st;
         if (deferred) {
             // the phase layers' re-pack behind their update, on the side stream; whoever reads them, the gradient or the

@@ -737,6 +737,9 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
     __shared__ uint32_t s_entry[1];
     const bool ahead = AHEAD_OK && wamp != nullptr;
     const int tid = threadIdx.x, u = tid >> 2, q = tid & 3, lane = tid & 63, wave = tid >> 6;
+#if defined(NAQS_HEAD_CLOCKS)
+    const long long head_t0 = clock64();
+#endif
     if (tid == 0) {
         for (int i = 0; i < MAXP + 2; ++i) b.U[i] = 0;
         b.U[0] = 1;
@@ -746,7 +749,6 @@ __global__ __launch_bounds__(HT) void sample_head_kernel(const NetDims d, const 
     }
     int U = 1;
 #if defined(NAQS_HEAD_CLOCKS)
-    const long long head_t0 = clock64();
     if (threadIdx.x == 0) g_head_clk[7][0] += 1;
 #endif
 #pragma unroll 1
@@ -976,7 +978,14 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     // 0: per-level launches only, 1 (default): 4 levels / 256 threads, 2: 5 levels / 1024 threads — measured slower
     // (94 us against 38 + 18 for the fifth level on its own: sixteen latency-bound waves on one CU)
     const int head = naqs::env_int("NAQS_SAMPLE_HEAD", 1);
-    if (head >= 1 && ((head >= 2 && d.P > 5 && cap >= 1024) || (d.P > 4 && cap >= 256))) {
+    const bool use_head = head >= 1 && ((head >= 2 && d.P > 5 && cap >= 1024) || (d.P > 4 && cap >= 256));
+    if (!(use_head && !(head >= 2 && d.P > 5 && cap >= 1024))) {
+        // no launch of this call can host a pending amplitude re-pack (naqs_vmc_step leaves it to the four-level head launch
+        // below): the amplitude jobs in order first — every level reads them
+        st = naqs::net_flush_amp_pack(net, s);
+        if (st != NAQS_OK) return st;
+    }
+    if (use_head) {
         const bool big = head >= 2 && d.P > 5 && cap >= 1024;
         const int hl = big ? 5 : 4;
         const int nin = 2 * (hl - 1);
@@ -986,9 +995,11 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sample_head_kernel<1024, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             NAQS_KLAUNCH((sample_head_kernel<1024, 5>), dim3(1), dim3(1024), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, naqs::PackPhaseArgs{});
         } else {
-            // the phase share of the last update's re-pack, if a training step left it pending, rides in this launch
+            // the last update's re-pack, if a training step left it pending, rides in this launch: the phase layers' share and
+            // (matrix-core form of the block MLPs, and the fragments of the hl pairs workgroup 0 reads packed by the update's own
+            // launch) the amplitude blocks'
             naqs::PackPhaseArgs pk;
-            st = naqs::net_take_pending_pack(net, s, &pk);
+            st = naqs::net_take_pending_pack(net, s, &pk, wamp != nullptr ? hl : 0);
             if (st != NAQS_OK) return st;
             NAQS_KLAUNCH((sample_head_kernel<256, 4>), dim3(1 + (unsigned)pk.n_wgs), dim3(256), lds, s, d, net->d_w, b, n_samples, k0, k1, wamp, pk);
         }

@@ -439,15 +439,19 @@ def test_training_run_is_reproducible_at_large_tables(tmp_path, monkeypatch):
 
 
 def test_pending_phase_repack_is_finished_by_whoever_comes_next(tmp_path, monkeypatch):
-    """naqs_vmc_step re-packs the amplitude blocks at once and leaves the phase layers' share of the re-pack pending: the next
-    sampler call's first launch hosts it (workgroups beside the one that samples), any other reader of the phase layers starts
-    it first, a new re-pack supersedes it.  Each exit against NAQS_PACK_OVERLAP=0 (everything in order), bit for bit: log psi
-    right after training steps (reader first), after a sampler call (hosted), and after loading other parameters (superseded);
-    and the training trajectory itself."""
+    """naqs_vmc_step leaves the re-pack of the updated parameters pending: the next sampler call's first launch hosts it
+    (workgroups beside the one that samples; round 6, NAQS_PACK_OVERLAP=2: the amplitude blocks' share too, that launch's first
+    workgroup packing the fragments of its own four pairs itself — round 4, =1: the phase layers' share only, the amplitude jobs
+    as a launch at the end of the step), any other reader starts what it reads first, a new re-pack supersedes it.  Each exit
+    against NAQS_PACK_OVERLAP=0 (everything in order), bit for bit: log psi right after training steps (reader first), the
+    amplitude blocks alone through the autograd pair naqs_net_logamp / naqs_net_amp_backward (reader of the amplitude share
+    only), after a sampler call (hosted), a sampler call in the VALU form of the block MLPs (which cannot host the amplitude
+    share), and after loading other parameters (superseded); and the training trajectory itself."""
+    from naqs_amd.fused import _LogAmp
     from naqs_amd.hamiltonian import keys_to_device
     from naqs_amd.optimizer import LogKey
     res = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         monkeypatch.setenv("NAQS_PACK_OVERLAP", mode)
         z, hil, wf, opt = make_opt_gpu("N2", tmp_path / mode)
         assert opt._can_onecall()
@@ -456,9 +460,21 @@ def test_pending_phase_repack_is_finished_by_whoever_comes_next(tmp_path, monkey
         opt.run(n_epochs=3, save_freq=None, save_final=False, output_freq=10 ** 9)
         a = fused.log_psi(keys).clone()                                  # reader first: the pending jobs run in order on its stream
         opt.run(n_epochs=2, save_freq=None, save_final=False, output_freq=10 ** 9)
+        amp_params = [q.detach().clone().requires_grad_(True) for q in fused._amp_params]
+        la = _LogAmp.apply(fused, keys, *amp_params)                     # reader of the amplitude blocks alone (forward) ...
+        opt.run(n_epochs=1, save_freq=None, save_final=False, output_freq=10 ** 9)
+        la2 = _LogAmp.apply(fused, keys, *amp_params)
+        opt.run(n_epochs=1, save_freq=None, save_final=False, output_freq=10 ** 9)   # (pending again when the backward comes)
+        la2.sum().backward()                                             # ... and backward (gradient at the parameters of NOW)
+        ga = torch.cat([q.grad.reshape(-1) for q in amp_params]).clone()
         g = torch.Generator(device="cuda").manual_seed(5)
         states, counts, probs, lp = wf.sample(100000, generator=g)       # a sampler call outside the step hosts them
         b = fused.log_psi(keys).clone()
+        opt.run(n_epochs=2, save_freq=None, save_final=False, output_freq=10 ** 9)
+        monkeypatch.setenv("NAQS_SAMPLE_MFMA", "0")                      # VALU form: reads the rows, cannot pack its own fragments
+        g = torch.Generator(device="cuda").manual_seed(6)
+        states_v, counts_v, probs_v, lp_v = wf.sample(100000, generator=g)
+        monkeypatch.delenv("NAQS_SAMPLE_MFMA")
         opt.run(n_epochs=2, save_freq=None, save_final=False, output_freq=10 ** 9)
         p_now = wf.flatten_parameters().clone()
         with torch.no_grad():
@@ -466,9 +482,11 @@ def test_pending_phase_repack_is_finished_by_whoever_comes_next(tmp_path, monkey
                 p.mul_(0.5)
         fused.refresh()                                                  # a new re-pack supersedes the pending one
         c = fused.log_psi(keys).clone()
-        res[mode] = dict(a=a, b=b, c=c, e=np.array(opt.log[LogKey.E_LOC]), p=p_now, counts=counts.clone(), lp=lp.detach().clone())
-    x, y = res["1"], res["0"]
-    assert np.array_equal(x["e"], y["e"]) and torch.equal(x["p"], y["p"])
-    assert torch.equal(x["a"], y["a"]) and torch.equal(x["b"], y["b"]) and torch.equal(x["c"], y["c"])
-    assert torch.equal(x["counts"], y["counts"]) and torch.equal(x["lp"], y["lp"])
-    assert not torch.equal(x["a"], x["b"])                               # (the parameters did move between the read-outs)
+        res[mode] = dict(a=a, b=b, c=c, e=np.array(opt.log[LogKey.E_LOC]), p=p_now, counts=counts.clone(), lp=lp.detach().clone(),
+                         la=la.detach().clone(), la2=la2.detach().clone(), ga=ga, counts_v=counts_v.clone(), lp_v=lp_v.detach().clone())
+    for m in ("2", "1"):
+        x, y = res[m], res["0"]
+        assert np.array_equal(x["e"], y["e"]) and torch.equal(x["p"], y["p"]), m
+        for k in ("a", "b", "c", "counts", "lp", "la", "la2", "ga", "counts_v", "lp_v"):
+            assert torch.equal(x[k], y[k]), (m, k)
+        assert not torch.equal(x["a"], x["b"]) and not torch.equal(x["la"], x["la2"])     # (the parameters did move between the read-outs)
