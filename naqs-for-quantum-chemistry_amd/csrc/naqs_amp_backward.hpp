@@ -123,7 +123,7 @@ __device__ __forceinline__ void amp_backward_pair(const NetDims &d, const float 
         } else {
             float la[4];
             bool ok[4];
-            naqs::amp_conditional(d, NB, o, abits, bbits, la, ok);
+            naqs::amp_conditional<true>(d, NB, o, abits, bbits, la, ok);
             // d la[occ] / d a4[c] = [c == occ] - softmax(2 a4)[c] on the allowed outcomes
             const bool live = valid && (occ == 0 ? ok[0] : (occ == 1 ? ok[1] : (occ == 2 ? ok[2] : ok[3])));
 #pragma unroll

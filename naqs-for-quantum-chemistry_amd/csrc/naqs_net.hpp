@@ -135,12 +135,24 @@ __device__ __forceinline__ void amp_budget_mask(const NetDims &d, int NB, uint32
 }
 
 // symmetrise the 5 raw outputs to the 4 outcome logits (nade.py:585-586): (o[0,1,1,2] + o[idx2sort[x_order]]) / 2
+// (BITSEL: the two selects as bit masks on the values.  The compiler may turn `cond ? o[3] : o[4]` on an array it keeps in memory
+// into ONE load from a selected address — in amp_backward_pair that made `o` a scratch array, five stores and two dependent loads
+// of private memory per tile and a kernel that needs scratch set up at dispatch; round 6.  Same values bit for bit.)
+template <bool BITSEL = false>
 __device__ __forceinline__ void amp_symmetrise(const NetDims &d, const float (&o)[5], uint32_t abits, uint32_t bbits,
                                                float (&a4)[4]) {
     if (d.sym) {
         const int x_order = abits > bbits ? 0 : (abits == bbits ? 1 : 2);
-        const float s1 = x_order == 0 ? o[3] : (x_order == 1 ? o[1] : o[4]);
-        const float s2 = x_order == 0 ? o[4] : (x_order == 1 ? o[1] : o[3]);
+        float s1, s2;
+        if (BITSEL) {
+            const uint32_t u1 = __float_as_uint(o[1]), u3 = __float_as_uint(o[3]), u4 = __float_as_uint(o[4]);
+            const uint32_t m0 = x_order == 0 ? 0xFFFFFFFFu : 0u, m1 = x_order == 1 ? 0xFFFFFFFFu : 0u, m2 = x_order == 2 ? 0xFFFFFFFFu : 0u;
+            s1 = __uint_as_float((m0 & u3) | (m1 & u1) | (m2 & u4));
+            s2 = __uint_as_float((m0 & u4) | (m1 & u1) | (m2 & u3));
+        } else {
+            s1 = x_order == 0 ? o[3] : (x_order == 1 ? o[1] : o[4]);
+            s2 = x_order == 0 ? o[4] : (x_order == 1 ? o[1] : o[3]);
+        }
         a4[0] = (o[0] + o[0]) * 0.5f;
         a4[1] = (o[1] + s1) * 0.5f;
         a4[2] = (o[1] + s2) * 0.5f;
@@ -152,10 +164,11 @@ __device__ __forceinline__ void amp_symmetrise(const NetDims &d, const float (&o
 
 // the conditional of pair NB: la[c] = 0.5 * log_softmax(2 a)[c] over the allowed outcomes (activations.py:40-46),
 // -inf where masked; the mask is skipped on the last pair under PARTIAL masking (nade.py:615-617)
+template <bool BITSEL = false>
 __device__ __forceinline__ void amp_conditional(const NetDims &d, int NB, const float (&o)[5], uint32_t abits,
                                                 uint32_t bbits, float (&la)[4], bool (&ok)[4]) {
     float a4[4];
-    amp_symmetrise(d, o, abits, bbits, a4);
+    amp_symmetrise<BITSEL>(d, o, abits, bbits, a4);
     const bool mask_active = !(d.masking == 0 || (d.masking == 1 && NB == d.P - 1));
     if (mask_active) amp_budget_mask(d, NB, abits, bbits, ok);
     else ok[0] = ok[1] = ok[2] = ok[3] = true;
@@ -388,17 +401,20 @@ inline AdamArgs adam_args(float *p, float *m, float *v, double lr, double beta1,
     return a;
 }
 #if defined(__HIPCC__)
-__device__ __forceinline__ float adam_update(const AdamArgs &a, const int64_t i, float gi) {      // -> the updated parameter
-    const float pi = a.p[i];
+// (pi, m0, v0: the element's parameter and moments as loaded by the caller — so that it can have them in flight under other loads)
+__device__ __forceinline__ float adam_update_loaded(const AdamArgs &a, const int64_t i, float gi, const float pi, const float m0, const float v0) {
     if (a.weight_decay != 0.0f) gi = fmaf(a.weight_decay, pi, gi);
-    const float mi = a.m[i] + (gi - a.m[i]) * (1.0f - a.beta1);
-    const float vi = a.beta2 * a.v[i] + (1.0f - a.beta2) * gi * gi;
+    const float mi = m0 + (gi - m0) * (1.0f - a.beta1);
+    const float vi = a.beta2 * v0 + (1.0f - a.beta2) * gi * gi;
     a.m[i] = mi;
     a.v[i] = vi;
     const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
     const float pn = pi - a.step_size * (mi / denom);
     a.p[i] = pn;
     return pn;
+}
+__device__ __forceinline__ float adam_update(const AdamArgs &a, const int64_t i, float gi) {      // -> the updated parameter
+    return adam_update_loaded(a, i, gi, a.p[i], a.m[i], a.v[i]);
 }
 #endif
 // naqs_sample.hip

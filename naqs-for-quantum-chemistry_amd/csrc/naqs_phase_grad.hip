@@ -350,9 +350,13 @@ __device__ __forceinline__ void head_pair_finish(const GradFinish &F, float *__r
     const int64_t stride = F.set[0].stride;
     const int np = F.set[0].n_partials;
     constexpr int U = 8;                                   // (sixteen: 73 registers, six waves per SIMD for every workgroup of the launch — 12.1 us against 11.0)
-    float s[HEAD_EPT];
+    float s[HEAD_EPT], p0[HEAD_EPT], m0[HEAD_EPT], v0[HEAD_EPT];
 #pragma unroll
-    for (int k = 0; k < HEAD_EPT; ++k) s[k] = 0.0f;
+    for (int k = 0; k < HEAD_EPT; ++k) {                   // (the update's own operands: requested first, used last)
+        s[k] = 0.0f;
+        const int64_t o = F.set_out[0] + H.off[p] + min(tid + 256 * k, cnt - 1);
+        p0[k] = A.p[o]; m0[k] = A.m[o]; v0[k] = A.v[o];
+    }
     for (int b0 = 0; b0 < np; b0 += U) {
         float v[HEAD_EPT][U];
 #pragma unroll
@@ -371,7 +375,7 @@ __device__ __forceinline__ void head_pair_finish(const GradFinish &F, float *__r
         if (e < cnt) {
             const int64_t o = F.set_out[0] + H.off[p] + e;
             grad[o] = s[k];
-            s_new[e] = naqs::adam_update(A, o, s[k]);
+            s_new[e] = naqs::adam_update_loaded(A, o, s[k], p0[k], m0[k], v0[k]);
         }
     }
     __syncthreads();
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish F, co
         o = J.out_off[job] + e;          // db_l follows dW_l in the flat gradient: element N K + n
     }
     grad[o] = s;
+    // (the update's operands requested ahead of the partial sums, as the launch's first workgroups do: measured neutral here)
     if (A.p != nullptr) naqs::adam_update(A, o, s);
 }
 
