@@ -131,6 +131,19 @@ __global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, co
     __shared__ double s_sums[4];
     __shared__ uint32_t s_half[8];
     const double *sums = sums_in;
+    // this thread's element (sample i, column quad q): everything it reads that does not depend on the sums is requested BEFORE
+    // the wait for them (round 6: the loads used to start when the sums arrived — one more round trip on the step's chain)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k4 = Kp >> 2;
+    const bool mine = e < M * k4;
+    const int64_t i = mine ? e / k4 : 0;
+    const int q = (int)(e - i * k4), k = mine ? q << 2 : 0;
+    const double2 el = eloc[i];
+    const double wi = w[i];
+    const uint64_t key = keys[i];
+    const int occ = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
+    const f32x4 wt = *reinterpret_cast<const f32x4 *>(Wtop + (int64_t)occ * Kp + k);
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(act + i * Kp + k);
     if (SUMS) {
         if (blockIdx.x == 0) {
             naqs::weighted_sums_block<256>(M, w, eloc, s_red, s_sums);
@@ -155,24 +168,15 @@ __global__ __launch_bounds__(256) void vmc_seed_delta_kernel(const NetDims d, co
         }
         sums = s_sums;
     }
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e == 0) {
         const double e_mean = sums[0] / sums[3];
         ev[0] = e_mean;
         ev[1] = sums[2] / sums[3] - e_mean * e_mean;
     }
-    const int k4 = Kp >> 2;
-    if (e >= M * k4) return;
-    const int64_t i = e / k4;
-    const int q = (int)(e - i * k4), k = q << 2;
+    if (!mine) return;
     const float m_re = (float)sums[0], m_im = (float)sums[1];
-    const double2 el = eloc[i];
-    const float two_w = 2.0f * (float)w[i];
+    const float two_w = 2.0f * (float)wi;
     const float gx = ((float)el.x - m_re) * two_w, gy = -(((float)el.y - m_im) * two_w);
-    const uint64_t key = keys[i];
-    const int occ = naqs::phase_out_row(d, (int)((key >> d.qa[d.P - 1]) & 1ull) + 2 * (int)((key >> d.qb[d.P - 1]) & 1ull));
-    const f32x4 wt = *reinterpret_cast<const f32x4 *>(Wtop + (int64_t)occ * Kp + k);
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(act + i * Kp + k);
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = a[c] > 0.0f ? gy * wt[c] : 0.0f;
