@@ -50,8 +50,8 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md: "
 MFMA_F32_PEAK_TF = 157.3   # f32-in/f32-acc MFMA dense peak (MI355X_MICROARCH.md: = the f32 vector rate)
 N_CU, SIMD_PER_CU, VALU_CYCLES_PER_WAVE_INST, MAX_CLOCK_HZ = 256, 4, 2, 2.4e9   # MI355X_MICROARCH.md (SIMD-32: 2 cycles)
 N_KEY_SETS = 4
-PMC_TRAFFIC = "profiles/r05_pmc_traffic.json"
-PMC_ISSUE = "profiles/r05_pmc_issue.json"
+PMC_TRAFFIC = "profiles/r06_pmc_traffic.json"
+PMC_ISSUE = "profiles/r06_pmc_issue.json"
 
 
 def phase_format(kernel_name=None):

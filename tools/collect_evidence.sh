@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy what tools/gpu_evidence_pass.sh left under gpurun_out/$SRC into profiles/ as round $ROUND (run in the repo root):
-#   SRC=r05 ROUND=r05 bash tools/collect_evidence.sh
-ROUND=${ROUND:-r05}; G=gpurun_out/${SRC:-$ROUND}; P=profiles
+#   SRC=r06 ROUND=r06 bash tools/collect_evidence.sh
+ROUND=${ROUND:-r06}; G=gpurun_out/${SRC:-$ROUND}; P=profiles
 for c in fetch write issue_n2 issue_li2o wait_n2 mfma_n2; do cp $G/pmc_$c/bench_counter_collection.csv $P/${ROUND}_pmc_${c}_counter_collection.csv; done
 cp $G/prof_pipeline2/bench_kernel_stats.csv $P/${ROUND}_bench_n2_10k_kernel_stats_pipeline2.csv
 cp $G/prof_serial/bench_kernel_stats.csv $P/${ROUND}_bench_n2_10k_kernel_stats_serial.csv
@@ -13,7 +13,7 @@ cp $G/step_timeline_train_h2o.txt $P/${ROUND}_train_step_h2o_timeline.txt
 cp $G/train_onecall_ab.txt $P/${ROUND}_train_step_onecall_ab.txt
 cp $G/train_scaling_n2.json $P/${ROUND}_train_step_scaling_model_n2.json
 cp $G/train_scaling_li2o_pub.json $P/${ROUND}_train_step_scaling_model_li2o_published.json
-grep -v "^\[" $G/pmc_phase_mem.txt > $P/${ROUND}_pmc_phase_mem.txt
+[ -f $G/pmc_phase_mem.txt ] && grep -v "^\[" $G/pmc_phase_mem.txt > $P/${ROUND}_pmc_phase_mem.txt
 cp $G/source_hash.txt $P/${ROUND}_library_source_hash.txt
 tail -4 $G/pytest.log > $P/${ROUND}_gpu_test_suite.txt; tail -2 $G/smoke.log >> $P/${ROUND}_gpu_test_suite.txt
 cp $G/n2_sweep.txt $P/${ROUND}_n2_sweep.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # final bench lines of the round, AFTER tools/collect_evidence.sh has put the counter files of this library build under
-# profiles/ (bench.py replays them when the source hash matches): ROUND=r04 bash tools/gpu_final.sh -> gpurun_out/$ROUND_final/
-ROUND=${ROUND:-r04}; G=gpurun_out/${ROUND}_final; mkdir -p $G
+# profiles/ (bench.py replays them when the source hash matches): ROUND=r06 bash tools/gpu_final.sh -> gpurun_out/$ROUND_final/
+ROUND=${ROUND:-r06}; G=gpurun_out/${ROUND}_final; mkdir -p $G
 timeout 600 python bench.py > $G/bench.log 2>/dev/null
 timeout 600 python bench.py --steps 20 --warmup 5 > $G/bench_driver_like.log 2>/dev/null
 timeout 600 python bench.py --shard rows --molecule Li2O --samples 50000 --steps 100 --warmup 10 > $G/bench_li2o.log 2>/dev/null

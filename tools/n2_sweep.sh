@@ -2,9 +2,9 @@
 # BASELINE config 5: the N2 bond-dissociation sweep with the reference's batch_train_full_mask.sh flags on ONE GPU, seeds
 # 111 / 222 / 333 (the reference runs five per geometry and reports the best) — through the farm: one process, the 33 runs
 # in-process, two at a time (profiles/r04_replicas_per_gpu.txt).
-# usage (GPU box): bash tools/n2_sweep.sh  ->  gpurun_out/${ROUND:-r05}/n2_sweep.txt
-R=$PWD; mkdir -p $R/gpurun_out/${ROUND:-r05}
-OUT=$R/gpurun_out/${ROUND:-r05}/n2_sweep.txt
+# usage (GPU box): bash tools/n2_sweep.sh  ->  gpurun_out/${ROUND:-r06}/n2_sweep.txt
+R=$PWD; mkdir -p $R/gpurun_out/${ROUND:-r06}
+OUT=$R/gpurun_out/${ROUND:-r06}/n2_sweep.txt
 GEOMS="0.75 0.9 1.05 1.2 1.35 1.5 1.65 1.8 1.95 2.1 2.25"
 MOLS=$(for r in $GEOMS; do printf "%s," "$R/tests/golden/ham_N2_$r.npz"; done); MOLS=${MOLS%,}
 rm -rf /tmp/sweep
