@@ -351,12 +351,13 @@ int naqs_vmc_sample_forward_eloc(naqs_net_t *net, naqs_ham_t *ham, int64_t n_sam
  * The one host/device rendezvous, M, is read from mapped host memory that the sampler writes as soon as the last level's size
  * is known (polled; NAQS_SPIN_WAIT=0: wait for the stream instead).  With adam_step >= 1 the reductions of the backward pass
  * apply Adam's update in the same launch (torch.optim.Adam's rule, as naqs_adam_step).
- * Re-pack: on return the amplitude blocks are re-packed (the next sampler call reads nothing else); the phase layers' share
- * (weight maxima, f16x2 planes, the backward's row-major copies) reads param_dev LATER, in stream order — inside the next
- * sampler call's first launch, or at the start of whichever call of this handle needs the phase layers first; a
- * naqs_net_set_weights supersedes it.  param_dev must therefore stay allocated, and unchanged unless naqs_net_set_weights
- * follows, until one of those calls has been made (it is the optimiser's own parameter vector in every caller here;
- * NAQS_PACK_OVERLAP=0: the whole re-pack before the call returns, as in ABI 5). */
+ * Re-pack: the kernels' packed copies of the updated parameters are made LATER, in stream order, from param_dev — inside the
+ * next sampler call's first launch (whose own busy workgroup reads the four leading pairs' fragments: those are packed by the
+ * update's launch itself), or at the start of whichever call of this handle first reads the amplitude blocks / the phase
+ * layers (it starts the share it reads); a naqs_net_set_weights supersedes it.  param_dev must therefore stay allocated, and
+ * unchanged unless naqs_net_set_weights follows, until one of those calls has been made (it is the optimiser's own parameter
+ * vector in every caller here).  NAQS_PACK_OVERLAP=1: the amplitude blocks' share before the call returns, only the phase
+ * layers' pending (ABI 6/7); 0: the whole re-pack before the call returns, as in ABI 5.  Same numbers in every form. */
 int naqs_vmc_step(naqs_net_t *net, naqs_ham_t *ham, int64_t n_samples, uint64_t seed, int64_t max_unique, int64_t m_lo,
                   int64_t m_hi, uint64_t *keys_dev, int64_t *counts_dev, float *probs_dev, double *weights_dev,
                   float *logpsi_dev, double *eloc_dev, double *sums_dev, float *g_dev, double *ev_dev, float *grad_dev,

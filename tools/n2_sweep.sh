@@ -12,6 +12,7 @@ cd naqs-for-quantum-chemistry_amd
 t0=$(date +%s%N)
 timeout 900 python -u -m experiments.run --farm --per-gpu ${PER_GPU:-2} --gpus 1 --seeds 111,222,333 -m $MOLS -o /tmp/sweep -single_phase -n1 -n_layer 1 -n_hid 64 -n_layer_phase 2 -n_hid_phase 512 -full_mask_psi -n_train 10000 -output_freq 5000 -save_freq -1 > /tmp/sweep.log 2>&1
 t1=$(date +%s%N)
+cp /tmp/sweep.log $R/gpurun_out/${ROUND:-r06}/n2_sweep_farm.log          # (a run that fails leaves its traceback here and no summary below)
 echo "r(A) seed time(s) final_E(Ha) FCI(Ha) error(mHa)" > $OUT
 for r in $GEOMS; do
   for s in 111 222 333; do
@@ -24,4 +25,5 @@ for r in $GEOMS; do
   done
 done
 echo "33 runs of 10 000 steps in $(( (t1 - t0) / 1000000 )) ms of wall time (one process, --per-gpu ${PER_GPU:-2}; training time per run is measured while two share the GPU)" >> $OUT
+grep -c "Traceback" $R/gpurun_out/${ROUND:-r06}/n2_sweep_farm.log | sed 's/^/tracebacks in the farm log: /' >> $OUT
 cat $OUT
