@@ -2327,6 +2327,8 @@ NAQS_API int naqs_net_set_amp_weights(naqs_net_t *net, const float *flat_dev, in
     net->have_weights = net->have_wb = false;   // the packed phase layers no longer belong to these parameters
     net->have_amp_weights = false;
     net->amp_head_packed = 0;
+    net->pack_pending_amp = false;              // (a training step's pending amplitude share is superseded by this re-pack; a hosted
+                                                //  copy of it would write the blocks from the OTHER parameter vector over these)
     // rows AND fragments: the sampler picks the matrix-core form of the block MLPs whenever the fragments are current, and the
     // two forms round differently — the same (parameters, seed) must not draw differently depending on which call packed last
     st = pack_amp_both(net, flat_dev, reinterpret_cast<hipStream_t>(stream));
