@@ -61,8 +61,10 @@ int naqs_last_hip_error(void);
 const char *naqs_last_hip_error_string(void);
 /* Kernels of this library that wait for a word another workgroup publishes (sampler look-back, column-split log-psi
  * tiles, fused sums, re-pack scale chain) give up after NAQS_POLL_BUDGET_MS (default 2000) instead of hanging: the wave
- * records the site in a per-device error word and leaves without writing results.  Every entry point looks at that word
- * when it is called; this call looks at it on demand (e.g. after a stream synchronisation): NAQS_OK, or NAQS_ERR_HIP with
+ * records the site in the error word of the network handle that launched the kernel (ABI 8; one word per device before: two
+ * runs sharing a GPU could take each other's failures) and leaves without writing results.  Every entry point of a handle
+ * looks at the handle's word when it is called; this call looks at the words of ALL live handles of the device on demand
+ * (e.g. after a stream synchronisation) and reports the first it finds: NAQS_OK, or NAQS_ERR_HIP with
  * naqs_last_hip_error_string() describing the wait.  The reference has no counterpart (its only failure path in the loop is
  * MaxBatchSizeExceededError, src/naqs/network/nade.py:39-40, 710-712 -> src/optimizer/energy.py:939-946); a hang has to
  * become an error somewhere. */

@@ -2076,7 +2076,8 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     naqs_net *net = new (std::nothrow) naqs_net();
     if (!net) return NAQS_ERR_NOMEM;
     net->device = device;
-    net->ctl = naqs::poll_ctl(device);
+    (void)naqs::poll_handle_create(device, &net->poll);
+    net->ctl = net->poll.dev;
     net->cfg = *cfg;
     NetDims &d = net->dims;
     d.P = P;
@@ -2255,6 +2256,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_scales) (void)hipFree(net->d_scales);
     if (net->d_ws_xchg) (void)hipFree(net->d_ws_xchg);
     if (net->d_sum_words) (void)hipFree(net->d_sum_words);
+    naqs::poll_handle_destroy(&net->poll);
     delete net;
     return NAQS_OK;
 }
@@ -2671,7 +2673,7 @@ int naqs::net_logpsi_impl(naqs_net *net, int64_t M, const uint64_t *keys_dev, fl
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
-    st = naqs::poll_check(net->device);                    // an earlier launch's device-side wait that gave up (naqs_poll.hpp)
+    st = naqs::poll_check(net->poll);                      // an earlier launch's device-side wait that gave up (naqs_poll.hpp)
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

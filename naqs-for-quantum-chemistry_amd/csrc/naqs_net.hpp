@@ -306,7 +306,8 @@ struct naqs_net {
     int64_t *d_info_alias = nullptr;        // their device address
     int64_t *d_info2 = nullptr;             // device words for the sampler's plain (M, overflow) output of those calls
     int64_t info_seq = 0;                   // sampling calls that published there
-    const naqs::PollCtl *ctl = nullptr;     // the device's bounded-wait control block (naqs_poll.hpp); every kernel that polls gets it
+    naqs::PollHandle poll;                  // this handle's bounded-wait control block and error word (naqs_poll.hpp) ...
+    const naqs::PollCtl *ctl = nullptr;     // ... = poll.dev: every kernel that polls gets it
     hipStream_t side_stream = nullptr;      // NAQS_TRAIN_SIDE_STREAM=1: the amplitude blocks' backward beside the phase MLP's; naqs_vmc_run: the
                                             // phase MLP's share of a step's backward pass, update and re-pack, beside the NEXT step's sampler
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -839,7 +839,7 @@ static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     } else {
         HIP_TRY(hipStreamSynchronize(s));
     }
-    { const int pc = naqs::poll_check(net->device); if (pc != NAQS_OK) return pc; }      // a look-back wait that gave up (naqs_poll.hpp)
+    { const int pc = naqs::poll_check(net->poll); if (pc != NAQS_OK) return pc; }      // a look-back wait that gave up (naqs_poll.hpp)
     if (h[2] != seq) return NAQS_ERR_HIP;                   // the stream drained and nothing was published
     out[0] = h[0];
     out[1] = h[1];

@@ -7,7 +7,7 @@
 //
 // Every wait is BOUNDED: if the tag has not appeared after `budget` ticks of the 100 MHz constant clock (default 2 s: four
 // orders of magnitude above any kernel of the library), the waiting lane records (site, workgroup, waited-for index) in the
-// device's error word — mapped host memory, first failure wins — and returns `false`; the caller then leaves WITHOUT
+// handle's error word — mapped host memory, first failure wins — and returns `false`; the caller then leaves WITHOUT
 // writing results.  The host sees the word at its next look (every API entry, and wherever it already polls the sampler's
 // published words) and returns NAQS_ERR_HIP with `naqs_last_hip_error_string()` naming the site.  The reference's only
 // failure path in this loop is the sampler's MaxBatchSizeExceededError (src/naqs/network/nade.py:39-40, 710-712 ->
@@ -30,7 +30,7 @@ enum PollSite : uint32_t {
     POLL_N_SITES
 };
 
-// per device, in device memory (read on the slow path only); `err` points into mapped host memory
+// per handle, in device memory (read on the slow path only); `err` points into mapped host memory
 struct PollCtl {
     unsigned long long budget;      // ticks of wall_clock64() (100 MHz)
     uint32_t drop_site;             // debugging (NAQS_DEBUG_DROP_STORE=<site>): the producers of this site skip one store
@@ -72,8 +72,19 @@ __device__ __forceinline__ bool poll_tagged(const unsigned long long *src, const
 }
 #endif
 
-// host side (naqs_hip.hip): the device's control block (created on first use) and the check of its error word
-PollCtl *poll_ctl(int device);                 // device pointer, or nullptr when it could not be created (waits stay bounded by the default)
-int poll_check(int device);                    // NAQS_OK, or NAQS_ERR_HIP after recording what the word said (and clearing it)
+// host side (naqs_hip.hip).  Round 6: a control block and an error word PER HANDLE that launches waiting kernels (every network
+// handle), not per device — two runs share a GPU in the farm (experiments.run --per-gpu 2), and with one word per device the
+// run whose kernel gave up could find its error taken by its neighbour's next call: the neighbour failed for nothing and the
+// victim went on with results that were never written.  A handle looks at ITS word; naqs_device_check(device) looks at all
+// of the device's.
+struct PollHandle {
+    PollCtl *dev = nullptr;                    // device copy of the control block, or nullptr (waits stay bounded by the default, unreported)
+    unsigned long long *err_host = nullptr;    // mapped host word
+    int device = -1;
+};
+int poll_handle_create(int device, PollHandle *out);     // NAQS_OK even when nothing could be allocated (dev == nullptr then)
+void poll_handle_destroy(PollHandle *h);
+int poll_check(const PollHandle &h);           // NAQS_OK, or NAQS_ERR_HIP after recording what the word said (and clearing it)
+int poll_check_device(int device);             // the same over every live handle of the device
 
 }  // namespace naqs

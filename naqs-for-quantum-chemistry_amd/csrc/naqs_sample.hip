@@ -916,7 +916,7 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     DeviceGuard guard;
     int st = guard.init(net->device);
     if (st != NAQS_OK) return st;
-    st = naqs::poll_check(net->device);            // an earlier launch's device-side wait that gave up (naqs_poll.hpp)
+    st = naqs::poll_check(net->poll);              // an earlier launch's device-side wait that gave up (naqs_poll.hpp)
     if (st != NAQS_OK) return st;
     const NetDims &d = net->dims;
     const int64_t cap = max_unique;

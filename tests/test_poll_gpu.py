@@ -112,3 +112,30 @@ def test_repack_scale_chain_wait_is_bounded():
             fused.log_psi(keys)                                   # the next entry sees the error word
         expect_timeout(call, "re-pack")
     """, site=5)
+
+
+def test_a_wait_that_gives_up_fails_its_own_handle_not_its_neighbour():
+    """Round 6: the error word is per network handle.  Two handles share the device (the farm's two runs per GPU): the first one's
+    column-split kernel gives up (its producer's store is dropped) — the SECOND handle's next calls neither see an error nor lose
+    a digit, and the first handle's next call reports its own failure (with one word per device the neighbour's call took the
+    error, failed for nothing, and the victim went on with results that had never been written)."""
+    _run("""
+        fused_a = FusedLogPsi(wf)                                  # created with NAQS_DEBUG_DROP_STORE=1: its producers skip a store
+        del os.environ["NAQS_DEBUG_DROP_STORE"]
+        hil_b, wf_b = make_wf("N2", z, device="cuda")
+        fused_b = FusedLogPsi(wf_b)                                # ... this one's do not
+        keys = hamiltonian.keys_to_device(z["eval_keys"][:640], wf.device)
+        want = fused_b.log_psi(keys).clone()
+        torch.cuda.synchronize()
+        out = torch.full((640, 2), 7.0, dtype=torch.float32, device=wf.device)
+        fused_a.log_psi(keys, out=out)                             # gives up after the budget, writes nothing for tile 0
+        torch.cuda.synchronize()
+        assert bool((out[:16] == 7.0).all())
+        for _ in range(3):                                         # the neighbour: no error, same numbers
+            got = fused_b.log_psi(keys)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+        def call():
+            fused_a.log_psi(keys, out=out)                         # the victim: told at its next entry
+        expect_timeout(call, "column-split")
+    """, site=1)
