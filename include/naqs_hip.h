@@ -69,6 +69,8 @@ const char *naqs_last_hip_error_string(void);
  * MaxBatchSizeExceededError, src/naqs/network/nade.py:39-40, 710-712 -> src/optimizer/energy.py:939-946); a hang has to
  * become an error somewhere. */
 int naqs_device_check(int device);
+/* The same for ONE network handle: its own word only (what a caller sharing the device with other runs asks; ABI 8). */
+int naqs_net_check(naqs_net_t *net);
 
 /* Number of HIP devices visible to the library (0 when there is none); never fails. */
 int naqs_device_count(void);

@@ -2490,6 +2490,11 @@ int naqs::net_flush_pack(naqs_net *net, hipStream_t s) {
 }
 int naqs::net_finish_pending(naqs_net *net, hipStream_t s) { return naqs::net_flush_pack(net, s); }
 
+NAQS_API int naqs_net_check(naqs_net_t *net) {
+    if (!net) return NAQS_ERR_INVALID;
+    return naqs::poll_check(net->poll);
+}
+
 NAQS_API int naqs_net_finish_pending(naqs_net_t *net, void *stream) {
     if (!net) return NAQS_ERR_INVALID;
     DeviceGuard guard;

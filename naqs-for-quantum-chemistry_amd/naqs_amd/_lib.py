@@ -24,6 +24,7 @@ SIGNATURES = {
     "naqs_last_hip_error_string": (ctypes.c_char_p, []),
     "naqs_device_count": (ctypes.c_int, []),
     "naqs_device_check": (ctypes.c_int, [ctypes.c_int]),
+    "naqs_net_check": (ctypes.c_int, [c_vp]),
     "naqs_terms_group": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "naqs_ham_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_vp, c_vp, c_vp,
                                        ctypes.c_int, ctypes.POINTER(c_vp)]),

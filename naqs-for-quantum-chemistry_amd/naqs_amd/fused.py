@@ -358,7 +358,7 @@ class FusedLogPsi:
         m, overflow = info.tolist()
         if overflow:
             # (a look-back wait that ran out also ends the call through the overflow flag: that is an error, not a big tree)
-            _lib.check(self._lib.naqs_device_check(self.device.index or 0), "naqs_net_sample")
+            _lib.check(self._lib.naqs_net_check(self._h), "naqs_net_sample")
             raise MaxBatchSizeExceededError
         out = (keys[:m], counts[:m], probs[:m]) + ((weights[:m],) if with_weights else ())
         if 4 * m < cap and cap > (1 << 16):
