@@ -69,8 +69,6 @@ const char *naqs_last_hip_error_string(void);
  * MaxBatchSizeExceededError, src/naqs/network/nade.py:39-40, 710-712 -> src/optimizer/energy.py:939-946); a hang has to
  * become an error somewhere. */
 int naqs_device_check(int device);
-/* The same for ONE network handle: its own word only (what a caller sharing the device with other runs asks; ABI 8). */
-int naqs_net_check(naqs_net_t *net);
 
 /* Number of HIP devices visible to the library (0 when there is none); never fails. */
 int naqs_device_count(void);
@@ -426,6 +424,9 @@ typedef struct naqs_vmc_run_args {
  * the next forward pass waits for it, and so does this call before it returns: the caller never sees a half-updated
  * parameter vector.  Same kernels on the same operands either way. */
 int naqs_vmc_run(naqs_net_t *net, naqs_ham_t *ham, int64_t n_steps, naqs_vmc_run_args_t *args, void *stream);
+/* naqs_device_check for ONE network handle: its own wait-failure word only (what a caller that shares the device with other
+ * runs asks; ABI 8). */
+int naqs_net_check(naqs_net_t *net);
 /* Order `stream` behind whatever work of this handle is still in flight on its own streams (the deferred phase chain of a
  * naqs_vmc_run that ended early with an error; a re-pack of the phase layers that no launch has hosted yet is started on
  * `stream`).  Every entry point that reads the phase layers does this itself; callers that read the flat parameter or
