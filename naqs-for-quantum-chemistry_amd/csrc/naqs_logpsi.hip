@@ -2426,7 +2426,8 @@ static int pack_single_phase(naqs_net *net, const float *flat_dev, hipStream_t s
     } else {                                               // PACK_TAKE: the caller's launch hosts the jobs
         take->flat = flat_dev; take->jobs = jobs; take->wb = wb; take->w = net->d_w; take->wh = net->d_wh; take->raw = raw;
         take->scales = net->d_scales; take->tag = net->pack_seq; take->gx = gx; take->ctl = net->ctl;
-        take->n_wgs = d.n_lin * naqs::BOUNDS_WG + gy_phase * gx;
+        take->gxl = std::max(1, std::min(gx, naqs::HOSTED_WAITING_WGS / std::max(1, d.n_lin)));      // (naqs_pack.hpp: HOSTED_WAITING_WGS)
+        take->n_wgs = d.n_lin * naqs::BOUNDS_WG + wb.n * gx + d.n_lin * take->gxl;
         if (net->pack_pending_amp) {                       // the amplitude share rides along, in front (naqs_pack.hpp)
             take->amp = 1; take->so = so; take->wamp = net->d_wamp; take->head_pairs = std::min(head_pairs, d.P);
             take->gxa = std::max(1, ((d.Ha * ((2 * (d.P - 1) + 1 + 5 + 3) & ~3) + 8) + 255) / 256);

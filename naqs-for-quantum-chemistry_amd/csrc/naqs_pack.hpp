@@ -266,7 +266,19 @@ __device__ __forceinline__ void pack_wb_job(const float *__restrict__ flat, cons
     }
 }
 
-// the phase share of a re-pack as a flat range of n_wgs workgroups: [maxima: n_lin x BOUNDS_WG][layers: n_lin x gx][copies: wb.n x gx]
+// the phase share of a re-pack as a flat range of n_wgs workgroups: [maxima: n_lin x BOUNDS_WG][copies: wb.n x gx][layers: n_lin x gxl]
+//
+// HOSTED_WAITING_WGS (round 6).  The layer jobs WAIT (for the maxima's words) while they hold a workgroup slot, and the hosting
+// kernel — sample_head_kernel, ~300 registers per lane — has ONE slot per CU, 32 per XCD.  A launch's workgroups are dealt to the
+// eight XCDs and dispatched in index order per XCD only; with two launches in flight (the farm's two runs per GPU) and
+// 3 x 256 layer workgroups each, an XCD could fill with one launch's waiting workgroups while that launch's maxima jobs sat
+// queued on another XCD that the OTHER launch's waiting workgroups had filled — a circular wait that only the 2 s budget of
+// naqs_poll.hpp ends, with an error for both runs.  So a hosted launch gets at most HOSTED_WAITING_WGS waiting workgroups:
+// 2 launches x 120 / 8 XCDs = 30 < 32 slots, i.e. some slot of every XCD is always held by (or free for) a workgroup that waits
+// for nobody, and every maxima job runs.  (The column-split log-psi kernel is inside the same bound by its own condition,
+// 2 x tiles <= CUs: its consumers are at most 16 per XCD and launch.  The sampler's look-back launches are NOT bounded this way
+// beyond ~500 workgroups per launch; two of THOSE in flight at Li2O sizes are the remaining exposure of --per-gpu 2.)
+constexpr int HOSTED_WAITING_WGS = 120;
 struct PackPhaseArgs {
     const float *flat = nullptr;       // nullptr: nothing to do
     PhasePackJobs jobs;
@@ -276,7 +288,7 @@ struct PackPhaseArgs {
     PhaseRaw *raw = nullptr;
     PhaseScales *scales = nullptr;
     uint32_t tag = 0;
-    int gx = 0, n_wgs = 0;
+    int gx = 0, gxl = 0, n_wgs = 0;    // workgroups per copy job / per layer job (the waiting kind: few)
     const PollCtl *ctl = nullptr;
     // round 6 — the amplitude blocks' share as well (amp != 0): [rows: P x gxa][fragments of the pairs from head_pairs on:
     // (P - head_pairs) x gxf] in FRONT of the phase jobs; the fragments of pairs 0 .. head_pairs - 1 — what the hosting launch's
@@ -295,12 +307,16 @@ __device__ __forceinline__ void pack_phase_dispatch(const NetDims &d, const Pack
         }
         bid -= a.n_amp_wgs;
     }
+    // [maxima][row-major copies: wait for nobody][layers: WAIT for the maxima] — and few of the last kind (gxl per layer), see
+    // HOSTED_WAITING_WGS
     const int nb = d.n_lin * BOUNDS_WG;
     if (bid < nb) { net_bounds_body(a.flat, a.jobs, a.raw, bid / BOUNDS_WG, a.tag, bid % BOUNDS_WG, a.ctl); return; }
     bid -= nb;
-    const int y = bid / a.gx, x = bid - y * a.gx;
-    if (y < d.n_lin) pack_phase_job_f16x2(a.flat, d, a.jobs, a.w, a.wh, y, a.raw, a.scales, a.tag, x, a.gx, a.ctl);
-    else if (y - d.n_lin < a.wb.n) pack_wb_job(a.flat, a.wb, y - d.n_lin, x, a.gx);
+    const int n_copy = a.wb.n * a.gx;
+    if (bid < n_copy) { pack_wb_job(a.flat, a.wb, bid / a.gx, bid % a.gx, a.gx); return; }
+    bid -= n_copy;
+    const int y = bid / a.gxl, x = bid - y * a.gxl;
+    if (y < d.n_lin) pack_phase_job_f16x2(a.flat, d, a.jobs, a.w, a.wh, y, a.raw, a.scales, a.tag, x, a.gxl, a.ctl);
 }
 
 // naqs_logpsi.hip: the pending phase share of the last re-pack (naqs_vmc_step), for a launch that can host it (`out` filled,
