@@ -276,8 +276,11 @@ __device__ __forceinline__ void pack_wb_job(const float *__restrict__ flat, cons
 // naqs_poll.hpp ends, with an error for both runs.  So a hosted launch gets at most HOSTED_WAITING_WGS waiting workgroups:
 // 2 launches x 120 / 8 XCDs = 30 < 32 slots, i.e. some slot of every XCD is always held by (or free for) a workgroup that waits
 // for nobody, and every maxima job runs.  (The column-split log-psi kernel is inside the same bound by its own condition,
-// 2 x tiles <= CUs: its consumers are at most 16 per XCD and launch.  The sampler's look-back launches are NOT bounded this way
-// beyond ~500 workgroups per launch; two of THOSE in flight at Li2O sizes are the remaining exposure of --per-gpu 2.)
+// 2 x tiles <= CUs: its consumers are at most 16 per XCD and launch.  The sampler's look-back launches are NOT: they, too, have
+// one slot per CU, every one of their workgroups waits for all before it, and an N2 launch has ~29 of them per XCD — two in
+// flight can in principle take a whole XCD each before the other's first workgroup there.  That needs the two launches to
+// overtake each other XCD by XCD within microseconds; it is what is left of the exposure of --per-gpu 2, and why the farm
+// starts a run again when a wait of it gave up: experiments/_base.py)
 constexpr int HOSTED_WAITING_WGS = 120;
 struct PackPhaseArgs {
     const float *flat = nullptr;       // nullptr: nothing to do

@@ -367,8 +367,7 @@ def _farm_threads(args, job_ids):
     jobs = farm_jobs(args.molecule, args.seeds, args.seed)
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
 
-    def one(j):
-        mol, seed = jobs[j]
+    def attempt(mol, seed):
         if dev is None:
             return _run_job(args, mol, seed)
         torch.cuda.set_device(dev)                             # (the current device is per thread)
@@ -376,6 +375,22 @@ def _farm_threads(args, job_ids):
             res = _run_job(args, mol, seed)
             torch.cuda.current_stream().synchronize()
             return res
+
+    def one(j):
+        # A run is seeded start to finish, so one that fails because a device-side wait ran out of its budget (NAQS_ERR_HIP,
+        # "... wait timed out ...": csrc/naqs_poll.hpp) is simply started again — same numbers.  With two runs per GPU their
+        # launches' waiting workgroups can, rarely, hold each other's slots until both budgets expire; anything
+        # else, and a third failure, is raised.
+        from naqs_amd._lib import NaqsError
+        mol, seed = jobs[j]
+        for tries_left in (2, 1, 0):
+            try:
+                return attempt(mol, seed)
+            except NaqsError as exc:
+                if tries_left == 0 or "wait timed out" not in str(exc):
+                    raise
+                print(f"farm: job {j} ({mol}, seed {seed}) lost a launch to a device-side wait that gave up ({exc}); "
+                      f"the run is seeded — starting it again", flush=True)
 
     import sys
     old = sys.getswitchinterval()

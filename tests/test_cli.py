@@ -156,3 +156,37 @@ def test_cli_runs_the_live_options_no_published_script_uses(extra, suffix, tmp_p
         assert "Using combined amplitude and phase blocks" in text and "--> use for phase = True" not in text or True
     if extra[0] == "-weight_by_psi":
         assert "Samples will be weighted by their frequency." in text
+
+
+def test_farm_restarts_a_run_that_lost_a_launch_to_an_expired_wait(monkeypatch, capsys):
+    """Two runs share a GPU in the farm; their launches' waiting workgroups can, rarely, hold each other's slots until the
+    bounded waits give up and both runs fail with NAQS_ERR_HIP.  A run is seeded start to finish, so the farm
+    starts such a run again (twice at most); any other failure is raised at once."""
+    import argparse
+    from experiments import _base
+    from naqs_amd._lib import NaqsError
+    calls = []
+
+    def fake_run_job(args, mol, seed):
+        calls.append((mol, seed))
+        n = sum(1 for c in calls if c == (mol, seed))
+        if mol == "flaky" and n <= 2:
+            raise NaqsError("naqs_vmc_run failed: HIP runtime error: device-side wait timed out on device 0: sampler ... (-2)")
+        if mol == "hopeless":
+            raise NaqsError("naqs_vmc_run failed: HIP runtime error: device-side wait timed out on device 0: sampler ... (-2)")
+        if mol == "broken":
+            raise NaqsError("naqs_eloc failed: invalid argument (-1)")
+        return [f"{mol}:{seed}"]
+
+    monkeypatch.setattr(_base, "_run_job", fake_run_job)
+    monkeypatch.setattr(_base.torch.cuda, "is_available", lambda: False)
+    ns = argparse.Namespace(molecule="ok,flaky", seeds="1,2", seed=1, number=1, per_gpu=2)
+    assert _base._farm_threads(ns, [0, 1, 2, 3]) == ["ok:1", "ok:2", "flaky:1", "flaky:2"]
+    assert calls.count(("flaky", 1)) == 3 and calls.count(("ok", 1)) == 1
+    assert capsys.readouterr().out.count("starting it again") == 4
+    for mol, n_calls in (("hopeless", 3), ("broken", 1)):
+        calls.clear()
+        ns = argparse.Namespace(molecule=mol, seeds=None, seed=7, number=1, per_gpu=1)
+        with pytest.raises(NaqsError):
+            _base._farm_threads(ns, [0])
+        assert len(calls) == n_calls
