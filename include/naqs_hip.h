@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAQS_ABI_VERSION 8
+#define NAQS_ABI_VERSION 9
 
 typedef struct naqs_ham naqs_ham_t;
 
@@ -262,6 +262,17 @@ int64_t naqs_launch_count(void);
  * same kernel on the same rows either way.  counts[0] = forwards launched ahead, counts[1] = of those, the ones that stood.
  * NAQS_SPEC_FORWARD=0: never ahead.  No counterpart in the reference (its loop is synchronous: energy.py:975-998). */
 int naqs_net_spec_counts(const naqs_net_t *net, int64_t counts[2]);
+/* Two (or more) handles driven from different threads / streams of ONE GPU — the farm's `experiments.run --farm --per-gpu 2`, no
+ * counterpart in the reference, whose runs are one process each (experiments/bash/naqs/batch_train.sh:11-15).  on = 1: this
+ * handle's sampler calls take turns with those of the device's other sharing handles: the sampler's look-back workgroups wait
+ * for every workgroup before them, which is only certain to end while one such launch is in flight.  The turn
+ * is held on the host (a spin lock per device, no event between the streams): naqs_vmc_step / naqs_vmc_run / 
+ * naqs_vmc_sample_forward_eloc keep it from the sampler's first launch until they have read the draw's size, which they wait for
+ * anyway; naqs_net_sample / naqs_net_sample_weighted wait for `stream` to drain before they return (in this mode only).
+ * on = 0: off; on = -1: leave as is.  Default: the value of NAQS_SHARED_GPU (0) when the handle was created.
+ * turns (may be NULL) <- sampler calls of this handle so far that had to wait for another handle's turn to end.
+ * The samples do not depend on the switch. */
+int naqs_net_share_device(naqs_net_t *net, int on, int64_t *turns);
 /* Name of the log-psi kernel the most recent naqs_net_logpsi / naqs_logpsi_eloc / training forward launched. */
 int naqs_net_last_kernel(const naqs_net_t *net, char *buf, int buf_len);
 

@@ -2078,6 +2078,7 @@ NAQS_API int naqs_net_create(const naqs_net_config_t *cfg, int device, naqs_net_
     net->device = device;
     (void)naqs::poll_handle_create(device, &net->poll);
     net->ctl = net->poll.dev;
+    net->shared_gpu = naqs::env_int("NAQS_SHARED_GPU", 0) == 1;    // (naqs_net_share_device: the same switch per handle)
     net->cfg = *cfg;
     NetDims &d = net->dims;
     d.P = P;
@@ -2251,6 +2252,7 @@ NAQS_API int naqs_net_destroy(naqs_net_t *net) {
     if (net->d_info2) (void)hipFree(net->d_info2);
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->ev_phase_done) (void)hipEventDestroy(net->ev_phase_done);
     if (net->side_stream) (void)hipStreamDestroy(net->side_stream);
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_scales) (void)hipFree(net->d_scales);

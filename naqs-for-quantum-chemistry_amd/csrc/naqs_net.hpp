@@ -324,6 +324,12 @@ struct naqs_net {
     int64_t spec_hint = 0;                  // unique samples of the last accepted draw (0: none yet)
     int last_form_kind = 0, last_form_rb = 0, last_form_split = 0;      // what net_logpsi_impl launched last
     int64_t spec_launched = 0, spec_hits = 0;                           // naqs_net_spec_counts
+    // two runs per GPU (NAQS_SHARED_GPU=1 when the handle is created — the farm's `--per-gpu 2` sets it): this handle's sampler
+    // calls take turns with the other handles' of the device (naqs_sample.hip: lookback_turn_begin)
+    bool shared_gpu = false;
+    bool turn_held = false;                 // this handle holds the device's look-back turn
+    bool turn_caller_ends = false;          // ... and the sampler's caller ends it (sample_and_wait), not the sampler's entry point
+    int64_t lookback_turns = 0;             // sampler calls of this handle that had to wait for another handle's (naqs_net_share_device reports it)
     bool hold_finish = false;               // in: the sampler leaves its finish job pending (fin_job) instead of launching it
     bool fin_pending = false;               // a finish job nobody has launched or hosted yet (naqs::net_sample_finish_flush)
     naqs::SampleFinishJob fin_job{};
@@ -419,6 +425,11 @@ __device__ __forceinline__ float adam_update(const AdamArgs &a, const int64_t i,
 }
 #endif
 // naqs_sample.hip
+// NAQS_SHARED_GPU / naqs_net_share_device: the device's turn for look-back launches (naqs_sample.hip).  The sampler takes it before
+// its first look-back launch (net->turn_held); whoever waits for the draw ends it: sample_and_wait once the draw's size is known
+// (it sets net->turn_caller_ends around the call), the plain sampler entry points once their stream has drained
+void lookback_turn_begin(naqs_net *net);
+void lookback_turn_end(naqs_net *net);
 int net_sample_finish_flush(naqs_net *net, hipStream_t s);      // launch a pending finish job as a kernel of its own (no-op if none)
 int net_info_alloc(naqs_net *net);
 int net_sample_early(naqs_net *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev, int64_t *counts_dev,

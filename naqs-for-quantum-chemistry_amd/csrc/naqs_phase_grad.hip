@@ -809,6 +809,13 @@ static int sample_and_wait(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     const int64_t seq = ++net->info_seq;
     const bool prof = net->prof_samp.armed();              // (bench.py's train_step.sampler_us: every stride-th step)
     if (prof) { int stp = net->prof_samp.begin(s); if (stp != NAQS_OK) return stp; }
+    // two runs per GPU: the sampler takes the device's look-back turn before its level launches; it is given back here, when M is
+    // known (or this call fails) — naqs_sample.hip
+    struct Turn {
+        naqs_net_t *n;
+        explicit Turn(naqs_net_t *net_) : n(net_) { n->turn_caller_ends = true; }
+        ~Turn() { n->turn_caller_ends = false; naqs::lookback_turn_end(n); }
+    } turn(net);
     net->hold_finish = after != nullptr;
     int st = naqs::net_sample_early(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev,
                                     info_dev ? info_dev : net->d_info2, s,

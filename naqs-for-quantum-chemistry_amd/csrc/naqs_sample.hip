@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <atomic>
 #include <cstdio>
 
 #include "naqs_common.hpp"
@@ -907,9 +908,9 @@ int naqs::net_info_alloc(naqs_net *net) {
     return NAQS_OK;
 }
 
-static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
-                           int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream,
-                           int64_t *early = nullptr, int64_t seq = 0) {
+static int net_sample_enqueue(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                              int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream,
+                              int64_t *early, int64_t seq) {
     if (!net || n_samples < 0 || max_unique <= 0 || !keys_dev || !counts_dev || !info_dev) return NAQS_ERR_INVALID;
     if (!net->have_amp_weights) return NAQS_ERR_INVALID;
     if (n_samples > (1ll << 44) || max_unique >= (1ll << 31)) return NAQS_ERR_UNSUPPORTED;
@@ -1030,6 +1031,9 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
     // sizes are a hint read from mapped memory without synchronising (stale, or from another cap, at worst a slower cut);
     // the samples do not depend on the cut.  NAQS_SAMPLE_MULTI=1: always one level per launch.
     const int multi = fused_levels ? std::min(4, std::max(1, naqs::env_int("NAQS_SAMPLE_MULTI", 4))) : 1;
+    // two runs per GPU: the launches below wait across workgroups without a bound on the waiters — the device's turn (below;
+    // the head launch above needs none: one busy workgroup, and hosted waiters that only wait for jobs which wait for nobody)
+    if (n_first < d.P) naqs::lookback_turn_begin(net);
     int half = n_first & 1;                                // which half of the ping-pong arrays holds the level a launch starts at
     const int64_t multi3_max = naqs::env_int("NAQS_SAMPLE_MULTI3_MAX", 2048);
     volatile const int64_t *hint = net->h_info + 4;
@@ -1113,6 +1117,60 @@ static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, in
             std::fprintf(stderr, "\n");
         }
     }
+    return NAQS_OK;
+}
+
+// Two runs on one GPU (the farm's `--per-gpu 2`; NAQS_SHARED_GPU=1 when the handle is created): their samplers' look-back launches
+// can take TURNS on the device.  A look-back workgroup waits for every workgroup before it, which the dispatcher is certain to
+// have started only while ONE such launch is in flight (naqs_poll.hpp; DESIGN.md 4.13: dispatch is in index order per XCD, so
+// two launches of ~29 one-per-CU waiters per XCD can fill each other's XCDs and stand until their budgets expire).  A turn is
+// held on the HOST: from before the first look-back launch of a call is queued (behind its head launch, which goes ahead and
+// runs while the host waits for the turn) until the call's last level's size is known — naqs_vmc_step / naqs_vmc_run wait for
+// exactly that word anyway (sample_and_wait), and by then every word a look-back of the call can wait for has been published —
+// or, for the plain sampler calls, until the stream has drained.  A spin lock per device (a turn is tens of microseconds; a
+// sleeping lock's wake-up is longer than that), no event between the two queues: those hand-overs were measured first and cost
+// the farm 11 %.  The other launches of a step that wait inside (the column-split forward: at most 16
+// consumers per XCD, all behind their producers; the hosted re-pack: HOSTED_WAITING_WGS, behind jobs that wait for nobody) end
+// whatever runs beside them — a chain of depth two cannot close a cycle — and need no turn.
+namespace {
+constexpr int GATE_DEVICES = 64;
+std::atomic<const naqs_net *> g_lookback_holder[GATE_DEVICES];
+}  // namespace
+
+void naqs::lookback_turn_begin(naqs_net *net) {
+    if (!net->shared_gpu || net->turn_held || net->device < 0 || net->device >= GATE_DEVICES) return;
+    std::atomic<const naqs_net *> &h = g_lookback_holder[net->device];
+    bool waited = false;
+    for (const naqs_net *none = nullptr; !h.compare_exchange_weak(none, net, std::memory_order_acquire, std::memory_order_relaxed); none = nullptr) {
+        waited = true;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (waited) ++net->lookback_turns;
+    net->turn_held = true;
+}
+void naqs::lookback_turn_end(naqs_net *net) {
+    if (!net->turn_held) return;
+    net->turn_held = false;
+    g_lookback_holder[net->device].store(nullptr, std::memory_order_release);
+}
+
+static int net_sample_impl(naqs_net_t *net, int64_t n_samples, uint64_t seed, int64_t max_unique, uint64_t *keys_dev,
+                           int64_t *counts_dev, float *probs_dev, double *weights_dev, int64_t *info_dev, void *stream,
+                           int64_t *early = nullptr, int64_t seq = 0) {
+    int st = net_sample_enqueue(net, n_samples, seed, max_unique, keys_dev, counts_dev, probs_dev, weights_dev, info_dev, stream, early, seq);
+    if (net != nullptr && net->turn_held && !net->turn_caller_ends) {          // nobody above waits for this call: wait here
+        if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess && st == NAQS_OK) st = NAQS_ERR_HIP;
+        naqs::lookback_turn_end(net);
+    }
+    return st;
+}
+
+NAQS_API int naqs_net_share_device(naqs_net_t *net, int on, int64_t *turns) {
+    if (!net || on < -1 || on > 1) return NAQS_ERR_INVALID;
+    if (on >= 0) net->shared_gpu = on == 1;
+    if (turns) *turns = net->lookback_turns;
     return NAQS_OK;
 }
 

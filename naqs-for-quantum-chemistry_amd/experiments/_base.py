@@ -345,6 +345,9 @@ def _farm_launch(args, argv):
         if args.per_gpu > 1:
             # (NAQS_DEFER_PHASE=1 would give every replica a second stream of its own: a hardware queue too many — see below)
             env["NAQS_DEFER_PHASE"] = "0"
+            # the runs' sampler calls take turns on the device (include/naqs_hip.h: naqs_net_share_device): a
+            # look-back launch is only certain to end while it is the one such launch in flight
+            env.setdefault("NAQS_SHARED_GPU", "1")
         if args.per_gpu > 2:
             # more than two ACTIVE hardware queues are time-sliced in multi-millisecond quanta on this pool (k = 4 threads on
             # four queues: 3 000-step runs take 40-130 s instead of 9): let the runtime map the threads' streams onto two
@@ -379,8 +382,9 @@ def _farm_threads(args, job_ids):
     def one(j):
         # A run is seeded start to finish, so one that fails because a device-side wait ran out of its budget (NAQS_ERR_HIP,
         # "... wait timed out ...": csrc/naqs_poll.hpp) is simply started again — same numbers.  With two runs per GPU their
-        # launches' waiting workgroups can, rarely, hold each other's slots until both budgets expire; anything
-        # else, and a third failure, is raised.
+        # launches' waiting workgroups could hold each other's slots until both budgets expire (the samplers now take
+        # turns, NAQS_SHARED_GPU=1, which closes the one exposure found; the restart stays as the net under it); anything else,
+        # and a third failure, is raised.
         from naqs_amd._lib import NaqsError
         mol, seed = jobs[j]
         for tries_left in (2, 1, 0):

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(os.path.dirname(_HERE), "lib")
 
 NAQS_OK = 0
-ABI_VERSION = 8          # NAQS_ABI_VERSION of include/naqs_hip.h
+ABI_VERSION = 9          # NAQS_ABI_VERSION of include/naqs_hip.h
 PSI_F32, PSI_F64, LOGPSI_F32, LOGPSI_F64 = 0, 1, 2, 3
 
 c_i64, c_u64p, c_f64p, c_vp = ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
@@ -69,6 +69,7 @@ SIGNATURES = {
     "naqs_net_prof_select": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "naqs_launch_count": (c_i64, []),
     "naqs_net_spec_counts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    "naqs_net_share_device": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(c_i64)]),
     "naqs_shard_proof": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp]),
     "naqs_vmc_shard_sample_forward": (ctypes.c_int, [c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),

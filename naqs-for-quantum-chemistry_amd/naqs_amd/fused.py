@@ -633,6 +633,15 @@ class FusedLogPsi:
         _lib.check(self._lib.naqs_net_last_kernel(self._h, buf, 128), "naqs_net_last_kernel")
         return buf.value.decode()
 
+    def share_device(self, on=None):
+        """Two runs per GPU (the farm's `--per-gpu 2`): this handle's sampler calls take turns with those of the device's other
+        sharing handles (`naqs_net_share_device`; default NAQS_SHARED_GPU when the handle was created).  `on=None` only reads.
+        -> sampler calls so far that had to wait for another handle's turn to end."""
+        turns = ctypes.c_int64(0)
+        _lib.check(self._lib.naqs_net_share_device(self._h, -1 if on is None else int(bool(on)), ctypes.byref(turns)),
+                   "naqs_net_share_device")
+        return turns.value
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.naqs_net_destroy(self._h)

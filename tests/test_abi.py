@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.lib_path())
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert _lib.load_library().naqs_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.load_library().naqs_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_strerror_and_device_count():

@@ -190,3 +190,32 @@ def test_farm_restarts_a_run_that_lost_a_launch_to_an_expired_wait(monkeypatch, 
         with pytest.raises(NaqsError):
             _base._farm_threads(ns, [0])
         assert len(calls) == n_calls
+
+
+def test_farm_launcher_tells_two_runs_per_gpu_to_share_the_device(monkeypatch, capsys):
+    """`--per-gpu 2`: the workers are started with NAQS_SHARED_GPU=1 (their handles' sampler calls take turns on the device,
+    include/naqs_hip.h: naqs_net_share_device) unless the caller set it; one run per GPU: not at all."""
+    import argparse
+    from experiments import _base
+    seen = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            seen.append(env)
+
+        def wait(self):
+            return 0
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("NAQS_SHARED_GPU", raising=False)
+    ns = argparse.Namespace(molecule="LiH,H2O", seeds=None, seed=1, farm_gpus=1, per_gpu=2)
+    _base._farm_launch(ns, ["-m", "LiH,H2O", "--farm", "--per-gpu", "2"])
+    assert seen[-1]["NAQS_SHARED_GPU"] == "1" and seen[-1]["NAQS_DEFER_PHASE"] == "0"
+    monkeypatch.setenv("NAQS_SHARED_GPU", "0")
+    _base._farm_launch(ns, ["-m", "LiH,H2O", "--farm", "--per-gpu", "2"])
+    assert seen[-1]["NAQS_SHARED_GPU"] == "0"
+    monkeypatch.delenv("NAQS_SHARED_GPU")
+    ns.per_gpu = 1
+    _base._farm_launch(ns, ["-m", "LiH,H2O", "--farm"])
+    assert "NAQS_SHARED_GPU" not in seen[-1]

@@ -242,3 +242,50 @@ def test_group_draws_on_the_device_match_the_binomial_pmf(group):
     _lib.check(lib.naqs_rng_binomial_device(group, C, n.data_ptr(), p.data_ptr(), ctypes.c_uint64(20260000 + group), reps,
                                             out2.data_ptr(), torch.cuda.current_stream().cuda_stream), "naqs_rng_binomial_device")
     assert torch.equal(out, out2)
+
+
+def test_sampler_calls_of_two_handles_sharing_a_gpu_take_turns_and_draw_the_same():
+    """Round 6 (`naqs_net_share_device`; the farm's `--per-gpu 2` sets NAQS_SHARED_GPU=1): two handles driven from two threads on
+    two streams of one GPU.  A look-back launch is only certain to end while it is the one such launch in flight, so the handles'
+    sampler calls take turns (a host-side turn per device, held until the call's stream has drained).  The draws are those of each
+    handle alone, and the calls really were ordered: with both threads sampling in a loop, somebody has had to wait for a turn."""
+    import threading
+    from test_nade import make_wf
+    from naqs_amd.fused import FusedLogPsi
+    z = golden("nade_N2.npz")
+    handles = [FusedLogPsi(make_wf("N2", z, device="cuda")[1]) for _ in range(2)]
+    seeds = [100 + i for i in range(40)]
+    alone = [[tuple(t.clone() for t in f.sample(10 ** 8, seed=s, max_unique=100000)) for s in seeds[:4]] for f in handles]
+    torch.cuda.synchronize()
+    assert [f.share_device() for f in handles] == [0, 0]                      # off by default: nobody waited for anybody
+    for f in handles:
+        f.share_device(True)
+    got, errors = [[], []], []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream(device="cuda")):
+                start.wait()
+                for s in seeds:
+                    got[i].append(tuple(t.clone() for t in handles[i].sample(10 ** 8, seed=s, max_unique=100000)))
+                torch.cuda.current_stream().synchronize()
+        except Exception as exc:                                                  # noqa: BLE001 (reported below)
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for a, b in zip(alone[i], got[i][:4]):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+    turns = [f.share_device() for f in handles]
+    assert 1 <= sum(turns) <= 2 * len(seeds), turns
+    handles[0].share_device(False)                                               # off again: its calls go straight ahead
+    before = handles[0].share_device()
+    handles[0].sample(10 ** 8, seed=1, max_unique=100000)
+    assert handles[0].share_device() == before
