@@ -267,7 +267,7 @@ def test_sampler_calls_of_two_handles_sharing_a_gpu_take_turns_and_draw_the_same
         try:
             torch.cuda.set_device(0)
             with torch.cuda.stream(torch.cuda.Stream(device="cuda")):
-                start.wait()
+                start.wait(timeout=120)
                 for s in seeds:
                     got[i].append(tuple(t.clone() for t in handles[i].sample(10 ** 8, seed=s, max_unique=100000)))
                 torch.cuda.current_stream().synchronize()
