@@ -31,7 +31,7 @@ PMC="$ISSUE" pmc pmc_issue_li2o $L
 PMC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" pmc pmc_wait_n2 $B
 PMC="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" pmc pmc_mfma_n2 $B
 # the log-psi kernel's vector-memory path (TA / TCP / TD / TCC, two counters per block and pass)
-# (SKIP_PHASE_MEM=1: rounds in which that kernel did not change keep the earlier pass — ten counter passes are up to 25 minutes)
+# (SKIP_PHASE_MEM=1: rounds in which that kernel did not change keep the earlier pass — ten counter passes; 20 s when every pass goes through, 150 s for each one that hangs)
 if [ "${SKIP_PHASE_MEM:-0}" != "1" ]; then ( cd $R && bash tools/pmc_phase_mem.sh > $G/pmc_phase_mem.txt 2>&1 ); fi
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_train -o train -- python3 $R/tools/train_loop_profile.py > $G/prof_train.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $G/prof_train_h2o -o train -- python3 $R/tools/train_loop_profile.py $R/tests/golden/ham_H2O.npz 1000000 300 40 > $G/prof_train_h2o.log 2>&1
